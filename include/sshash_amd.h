@@ -1,0 +1,153 @@
+/* sshash_amd.h -- C ABI of the MI355X-native batched k-mer Lookup engine for SSHash.
+ *
+ * The reference (jermp/sshash) has no FFI layer: its boundary for this path is the C++ class
+ * `sshash::dictionary<Kmer, Offsets>` (reference include/dictionary.hpp:10-181). Each entry
+ * point below names the reference interface it stands in for. Conventions:
+ *   - opaque handle, plain pointers and sizes, no exceptions across the ABI;
+ *   - every function returns an sshash_status; sshash_last_error() gives the message of the
+ *     last failure on the calling thread;
+ *   - "not found" is NOT an error: kmer_id == SSHASH_INVALID_U64 (include/constants.hpp:5);
+ *   - lookups run on the GPU only. Without a visible HIP device they fail with
+ *     SSHASH_ERR_NO_DEVICE; there is no CPU fallback.
+ *   - k-mers are 2-bit packed, first base in the least-significant bits, A=0 C=1 T=2 G=3
+ *     (include/kmer.hpp:80,194); W = 1 64-bit word per k-mer for k <= 31, W = 2 for k <= 63.
+ */
+#ifndef SSHASH_AMD_H
+#define SSHASH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSHASH_INVALID_U64 UINT64_MAX
+
+typedef enum sshash_status {
+    SSHASH_OK = 0,
+    SSHASH_ERR_ARGUMENT = 1,  /* null pointer, bad k/m, id out of range ...                    */
+    SSHASH_ERR_IO = 2,        /* "error in opening the file" (src/query.cpp:128, tools/build.cpp) */
+    SSHASH_ERR_FORMAT = 3,    /* not an index file / corrupt                                     */
+    SSHASH_ERR_VERSION = 4,   /* "MAJOR index version mismatch" (include/util.hpp:191-195)       */
+    SSHASH_ERR_NO_DEVICE = 5, /* no HIP device visible, or dictionary not resident on the device  */
+    SSHASH_ERR_HIP = 6,       /* a HIP runtime call failed                                       */
+    SSHASH_ERR_BUILD = 7,     /* index construction failed                                       */
+    SSHASH_ERR_INTERNAL = 8
+} sshash_status;
+
+typedef struct sshash_dict sshash_dict; /* stands for sshash::dictionary_type (include/dictionary_types.hpp:9) */
+
+/* build_configuration (include/util.hpp:143-159); zero-initialise then override. */
+typedef struct sshash_build_config {
+    uint32_t k;           /* default 31 */
+    uint32_t m;           /* default 20 */
+    uint64_t seed;        /* default 1  */
+    uint32_t canonical;   /* default 0  */
+    uint32_t num_threads; /* default 1; 0 = hardware concurrency */
+    double lambda;        /* default 5.0 */
+    uint32_t verbose;
+    uint32_t reserved;
+} sshash_build_config;
+
+/* accessors of dictionary (include/dictionary.hpp:31-38) */
+typedef struct sshash_info {
+    uint8_t version[3];
+    uint8_t canonical;
+    uint32_t k, m;
+    uint32_t words_per_kmer;
+    uint64_t num_kmers, num_strings, num_bases, num_minimizers;
+    uint64_t num_bits;      /* dictionary::num_bits(), host representation */
+    uint32_t skew_partitions;
+    uint32_t reserved;
+} sshash_info;
+
+/* lookup_result (include/util.hpp:38-62) as a struct of arrays: one entry per query.
+ * kmer_id is mandatory for sshash_lookup_*; any other pointer may be NULL (field not produced).
+ * A query that is not found has every u64 field == SSHASH_INVALID_U64. */
+typedef struct sshash_results {
+    uint64_t* kmer_id;
+    uint64_t* kmer_id_in_string;
+    uint64_t* kmer_offset;
+    uint64_t* string_id;
+    uint64_t* string_begin;
+    uint64_t* string_end;
+    int8_t* kmer_orientation;  /* +1 forward, -1 backward (include/constants.hpp:17-18) */
+    uint8_t* minimizer_found;
+} sshash_results;
+
+/* streaming_query_report (include/util.hpp:21-36) */
+typedef struct sshash_streaming_report {
+    uint64_t num_kmers;
+    uint64_t num_positive_kmers;
+    uint64_t num_negative_kmers;
+    uint64_t num_invalid_kmers;
+    uint64_t num_searches;
+    uint64_t num_extensions;
+} sshash_streaming_report;
+
+const char* sshash_last_error(void);
+void sshash_build_config_default(sshash_build_config* cfg);
+
+/* ---- construction / persistence: dictionary::build (src/builder/build.cpp:10-28),
+ *      essentials::save / load (tools/build.cpp:90-95, tools/common.hpp:19-22) ------------- */
+sshash_status sshash_build_from_fasta(const char* filename, const sshash_build_config* cfg, sshash_dict** out);
+/* strings already 2-bit packed back to back: `words` holds endpoints[num_strings] bases. */
+sshash_status sshash_build_from_packed(const uint64_t* words, const uint64_t* endpoints, uint64_t num_strings,
+                                       const sshash_build_config* cfg, sshash_dict** out);
+sshash_status sshash_save(const sshash_dict* d, const char* filename);
+sshash_status sshash_load(const char* filename, sshash_dict** out);
+void sshash_free(sshash_dict* d);
+sshash_status sshash_get_info(const sshash_dict* d, sshash_info* info);
+
+/* ---- device residency (no reference counterpart: the reference is host-only) ------------- */
+int sshash_device_count(void);
+sshash_status sshash_to_device(sshash_dict* d, int device);
+sshash_status sshash_device_bytes(const sshash_dict* d, int device, uint64_t* bytes);
+
+/* ---- dictionary::lookup(Kmer, bool) / lookup(char const*, bool): include/dictionary.hpp:41-42,
+ *      src/dictionary.cpp:58-78. Batched. ------------------------------------------------------
+ * *_device: `kmers` and every non-NULL array of `out` are DEVICE pointers in the HBM of `device`;
+ *           the launch is asynchronous on `hip_stream` (hipStream_t as void*, NULL = default stream).
+ * host variants: caller-owned host buffers; the batch is sharded over all resident devices.    */
+sshash_status sshash_lookup_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                          int check_reverse_complement, const sshash_results* out, void* hip_stream);
+sshash_status sshash_lookup_ascii_device(const sshash_dict* d, int device, const char* kmers, uint64_t n,
+                                         int check_reverse_complement, const sshash_results* out, void* hip_stream);
+sshash_status sshash_lookup_packed(const sshash_dict* d, const uint64_t* kmers, uint64_t n, int check_reverse_complement,
+                                   const sshash_results* out);
+sshash_status sshash_lookup_ascii(const sshash_dict* d, const char* kmers, uint64_t n, int check_reverse_complement,
+                                  const sshash_results* out);
+
+/* ---- dictionary::is_member: include/dictionary.hpp:75-76, src/dictionary.cpp:80-88 -------- */
+sshash_status sshash_is_member_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                             int check_reverse_complement, uint8_t* out, void* hip_stream);
+sshash_status sshash_is_member_packed(const sshash_dict* d, const uint64_t* kmers, uint64_t n, int check_reverse_complement,
+                                      uint8_t* out);
+sshash_status sshash_is_member_ascii(const sshash_dict* d, const char* kmers, uint64_t n, int check_reverse_complement,
+                                     uint8_t* out);
+
+/* ---- dictionary::access (include/dictionary.hpp:69, src/dictionary.cpp:90-94): host side,
+ *      used to draw positive queries as tools/perf.hpp:38-51 does ---------------------------- */
+sshash_status sshash_access(const sshash_dict* d, uint64_t kmer_id, char* out_k_chars);
+sshash_status sshash_access_packed(const sshash_dict* d, const uint64_t* kmer_ids, uint64_t n, uint64_t* out_words);
+
+/* ---- dictionary::streaming_query_from_file (include/dictionary.hpp:81-82, src/query.cpp:118-175)
+ *      and streaming_query<Dict,canonical> over reads in memory (include/streaming_query.hpp) -- */
+sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char* filename, int multiline,
+                                               sshash_streaming_report* report);
+/* reads stored back to back: read r = bases[read_offsets[r] .. read_offsets[r+1]) ; host buffers */
+sshash_status sshash_streaming_query(const sshash_dict* d, const char* bases, const uint64_t* read_offsets,
+                                     uint64_t num_reads, sshash_streaming_report* report);
+/* device buffers; `report` is a device pointer to 6 uint64 counters, accumulated into */
+sshash_status sshash_streaming_query_device(const sshash_dict* d, int device, const char* bases,
+                                            const uint64_t* read_offsets, uint64_t num_reads, uint64_t* report,
+                                            void* hip_stream);
+
+/* ---- tuning knob for experiments: maximum workgroups per launch (0 = default) ------------- */
+sshash_status sshash_set_max_blocks(sshash_dict* d, uint32_t max_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSHASH_AMD_H */

@@ -1,0 +1,382 @@
+"""ctypes binding of include/sshash_amd.h. Host-side mirror of the reference's dictionary interface."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Iterable, Optional, Sequence, Union
+
+import numpy as np
+
+INVALID_U64 = 0xFFFFFFFFFFFFFFFF  # reference include/constants.hpp:5
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libsshash_amd.so"
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+class SSHashError(RuntimeError):
+    """Raised for every non-OK sshash_status; ``.status`` holds the code (include/sshash_amd.h)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[sshash status {status}] {message}")
+        self.status = status
+
+
+class _BuildConfig(C.Structure):
+    _fields_ = [
+        ("k", C.c_uint32),
+        ("m", C.c_uint32),
+        ("seed", C.c_uint64),
+        ("canonical", C.c_uint32),
+        ("num_threads", C.c_uint32),
+        ("lambda_", C.c_double),
+        ("verbose", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class _Info(C.Structure):
+    _fields_ = [
+        ("version", C.c_uint8 * 3),
+        ("canonical", C.c_uint8),
+        ("k", C.c_uint32),
+        ("m", C.c_uint32),
+        ("words_per_kmer", C.c_uint32),
+        ("num_kmers", C.c_uint64),
+        ("num_strings", C.c_uint64),
+        ("num_bases", C.c_uint64),
+        ("num_minimizers", C.c_uint64),
+        ("num_bits", C.c_uint64),
+        ("skew_partitions", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class _Results(C.Structure):
+    _fields_ = [
+        ("kmer_id", C.c_void_p),
+        ("kmer_id_in_string", C.c_void_p),
+        ("kmer_offset", C.c_void_p),
+        ("string_id", C.c_void_p),
+        ("string_begin", C.c_void_p),
+        ("string_end", C.c_void_p),
+        ("kmer_orientation", C.c_void_p),
+        ("minimizer_found", C.c_void_p),
+    ]
+
+
+class _Report(C.Structure):
+    _fields_ = [
+        ("num_kmers", C.c_uint64),
+        ("num_positive_kmers", C.c_uint64),
+        ("num_negative_kmers", C.c_uint64),
+        ("num_invalid_kmers", C.c_uint64),
+        ("num_searches", C.c_uint64),
+        ("num_extensions", C.c_uint64),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def _load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C sshash_amd/csrc`). "
+            "There is no pure-Python / CPU fallback for the lookup path."
+        )
+    lib = C.CDLL(path)
+    P = C.c_void_p
+    sigs = {
+        "sshash_last_error": (C.c_char_p, []),
+        "sshash_build_config_default": (None, [C.POINTER(_BuildConfig)]),
+        "sshash_build_from_fasta": (C.c_int, [C.c_char_p, C.POINTER(_BuildConfig), C.POINTER(P)]),
+        "sshash_build_from_packed": (C.c_int, [P, P, C.c_uint64, C.POINTER(_BuildConfig), C.POINTER(P)]),
+        "sshash_save": (C.c_int, [P, C.c_char_p]),
+        "sshash_load": (C.c_int, [C.c_char_p, C.POINTER(P)]),
+        "sshash_free": (None, [P]),
+        "sshash_get_info": (C.c_int, [P, C.POINTER(_Info)]),
+        "sshash_device_count": (C.c_int, []),
+        "sshash_to_device": (C.c_int, [P, C.c_int]),
+        "sshash_device_bytes": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64)]),
+        "sshash_lookup_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
+        "sshash_lookup_ascii_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
+        "sshash_lookup_packed": (C.c_int, [P, P, C.c_uint64, C.c_int, C.POINTER(_Results)]),
+        "sshash_lookup_ascii": (C.c_int, [P, P, C.c_uint64, C.c_int, C.POINTER(_Results)]),
+        "sshash_is_member_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, P, P]),
+        "sshash_is_member_packed": (C.c_int, [P, P, C.c_uint64, C.c_int, P]),
+        "sshash_is_member_ascii": (C.c_int, [P, P, C.c_uint64, C.c_int, P]),
+        "sshash_access": (C.c_int, [P, C.c_uint64, P]),
+        "sshash_access_packed": (C.c_int, [P, P, C.c_uint64, P]),
+        "sshash_streaming_query_from_file": (C.c_int, [P, C.c_char_p, C.c_int, C.POINTER(_Report)]),
+        "sshash_streaming_query": (C.c_int, [P, P, P, C.c_uint64, C.POINTER(_Report)]),
+        "sshash_streaming_query_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, P, P]),
+        "sshash_set_max_blocks": (C.c_int, [P, C.c_uint32]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI symbol missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+C_ABI_SYMBOLS = (
+    "sshash_last_error sshash_build_config_default sshash_build_from_fasta sshash_build_from_packed sshash_save "
+    "sshash_load sshash_free sshash_get_info sshash_device_count sshash_to_device sshash_device_bytes "
+    "sshash_lookup_packed_device sshash_lookup_ascii_device sshash_lookup_packed sshash_lookup_ascii "
+    "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
+    "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device sshash_set_max_blocks"
+).split()
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        raise SSHashError(status, _load().sshash_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    return int(_load().sshash_device_count())
+
+
+@dataclass
+class LookupResult:
+    """Struct-of-arrays form of lookup_result (reference include/util.hpp:38-62)."""
+
+    kmer_id: np.ndarray
+    kmer_id_in_string: Optional[np.ndarray] = None
+    kmer_offset: Optional[np.ndarray] = None
+    kmer_orientation: Optional[np.ndarray] = None
+    string_id: Optional[np.ndarray] = None
+    string_begin: Optional[np.ndarray] = None
+    string_end: Optional[np.ndarray] = None
+    minimizer_found: Optional[np.ndarray] = None
+
+
+@dataclass
+class StreamingQueryReport:
+    """streaming_query_report (reference include/util.hpp:21-36)."""
+
+    num_kmers: int = 0
+    num_positive_kmers: int = 0
+    num_negative_kmers: int = 0
+    num_invalid_kmers: int = 0
+    num_searches: int = 0
+    num_extensions: int = 0
+
+
+def encode_kmers(kmers: Sequence[Union[str, bytes]], k: int) -> np.ndarray:
+    """ASCII k-mers -> contiguous (n, k) uint8 array as the *_ascii entry points expect."""
+    buf = bytearray()
+    for s in kmers:
+        b = s.encode("ascii") if isinstance(s, str) else bytes(s)
+        if len(b) < k:
+            raise ValueError(f"k-mer shorter than k={k}: {s!r}")
+        buf += b[:k]
+    return np.frombuffer(bytes(buf), dtype=np.uint8).reshape(len(kmers), k)
+
+
+KmerBatch = Union[np.ndarray, Sequence[str], Sequence[bytes], str, bytes]
+
+
+class Dictionary:
+    """Handle on one SSHash dictionary (host index + optional HBM replicas)."""
+
+    def __init__(self, handle: int):
+        self._h = C.c_void_p(handle)
+        info = _Info()
+        _check(_load().sshash_get_info(self._h, C.byref(info)))
+        self._info = info
+
+    # ---- construction / persistence ------------------------------------------------------
+    @staticmethod
+    def _config(k, m, seed, canonical, num_threads, lambda_, verbose) -> _BuildConfig:
+        cfg = _BuildConfig()
+        _load().sshash_build_config_default(C.byref(cfg))
+        cfg.k, cfg.m, cfg.seed = int(k), int(m), int(seed)
+        cfg.canonical = 1 if canonical else 0
+        cfg.num_threads = int(num_threads)
+        cfg.lambda_ = float(lambda_)
+        cfg.verbose = 1 if verbose else 0
+        return cfg
+
+    @classmethod
+    def build(cls, input_filename: str, k: int = 31, m: int = 20, seed: int = 1, canonical: bool = False,
+              num_threads: int = 0, lambda_: float = 5.0, verbose: bool = False) -> "Dictionary":
+        """dictionary::build(input_filename, build_configuration) -- reference include/dictionary.hpp:28."""
+        cfg = cls._config(k, m, seed, canonical, num_threads, lambda_, verbose)
+        h = C.c_void_p()
+        _check(_load().sshash_build_from_fasta(os.fsencode(input_filename), C.byref(cfg), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def build_from_packed(cls, words: np.ndarray, endpoints: np.ndarray, k: int = 31, m: int = 20, seed: int = 1,
+                          canonical: bool = False, num_threads: int = 0, lambda_: float = 5.0,
+                          verbose: bool = False) -> "Dictionary":
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        endpoints = np.ascontiguousarray(endpoints, dtype=np.uint64)
+        need = (2 * int(endpoints[-1]) + 63) // 64
+        if words.size < need:
+            raise ValueError("packed words shorter than endpoints[-1] bases")
+        cfg = cls._config(k, m, seed, canonical, num_threads, lambda_, verbose)
+        h = C.c_void_p()
+        _check(_load().sshash_build_from_packed(words.ctypes.data, endpoints.ctypes.data, endpoints.size - 1,
+                                                C.byref(cfg), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def load(cls, index_filename: str) -> "Dictionary":
+        h = C.c_void_p()
+        _check(_load().sshash_load(os.fsencode(index_filename), C.byref(h)))
+        return cls(h.value)
+
+    def save(self, index_filename: str) -> None:
+        _check(_load().sshash_save(self._h, os.fsencode(index_filename)))
+
+    def close(self) -> None:
+        if self._h:
+            _load().sshash_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- accessors (reference include/dictionary.hpp:31-38) --------------------------------
+    def k(self) -> int: return int(self._info.k)
+    def m(self) -> int: return int(self._info.m)
+    def canonical(self) -> bool: return bool(self._info.canonical)
+    def num_kmers(self) -> int: return int(self._info.num_kmers)
+    def num_strings(self) -> int: return int(self._info.num_strings)
+    def num_bases(self) -> int: return int(self._info.num_bases)
+    def num_minimizers(self) -> int: return int(self._info.num_minimizers)
+    def num_bits(self) -> int: return int(self._info.num_bits)
+    def words_per_kmer(self) -> int: return int(self._info.words_per_kmer)
+    def vnum(self): return tuple(self._info.version)
+
+    # ---- device residency -----------------------------------------------------------------
+    def to_device(self, device: int = 0) -> "Dictionary":
+        _check(_load().sshash_to_device(self._h, int(device)))
+        return self
+
+    def device_bytes(self, device: int = 0) -> int:
+        out = C.c_uint64()
+        _check(_load().sshash_device_bytes(self._h, int(device), C.byref(out)))
+        return int(out.value)
+
+    def set_max_blocks(self, n: int) -> None:
+        _check(_load().sshash_set_max_blocks(self._h, int(n)))
+
+    # ---- lookups ---------------------------------------------------------------------------
+    def _as_batch(self, kmers: KmerBatch):
+        """-> (is_ascii, contiguous ndarray, n)"""
+        if isinstance(kmers, (str, bytes)):
+            kmers = [kmers]
+        if isinstance(kmers, np.ndarray) and kmers.dtype == np.uint64:
+            a = np.ascontiguousarray(kmers)
+            w = self.words_per_kmer()
+            if a.size % w:
+                raise ValueError("packed k-mer array length is not a multiple of words_per_kmer")
+            return False, a, a.size // w
+        if isinstance(kmers, np.ndarray) and kmers.dtype == np.uint8:
+            a = np.ascontiguousarray(kmers)
+            if a.size % self.k():
+                raise ValueError("ASCII k-mer buffer length is not a multiple of k")
+            return True, a, a.size // self.k()
+        a = encode_kmers(list(kmers), self.k())
+        return True, np.ascontiguousarray(a), a.shape[0]
+
+    def lookup(self, kmers: KmerBatch, check_reverse_complement: bool = True, full: bool = False) -> LookupResult:
+        """Batched dictionary::lookup (reference src/dictionary.cpp:58-78). Host buffers in/out."""
+        is_ascii, a, n = self._as_batch(kmers)
+        res = LookupResult(kmer_id=np.empty(n, dtype=np.uint64))
+        r = _Results()
+        r.kmer_id = res.kmer_id.ctypes.data
+        if full:
+            for name in ("kmer_id_in_string", "kmer_offset", "string_id", "string_begin", "string_end"):
+                arr = np.empty(n, dtype=np.uint64)
+                setattr(res, name, arr)
+                setattr(r, name, arr.ctypes.data)
+            res.kmer_orientation = np.empty(n, dtype=np.int8)
+            res.minimizer_found = np.empty(n, dtype=np.uint8)
+            r.kmer_orientation = res.kmer_orientation.ctypes.data
+            r.minimizer_found = res.minimizer_found.ctypes.data
+        fn = _load().sshash_lookup_ascii if is_ascii else _load().sshash_lookup_packed
+        _check(fn(self._h, a.ctypes.data, n, 1 if check_reverse_complement else 0, C.byref(r)))
+        return res
+
+    def is_member(self, kmers: KmerBatch, check_reverse_complement: bool = True) -> np.ndarray:
+        """Batched dictionary::is_member (reference src/dictionary.cpp:80-88)."""
+        is_ascii, a, n = self._as_batch(kmers)
+        out = np.empty(n, dtype=np.uint8)
+        fn = _load().sshash_is_member_ascii if is_ascii else _load().sshash_is_member_packed
+        _check(fn(self._h, a.ctypes.data, n, 1 if check_reverse_complement else 0, out.ctypes.data))
+        return out.astype(bool)
+
+    def lookup_device(self, device: int, d_kmers: int, n: int, d_kmer_id: int, check_reverse_complement: bool = True,
+                      stream: int = 0, ascii_input: bool = False, **optional_outputs: int) -> None:
+        """Device-pointer entry point: all pointers are raw HBM addresses (e.g. torch ``.data_ptr()``)."""
+        r = _Results()
+        r.kmer_id = d_kmer_id
+        for name, ptr in optional_outputs.items():
+            setattr(r, name, ptr)
+        fn = _load().sshash_lookup_ascii_device if ascii_input else _load().sshash_lookup_packed_device
+        _check(fn(self._h, int(device), C.c_void_p(d_kmers), int(n), 1 if check_reverse_complement else 0, C.byref(r),
+                  C.c_void_p(stream)))
+
+    def is_member_device(self, device: int, d_kmers: int, n: int, d_out: int, check_reverse_complement: bool = True,
+                         stream: int = 0) -> None:
+        _check(_load().sshash_is_member_packed_device(self._h, int(device), C.c_void_p(d_kmers), int(n),
+                                                      1 if check_reverse_complement else 0, C.c_void_p(d_out),
+                                                      C.c_void_p(stream)))
+
+    # ---- access (host) ----------------------------------------------------------------------
+    def access(self, kmer_id: int) -> str:
+        buf = C.create_string_buffer(self.k())
+        _check(_load().sshash_access(self._h, int(kmer_id), buf))
+        return buf.raw.decode("ascii")
+
+    def access_packed(self, kmer_ids: Iterable[int]) -> np.ndarray:
+        ids = np.ascontiguousarray(np.asarray(kmer_ids, dtype=np.uint64))
+        out = np.empty(ids.size * self.words_per_kmer(), dtype=np.uint64)
+        _check(_load().sshash_access_packed(self._h, ids.ctypes.data, ids.size, out.ctypes.data))
+        return out
+
+    # ---- streaming query ----------------------------------------------------------------------
+    @staticmethod
+    def _report(r: _Report) -> StreamingQueryReport:
+        return StreamingQueryReport(r.num_kmers, r.num_positive_kmers, r.num_negative_kmers, r.num_invalid_kmers,
+                                    r.num_searches, r.num_extensions)
+
+    def streaming_query_from_file(self, filename: str, multiline: bool = False) -> StreamingQueryReport:
+        """dictionary::streaming_query_from_file (reference include/dictionary.hpp:81-82, src/query.cpp:118-175)."""
+        r = _Report()
+        _check(_load().sshash_streaming_query_from_file(self._h, os.fsencode(filename), 1 if multiline else 0, C.byref(r)))
+        return self._report(r)
+
+    def streaming_query(self, reads: Sequence[Union[str, bytes]]) -> StreamingQueryReport:
+        """One streaming_query per read (reset between reads), reads given in memory."""
+        chunks = [s.encode("ascii", "replace") if isinstance(s, str) else bytes(s) for s in reads]
+        offsets = np.zeros(len(chunks) + 1, dtype=np.uint64)
+        if chunks:
+            offsets[1:] = np.cumsum([len(c) for c in chunks], dtype=np.uint64)
+        bases = np.frombuffer(b"".join(chunks) or b"\0", dtype=np.uint8)
+        r = _Report()
+        _check(_load().sshash_streaming_query(self._h, bases.ctypes.data, offsets.ctypes.data, len(chunks), C.byref(r)))
+        return self._report(r)
+
+    def streaming_query_device(self, device: int, d_bases: int, d_read_offsets: int, num_reads: int, d_report: int,
+                               stream: int = 0) -> None:
+        _check(_load().sshash_streaming_query_device(self._h, int(device), C.c_void_p(d_bases), C.c_void_p(d_read_offsets),
+                                                     int(num_reads), C.c_void_p(d_report), C.c_void_p(stream)))

@@ -1,0 +1,306 @@
+// capi.cpp -- the C ABI declared in include/sshash_amd.h (thin shim over engine / index).
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+
+#include "../../include/sshash_amd.h"
+#include "engine.hpp"
+#include "reads.hpp"
+
+using namespace sshash_amd;
+
+struct sshash_dict {
+    std::shared_ptr<host_index> idx;
+    std::unique_ptr<engine> eng;
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+sshash_status fail(sshash_status s, std::string const& msg) {
+    g_last_error = msg;
+    return s;
+}
+
+sshash_status classify(std::exception const& e) {
+    const std::string m = e.what();
+    g_last_error = m;
+    if (m.find("MAJOR index version") != std::string::npos) return SSHASH_ERR_VERSION;
+    if (m.find("error in opening") != std::string::npos || m.find("cannot open") != std::string::npos ||
+        m.find("write error") != std::string::npos)
+        return SSHASH_ERR_IO;
+    if (m.find("index file") != std::string::npos) return SSHASH_ERR_FORMAT;
+    if (m.find("no HIP device") != std::string::npos || m.find("not resident") != std::string::npos ||
+        m.find("invalid device") != std::string::npos)
+        return SSHASH_ERR_NO_DEVICE;
+    if (m.find("HIP error") != std::string::npos) return SSHASH_ERR_HIP;
+    if (m.find("mphf") != std::string::npos || m.find("shorter than k") != std::string::npos ||
+        m.find("must be") != std::string::npos || m.find("no sequences") != std::string::npos)
+        return SSHASH_ERR_BUILD;
+    if (m.find("out of range") != std::string::npos || m.find("null") != std::string::npos) return SSHASH_ERR_ARGUMENT;
+    return SSHASH_ERR_INTERNAL;
+}
+
+template <typename Fn>
+sshash_status guarded(Fn&& fn) {
+    try {
+        fn();
+        return SSHASH_OK;
+    } catch (std::exception const& e) { return classify(e); } catch (...) {
+        return fail(SSHASH_ERR_INTERNAL, "unknown exception");
+    }
+}
+
+build_options to_options(sshash_build_config const* cfg) {
+    build_options o;
+    if (cfg) {
+        if (cfg->k) o.k = cfg->k;
+        if (cfg->m) o.m = cfg->m;
+        o.seed = cfg->seed;
+        o.canonical = cfg->canonical != 0;
+        o.num_threads = cfg->num_threads ? cfg->num_threads : std::max(1u, std::thread::hardware_concurrency());
+        if (cfg->lambda > 0) o.lambda = cfg->lambda;
+        o.verbose = cfg->verbose != 0;
+    }
+    return o;
+}
+
+sshash_dict* wrap(std::shared_ptr<host_index> idx) {
+    auto* d = new sshash_dict;
+    d->idx = std::move(idx);
+    d->eng = std::make_unique<engine>(d->idx);
+    return d;
+}
+
+result_view to_view(sshash_results const* r) {
+    result_view v{};
+    if (r) {
+        v.kmer_id = r->kmer_id;
+        v.kmer_id_in_string = r->kmer_id_in_string;
+        v.kmer_offset = r->kmer_offset;
+        v.string_id = r->string_id;
+        v.string_begin = r->string_begin;
+        v.string_end = r->string_end;
+        v.kmer_orientation = r->kmer_orientation;
+        v.minimizer_found = r->minimizer_found;
+    }
+    return v;
+}
+
+bool wants_full(sshash_results const* r) {
+    return r->kmer_id_in_string || r->kmer_offset || r->string_id || r->string_begin || r->string_end ||
+           r->kmer_orientation || r->minimizer_found;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sshash_last_error(void) { return g_last_error.c_str(); }
+
+void sshash_build_config_default(sshash_build_config* cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->k = 31;
+    cfg->m = 20;
+    cfg->seed = 1;
+    cfg->num_threads = 1;
+    cfg->lambda = 5.0;
+}
+
+sshash_status sshash_build_from_fasta(const char* filename, const sshash_build_config* cfg, sshash_dict** out) {
+    if (!filename || !out) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    *out = nullptr;
+    return guarded([&] {
+        auto idx = std::make_shared<host_index>();
+        build_from_fasta(*idx, filename, to_options(cfg));
+        *out = wrap(std::move(idx));
+    });
+}
+
+sshash_status sshash_build_from_packed(const uint64_t* words, const uint64_t* endpoints, uint64_t num_strings,
+                                       const sshash_build_config* cfg, sshash_dict** out) {
+    if (!words || !endpoints || !out || num_strings == 0) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    *out = nullptr;
+    return guarded([&] {
+        std::vector<uint64_t> e(endpoints, endpoints + num_strings + 1);
+        std::vector<uint64_t> w(words, words + (2 * e.back() + 63) / 64);
+        auto idx = std::make_shared<host_index>();
+        build_from_packed(*idx, std::move(w), std::move(e), to_options(cfg));
+        *out = wrap(std::move(idx));
+    });
+}
+
+sshash_status sshash_save(const sshash_dict* d, const char* filename) {
+    if (!d || !filename) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { save_index(*d->idx, filename); });
+}
+
+sshash_status sshash_load(const char* filename, sshash_dict** out) {
+    if (!filename || !out) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    *out = nullptr;
+    return guarded([&] {
+        auto idx = std::make_shared<host_index>();
+        load_index(*idx, filename);
+        *out = wrap(std::move(idx));
+    });
+}
+
+void sshash_free(sshash_dict* d) { delete d; }
+
+sshash_status sshash_get_info(const sshash_dict* d, sshash_info* info) {
+    if (!d || !info) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    host_index const& x = *d->idx;
+    std::memset(info, 0, sizeof(*info));
+    std::memcpy(info->version, x.version, 3);
+    info->canonical = x.canonical;
+    info->k = x.k;
+    info->m = x.m;
+    info->words_per_kmer = x.words_per_kmer();
+    info->num_kmers = x.num_kmers;
+    info->num_strings = x.num_strings;
+    info->num_bases = x.num_bases;
+    info->num_minimizers = x.num_minimizers();
+    info->num_bits = x.num_bits();
+    info->skew_partitions = x.skew_num_partitions;
+    return SSHASH_OK;
+}
+
+int sshash_device_count(void) { return visible_device_count(); }
+
+sshash_status sshash_to_device(sshash_dict* d, int device) {
+    if (!d) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->to_device(device); });
+}
+
+sshash_status sshash_device_bytes(const sshash_dict* d, int device, uint64_t* bytes) {
+    if (!d || !bytes) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { *bytes = d->eng->device_bytes(device); });
+}
+
+sshash_status sshash_lookup_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                          int check_rc, const sshash_results* out, void* hip_stream) {
+    if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        d->eng->lookup_packed_device(device, kmers, n, check_rc != 0, wants_full(out) ? out_mode::full : out_mode::ids,
+                                     to_view(out), nullptr, hip_stream);
+    });
+}
+
+sshash_status sshash_lookup_ascii_device(const sshash_dict* d, int device, const char* kmers, uint64_t n, int check_rc,
+                                         const sshash_results* out, void* hip_stream) {
+    if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        d->eng->lookup_ascii_device(device, kmers, n, check_rc != 0, wants_full(out) ? out_mode::full : out_mode::ids,
+                                    to_view(out), nullptr, hip_stream);
+    });
+}
+
+sshash_status sshash_lookup_packed(const sshash_dict* d, const uint64_t* kmers, uint64_t n, int check_rc,
+                                   const sshash_results* out) {
+    if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        d->eng->lookup_packed_host(kmers, n, check_rc != 0, wants_full(out) ? out_mode::full : out_mode::ids, to_view(out),
+                                   nullptr);
+    });
+}
+
+sshash_status sshash_lookup_ascii(const sshash_dict* d, const char* kmers, uint64_t n, int check_rc,
+                                  const sshash_results* out) {
+    if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        d->eng->lookup_ascii_host(kmers, n, check_rc != 0, wants_full(out) ? out_mode::full : out_mode::ids, to_view(out),
+                                  nullptr);
+    });
+}
+
+sshash_status sshash_is_member_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                             int check_rc, uint8_t* out, void* hip_stream) {
+    if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        d->eng->lookup_packed_device(device, kmers, n, check_rc != 0, out_mode::member, result_view{}, out, hip_stream);
+    });
+}
+
+sshash_status sshash_is_member_packed(const sshash_dict* d, const uint64_t* kmers, uint64_t n, int check_rc, uint8_t* out) {
+    if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->lookup_packed_host(kmers, n, check_rc != 0, out_mode::member, result_view{}, out); });
+}
+
+sshash_status sshash_is_member_ascii(const sshash_dict* d, const char* kmers, uint64_t n, int check_rc, uint8_t* out) {
+    if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->lookup_ascii_host(kmers, n, check_rc != 0, out_mode::member, result_view{}, out); });
+}
+
+sshash_status sshash_access(const sshash_dict* d, uint64_t kmer_id, char* out_k_chars) {
+    if (!d || !out_k_chars) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { access_kmer(*d->idx, kmer_id, out_k_chars); });
+}
+
+sshash_status sshash_access_packed(const sshash_dict* d, const uint64_t* kmer_ids, uint64_t n, uint64_t* out_words) {
+    if (!d || (!kmer_ids && n) || (!out_words && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        const uint32_t W = d->idx->words_per_kmer();
+        const uint32_t nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        std::string err;
+        detail::parallel_ranges(n, n >= 4096 ? nt : 1, [&](uint64_t b, uint64_t e, uint32_t) {
+            try {
+                for (uint64_t i = b; i < e; ++i) access_kmer_packed(*d->idx, kmer_ids[i], out_words + i * W);
+            } catch (std::exception const& ex) { err = ex.what(); }
+        });
+        if (!err.empty()) throw std::runtime_error(err);
+    });
+}
+
+sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char* filename, int multiline,
+                                               sshash_streaming_report* report) {
+    if (!d || !filename || !report) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    std::memset(report, 0, sizeof(*report));
+    return guarded([&] {
+        read_batch reads;
+        if (!load_reads(filename, multiline != 0, d->idx->k, reads)) {
+            /* src/query.cpp:169-171: unsupported extension -> message on stderr, empty report */
+            fprintf(stderr, "unsupported query file format\n");
+            return;
+        }
+        const streaming_report r = d->eng->streaming_query_host(reads.bases.data(), reads.offsets.data(), reads.num_reads());
+        report->num_kmers = r.num_kmers;
+        report->num_positive_kmers = r.num_positive_kmers;
+        report->num_negative_kmers = r.num_negative_kmers;
+        report->num_invalid_kmers = r.num_invalid_kmers;
+        report->num_searches = r.num_searches;
+        report->num_extensions = r.num_extensions;
+    });
+}
+
+sshash_status sshash_streaming_query(const sshash_dict* d, const char* bases, const uint64_t* read_offsets,
+                                     uint64_t num_reads, sshash_streaming_report* report) {
+    if (!d || !report || (num_reads && (!bases || !read_offsets))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    std::memset(report, 0, sizeof(*report));
+    return guarded([&] {
+        const streaming_report r = d->eng->streaming_query_host(bases, read_offsets, num_reads);
+        report->num_kmers = r.num_kmers;
+        report->num_positive_kmers = r.num_positive_kmers;
+        report->num_negative_kmers = r.num_negative_kmers;
+        report->num_invalid_kmers = r.num_invalid_kmers;
+        report->num_searches = r.num_searches;
+        report->num_extensions = r.num_extensions;
+    });
+}
+
+sshash_status sshash_streaming_query_device(const sshash_dict* d, int device, const char* bases,
+                                            const uint64_t* read_offsets, uint64_t num_reads, uint64_t* report,
+                                            void* hip_stream) {
+    if (!d || !report || (num_reads && (!bases || !read_offsets))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->streaming_query_device(device, bases, read_offsets, num_reads, 0, report, hip_stream); });
+}
+
+sshash_status sshash_set_max_blocks(sshash_dict* d, uint32_t max_blocks) {
+    if (!d) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    d->eng->set_block_cap(max_blocks);
+    return SSHASH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,318 @@
+// engine.hip -- device replicas, the batched lookup kernels and their launchers (gfx950 only).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <thread>
+
+#include "engine.hpp"
+#include "replica.hpp"
+
+namespace sshash_amd {
+
+int visible_device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+/* strings + endpoints -> granules (device_layout.hpp) */
+static std::vector<granule> make_granules(host_index const& idx, uint32_t num_threads) {
+    const uint64_t G = idx.num_bases / GRANULE_BASES + 1 + GRANULE_PAD;
+    std::vector<granule> g(G);
+    detail::parallel_ranges(G, num_threads, [&](uint64_t b, uint64_t e, uint32_t) {
+        for (uint64_t i = b; i < e; ++i) {
+            g[i].rank = 0;
+            g[i].marks = 0;
+            g[i].bases = i < idx.strings.size() ? idx.strings[i] : 0;
+        }
+    });
+    if (idx.endpoints.size() >= (uint64_t(1) << 32)) throw std::runtime_error("more than 2^32 strings");
+    for (uint64_t e : idx.endpoints) g[e >> 5].marks |= 1u << (e & 31);
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < G; ++i) {
+        g[i].rank = acc;
+        acc += uint32_t(__builtin_popcount(g[i].marks));
+    }
+    return g;
+}
+
+engine::engine(std::shared_ptr<host_index> idx) : m_idx(std::move(idx)) {}
+engine::~engine() = default;
+
+bool engine::on_device(int device) const {
+    for (auto const& r : m_replicas)
+        if (r->device == device) return true;
+    return false;
+}
+
+std::vector<int> engine::devices() const {
+    std::vector<int> d;
+    for (auto const& r : m_replicas) d.push_back(r->device);
+    return d;
+}
+
+uint64_t engine::device_bytes(int device) const { return replica(device)->bytes; }
+
+device_replica const* engine::replica(int device) const {
+    for (auto const& r : m_replicas)
+        if (r->device == device) return r.get();
+    throw std::runtime_error("dictionary is not resident on device " + std::to_string(device) +
+                             " (call sshash_to_device first)");
+}
+
+void engine::to_device(int device) {
+    if (on_device(device)) return;
+    const int count = visible_device_count();
+    if (count == 0) throw std::runtime_error("no HIP device visible: the lookup path requires an MI355X (no CPU fallback)");
+    if (device < 0 || device >= count) throw std::runtime_error("invalid device ordinal " + std::to_string(device));
+    device_guard guard(device);
+    host_index const& idx = *m_idx;
+    auto rep = std::make_unique<device_replica>();
+    rep->device = device;
+    dict_view& v = rep->view;
+    v.k = idx.k;
+    v.m = idx.m;
+    v.canonical = idx.canonical;
+    v.skew_parts = idx.skew_num_partitions;
+    v.hash_magic = idx.hash_magic;
+    v.num_kmers = idx.num_kmers;
+    v.num_strings = idx.num_strings;
+    v.num_bases = idx.num_bases;
+    {
+        const uint32_t nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<granule> g = make_granules(idx, nt);
+        v.granules = rep->put(g);
+    }
+    v.endpoints = rep->put(idx.endpoints);
+    v.minimizers = rep->put_mphf(idx.minimizers_mphf);
+    v.codewords = rep->put(idx.control_codewords.words);
+    v.cw_width = idx.control_codewords.width;
+    v.off_width = idx.mid_load_buckets.width;
+    v.begin_buckets_of_size = rep->put(idx.begin_buckets_of_size);
+    v.mid_load = rep->put(idx.mid_load_buckets.words);
+    v.heavy_load = rep->put(idx.heavy_load_buckets.words);
+    v.heavy_size = idx.heavy_load_buckets.size;
+    std::vector<skew_part_dev> skew(8);
+    for (uint32_t p = 0; p < 8; ++p) {
+        std::memset(&skew[p], 0, sizeof(skew_part_dev));
+        if (p < idx.skew_num_partitions && idx.skew_mphfs[p].num_keys) {
+            skew[p].f = rep->put_mphf(idx.skew_mphfs[p]);
+            skew[p].positions = rep->put(idx.skew_positions[p].words);
+            skew[p].pos_width = idx.skew_positions[p].width;
+        } else {
+            /* an absent key may still be routed here: give it a well-formed 1-key function */
+            mphf_host dummy;
+            dummy.pilot_width = 1;
+            dummy.num_keys = 1;
+            mphf_partition part{};
+            part.num_keys = 1;
+            part.table_size = 1;
+            part.dense_buckets = 1;
+            part.sparse_buckets = 1;
+            dummy.parts.push_back(part);
+            dummy.pilots.assign(2, 0);
+            dummy.free_slots.assign(1, 0);
+            skew[p].f = rep->put_mphf(dummy);
+            skew[p].positions = rep->put(std::vector<uint64_t>(2, 0));
+            skew[p].pos_width = 1;
+        }
+    }
+    rep->d_skew = rep->put(skew);
+    m_replicas.push_back(std::move(rep));
+}
+
+/* ---- kernels --------------------------------------------------------------------------- */
+
+template <int W, bool CANON, int MODE, bool ASCII>
+__global__ void __launch_bounds__(256)
+lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const void* __restrict__ queries,
+              const uint64_t n, const bool check_rc, const result_view out, uint8_t* __restrict__ member) {
+    const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        kmer_w<W> x;
+        if constexpr (ASCII) {
+            x = kmer_from_ascii<W>(static_cast<const char*>(queries) + i * d.k, d.k);
+        } else {
+            const uint64_t* q = static_cast<const uint64_t*>(queries) + i * W;
+            for (int j = 0; j < W; ++j) x.w[j] = q[j];
+            x = kmer_take_chars<W>(x, d.k);
+        }
+        const hit_t h = lookup_one<W, CANON>(d, skew, x, check_rc);
+        if constexpr (MODE == int(out_mode::member)) {
+            member[i] = h.found ? 1 : 0;
+        } else {
+            store_result<MODE == int(out_mode::full)>(d, out, i, h);
+        }
+    }
+}
+
+template <int W, bool CANON, int MODE, bool ASCII>
+static void launch(dict_view const& d, skew_part_dev const* skew, void const* q, uint64_t n, bool check_rc,
+                   result_view const& out, uint8_t* member, hipStream_t stream, uint32_t max_blocks) {
+    const uint32_t block = 256;
+    uint64_t blocks = (n + block - 1) / block;
+    const uint64_t cap = max_blocks ? max_blocks : (uint64_t(1) << 22);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((lookup_kernel<W, CANON, MODE, ASCII>), dim3(uint32_t(blocks)), dim3(block), 0, stream, d, skew,
+                       q, n, check_rc, out, member);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <int W, bool CANON, bool ASCII>
+static void launch_mode(out_mode mode, dict_view const& d, skew_part_dev const* skew, void const* q, uint64_t n,
+                        bool check_rc, result_view const& out, uint8_t* member, hipStream_t s, uint32_t mb) {
+    switch (mode) {
+        case out_mode::ids: launch<W, CANON, 0, ASCII>(d, skew, q, n, check_rc, out, member, s, mb); break;
+        case out_mode::full: launch<W, CANON, 1, ASCII>(d, skew, q, n, check_rc, out, member, s, mb); break;
+        case out_mode::member: launch<W, CANON, 2, ASCII>(d, skew, q, n, check_rc, out, member, s, mb); break;
+    }
+}
+
+template <bool ASCII>
+static void launch_any(out_mode mode, dict_view const& d, skew_part_dev const* skew, void const* q, uint64_t n,
+                       bool check_rc, result_view const& out, uint8_t* member, hipStream_t s, uint32_t mb) {
+    const bool wide = d.k > 31;
+    if (!wide && !d.canonical) launch_mode<1, false, ASCII>(mode, d, skew, q, n, check_rc, out, member, s, mb);
+    else if (!wide && d.canonical) launch_mode<1, true, ASCII>(mode, d, skew, q, n, check_rc, out, member, s, mb);
+    else if (wide && !d.canonical) launch_mode<2, false, ASCII>(mode, d, skew, q, n, check_rc, out, member, s, mb);
+    else launch_mode<2, true, ASCII>(mode, d, skew, q, n, check_rc, out, member, s, mb);
+}
+
+static void check_outputs(out_mode mode, result_view const& out, uint8_t* member) {
+    if (mode == out_mode::member) {
+        if (!member) throw std::runtime_error("is_member output pointer is null");
+    } else if (!out.kmer_id) {
+        throw std::runtime_error("kmer_id output pointer is null");
+    }
+}
+
+void engine::lookup_packed_device(int device, uint64_t const* d_kmers, uint64_t n, bool check_rc, out_mode mode,
+                                  result_view const& d_out, uint8_t* d_member, void* stream) const {
+    device_replica const* rep = replica(device);
+    check_outputs(mode, d_out, d_member);
+    if (n == 0) return;
+    device_guard guard(device);
+    launch_any<false>(mode, rep->view, rep->d_skew, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream), m_max_blocks);
+}
+
+void engine::lookup_ascii_device(int device, char const* d_kmers, uint64_t n, bool check_rc, out_mode mode,
+                                 result_view const& d_out, uint8_t* d_member, void* stream) const {
+    device_replica const* rep = replica(device);
+    check_outputs(mode, d_out, d_member);
+    if (n == 0) return;
+    device_guard guard(device);
+    launch_any<true>(mode, rep->view, rep->d_skew, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream), m_max_blocks);
+}
+
+/* ---- host-buffer path: shard over replicas, chunk through device staging buffers ---------- */
+
+namespace {
+
+struct staging {  // per-device scratch for one chunk
+    void* d_in = nullptr;
+    result_view d_out{};
+    uint8_t* d_member = nullptr;
+    std::vector<void*> owned;
+    template <typename T>
+    T* alloc(uint64_t n) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, std::max<uint64_t>(n, 1) * sizeof(T)));
+        owned.push_back(p);
+        return static_cast<T*>(p);
+    }
+    ~staging() {
+        for (void* p : owned) (void)hipFree(p);
+    }
+};
+
+template <typename T>
+void copy_back(T* h, T const* d, uint64_t off, uint64_t n, hipStream_t s) {
+    if (h) HIP_CHECK(hipMemcpyAsync(h + off, d, n * sizeof(T), hipMemcpyDeviceToHost, s));
+}
+
+}  // namespace
+
+template <bool ASCII>
+static void host_lookup(engine const& eng, std::vector<int> const& devs, void const* h_in, uint64_t bytes_per_query,
+                        uint64_t n, bool check_rc, out_mode mode, result_view const& h_out, uint8_t* h_member) {
+    check_outputs(mode, h_out, h_member);
+    if (n == 0) return;
+    if (devs.empty()) throw std::runtime_error("dictionary is not resident on any device (call sshash_to_device first)");
+    const uint64_t G = devs.size();
+    const uint64_t chunk = uint64_t(1) << 24;  // queries per device round
+    std::vector<std::string> errors(G);
+    std::vector<std::thread> workers;
+    for (uint64_t g = 0; g < G; ++g) {
+        workers.emplace_back([&, g] {
+            try {
+                const uint64_t lo = n * g / G, hi = n * (g + 1) / G;
+                if (lo == hi) return;
+                HIP_CHECK(hipSetDevice(devs[g]));
+                hipStream_t s;
+                HIP_CHECK(hipStreamCreate(&s));
+                {
+                    staging st;
+                    const uint64_t c = std::min(chunk, hi - lo);
+                    st.d_in = st.alloc<uint8_t>(c * bytes_per_query);
+                    if (mode == out_mode::member) st.d_member = st.alloc<uint8_t>(c);
+                    else {
+                        st.d_out.kmer_id = st.alloc<uint64_t>(c);
+                        if (mode == out_mode::full) {
+                            if (h_out.kmer_id_in_string) st.d_out.kmer_id_in_string = st.alloc<uint64_t>(c);
+                            if (h_out.kmer_offset) st.d_out.kmer_offset = st.alloc<uint64_t>(c);
+                            if (h_out.string_id) st.d_out.string_id = st.alloc<uint64_t>(c);
+                            if (h_out.string_begin) st.d_out.string_begin = st.alloc<uint64_t>(c);
+                            if (h_out.string_end) st.d_out.string_end = st.alloc<uint64_t>(c);
+                            if (h_out.kmer_orientation) st.d_out.kmer_orientation = st.alloc<int8_t>(c);
+                            if (h_out.minimizer_found) st.d_out.minimizer_found = st.alloc<uint8_t>(c);
+                        }
+                    }
+                    for (uint64_t at = lo; at < hi; at += c) {
+                        const uint64_t m = std::min(c, hi - at);
+                        HIP_CHECK(hipMemcpyAsync(st.d_in, static_cast<uint8_t const*>(h_in) + at * bytes_per_query,
+                                                 m * bytes_per_query, hipMemcpyHostToDevice, s));
+                        if (ASCII)
+                            eng.lookup_ascii_device(devs[g], static_cast<char const*>(st.d_in), m, check_rc, mode, st.d_out,
+                                                    st.d_member, s);
+                        else
+                            eng.lookup_packed_device(devs[g], static_cast<uint64_t const*>(st.d_in), m, check_rc, mode,
+                                                     st.d_out, st.d_member, s);
+                        if (mode == out_mode::member) copy_back(h_member, st.d_member, at, m, s);
+                        else {
+                            copy_back(h_out.kmer_id, st.d_out.kmer_id, at, m, s);
+                            if (mode == out_mode::full) {
+                                copy_back(h_out.kmer_id_in_string, st.d_out.kmer_id_in_string, at, m, s);
+                                copy_back(h_out.kmer_offset, st.d_out.kmer_offset, at, m, s);
+                                copy_back(h_out.string_id, st.d_out.string_id, at, m, s);
+                                copy_back(h_out.string_begin, st.d_out.string_begin, at, m, s);
+                                copy_back(h_out.string_end, st.d_out.string_end, at, m, s);
+                                copy_back(h_out.kmer_orientation, st.d_out.kmer_orientation, at, m, s);
+                                copy_back(h_out.minimizer_found, st.d_out.minimizer_found, at, m, s);
+                            }
+                        }
+                        HIP_CHECK(hipStreamSynchronize(s));
+                    }
+                }
+                HIP_CHECK(hipStreamDestroy(s));
+            } catch (std::exception const& e) { errors[g] = e.what(); }
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (auto const& e : errors)
+        if (!e.empty()) throw std::runtime_error(e);
+}
+
+void engine::lookup_packed_host(uint64_t const* h_kmers, uint64_t n, bool check_rc, out_mode mode,
+                                result_view const& h_out, uint8_t* h_member) const {
+    host_lookup<false>(*this, devices(), h_kmers, 8ull * m_idx->words_per_kmer(), n, check_rc, mode, h_out, h_member);
+}
+
+void engine::lookup_ascii_host(char const* h_kmers, uint64_t n, bool check_rc, out_mode mode, result_view const& h_out,
+                               uint8_t* h_member) const {
+    host_lookup<true>(*this, devices(), h_kmers, m_idx->k, n, check_rc, mode, h_out, h_member);
+}
+
+}  // namespace sshash_amd

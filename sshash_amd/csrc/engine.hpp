@@ -1,0 +1,73 @@
+// engine.hpp -- host-side owner of the device-resident dictionary replicas and kernel launchers.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "device_layout.hpp"
+#include "index.hpp"
+
+namespace sshash_amd {
+
+struct device_replica;  // defined in engine.hip
+
+enum class out_mode : int { ids = 0, full = 1, member = 2 };
+
+struct streaming_report {  // streaming_query_report, include/util.hpp:21-36
+    uint64_t num_kmers = 0, num_positive_kmers = 0, num_negative_kmers = 0, num_invalid_kmers = 0,
+             num_searches = 0, num_extensions = 0;
+};
+
+struct launch_timing {  // filled when the caller asks for device-side timing
+    float kernel_ms = 0.f;
+};
+
+class engine {
+public:
+    explicit engine(std::shared_ptr<host_index> idx);
+    ~engine();
+
+    host_index const& index() const { return *m_idx; }
+
+    /* Copy the dictionary into the HBM of `device` (no-op when already there). */
+    void to_device(int device);
+    bool on_device(int device) const;
+    std::vector<int> devices() const;
+    uint64_t device_bytes(int device) const;
+
+    /* Device-pointer entry points: queries and outputs already live in the HBM of `device`;
+       the launch is asynchronous on `stream` (a hipStream_t, may be null = default stream).
+       `packed`: n*W u64 words (W = 1 for k<=31, 2 otherwise). `ascii`: n*k chars, no NUL. */
+    void lookup_packed_device(int device, uint64_t const* d_kmers, uint64_t n, bool check_rc, out_mode mode,
+                              result_view const& d_out, uint8_t* d_member, void* stream) const;
+    void lookup_ascii_device(int device, char const* d_kmers, uint64_t n, bool check_rc, out_mode mode,
+                             result_view const& d_out, uint8_t* d_member, void* stream) const;
+
+    /* Host-buffer entry points: shard the batch over every replica, stream chunks through
+       pinned staging buffers, results land in the caller's arrays. */
+    void lookup_packed_host(uint64_t const* h_kmers, uint64_t n, bool check_rc, out_mode mode,
+                            result_view const& h_out, uint8_t* h_member) const;
+    void lookup_ascii_host(char const* h_kmers, uint64_t n, bool check_rc, out_mode mode, result_view const& h_out,
+                           uint8_t* h_member) const;
+
+    /* Batched streaming query over `n_reads` reads stored back to back in `bases`
+       (read r = bases[read_offsets[r] .. read_offsets[r+1])). Host buffers. */
+    streaming_report streaming_query_host(char const* bases, uint64_t const* read_offsets, uint64_t n_reads) const;
+    /* Device buffers, asynchronous; `d_report` receives 6 u64 counters (accumulated). */
+    void streaming_query_device(int device, char const* d_bases, uint64_t const* d_read_offsets, uint64_t n_reads,
+                                uint64_t total_bases, uint64_t* d_report, void* stream) const;
+
+    /* Tunables (set before launching; defaults are the measured best). */
+    void set_block_cap(uint32_t max_blocks) { m_max_blocks = max_blocks; }
+
+private:
+    device_replica const* replica(int device) const;
+    std::shared_ptr<host_index> m_idx;
+    std::vector<std::unique_ptr<device_replica>> m_replicas;
+    uint32_t m_max_blocks = 0;
+};
+
+int visible_device_count();  // 0 when no GPU / no driver
+
+}  // namespace sshash_amd

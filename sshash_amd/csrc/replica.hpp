@@ -1,0 +1,69 @@
+// replica.hpp -- one dictionary replica resident in the HBM of one device (internal header).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lookup_device.hpp"
+#include "mphf_build.hpp"
+
+namespace sshash_amd {
+
+inline void hip_check(hipError_t e, char const* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+#define HIP_CHECK(x) ::sshash_amd::hip_check((x), #x)
+
+struct device_guard {
+    int prev = 0;
+    int target;
+    explicit device_guard(int dev) : target(dev) {
+        HIP_CHECK(hipGetDevice(&prev));
+        if (prev != dev) HIP_CHECK(hipSetDevice(dev));
+    }
+    ~device_guard() {
+        if (prev != target) (void)hipSetDevice(prev);
+    }
+};
+
+struct device_replica {
+    int device = -1;
+    uint64_t bytes = 0;
+    dict_view view{};
+    skew_part_dev* d_skew = nullptr;
+    std::vector<void*> allocations;
+
+    template <typename T>
+    T* put(std::vector<T> const& v) {
+        T* d = nullptr;
+        const size_t n = (v.empty() ? 1 : v.size()) * sizeof(T);
+        HIP_CHECK(hipMalloc(&d, n));
+        allocations.push_back(d);
+        if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        bytes += n;
+        return d;
+    }
+    mphf_view put_mphf(mphf_host const& f) {
+        mphf_view v = f.view();
+        v.parts = put(f.parts);
+        v.pilots = put(f.pilots);
+        v.free_slots = put(f.free_slots);
+        return v;
+    }
+    device_replica() = default;
+    device_replica(device_replica const&) = delete;
+    device_replica& operator=(device_replica const&) = delete;
+    ~device_replica() {
+        if (device < 0) return;
+        int prev = 0;
+        if (hipGetDevice(&prev) != hipSuccess) return;
+        (void)hipSetDevice(device);
+        for (void* p : allocations) (void)hipFree(p);
+        (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace sshash_amd

@@ -1,0 +1,232 @@
+// streaming.hip -- batched streaming query: one read per lane (gfx950 only).
+//
+// Reference: streaming_query<Dict,canonical>::lookup / seed (include/streaming_query.hpp:56-109,
+// 144-197) driven per read by src/query.cpp:78-108. The state machine is sequential inside a
+// read and independent across reads, so reads are the parallel dimension. Per lane:
+//   * k-mer and its reverse complement are rolled one base at a time (:68-80);
+//   * while the previous k-mer matched at string offset `off`, the next k-mer is first compared
+//     with the string's own next k-mer ("extension", :86-100). With the granule layout the
+//     reference's `remaining_string_bases` counter is implicit: the window at off+-1 reports
+//     whether it runs across a string boundary, which is exactly remaining == 0;
+//   * otherwise seed(): the negative short-cut (:150-157), then the point lookups (:159-180).
+//     Minimizers are only needed inside seed(), so they are computed there, statelessly
+//     (the rolling iterators of include/minimizer_iterator.hpp return the same values: :56-57).
+// Output: the six counters of streaming_query_report (include/util.hpp:21-36).
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <thread>
+
+#include "engine.hpp"
+#include "replica.hpp"
+
+namespace sshash_amd {
+
+namespace {
+
+template <int W, bool CANON>
+__device__ __forceinline__ hit_t seed_lookup(dict_view const& d, skew_part_dev const* __restrict__ skew,
+                                             kmer_w<W> const& x, kmer_w<W> const& x_rc, minimizer_t mf, minimizer_t mr) {
+    if constexpr (CANON) {  // include/streaming_query.hpp:159-169
+        if (mf.value < mr.value) return probe_canonical<W>(d, skew, x, x_rc, mf);
+        if (mr.value < mf.value) return probe_canonical<W>(d, skew, x, x_rc, mr);
+        hit_t h = probe_canonical<W>(d, skew, x, x_rc, mf);
+        if (!h.found) h = probe_canonical<W>(d, skew, x, x_rc, mr);
+        return h;
+    } else {  // :170-180
+        hit_t h = probe_regular<W>(d, skew, x, mf);
+        if (!h.found) {
+            const bool mf_found = h.minimizer_found;
+            h = probe_regular<W>(d, skew, x_rc, mr);
+            h.orientation = -1;
+            h.minimizer_found = h.minimizer_found || mf_found;
+        }
+        return h;
+    }
+}
+
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+template <int W, bool CANON>
+__global__ void __launch_bounds__(256)
+streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const char* __restrict__ bases,
+                 const uint64_t* __restrict__ offsets, const uint64_t n_reads, uint64_t* __restrict__ report) {
+    uint64_t c_kmers = 0, c_invalid = 0, c_negative = 0, c_searches = 0, c_extensions = 0;
+    const uint32_t k = d.k;
+    const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
+    for (uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n_reads; r += stride) {
+        const uint64_t begin = offsets[r], len = offsets[r + 1] - begin;
+        if (len < k) continue;
+        c_kmers += len - k + 1;
+        kmer_w<W> x = kmer_zero<W>(), x_rc = kmer_zero<W>();
+        uint32_t valid_len = 0;
+        bool in_run = false;        // previous k-mer was found (remaining bases tracked via `off`)
+        bool neg_unknown_mini = false;  // previous k-mer: seed() said "negative, minimizer not in index"
+        uint64_t prev_f = 0, prev_r = 0;
+        uint64_t off = 0;
+        int ori = 1;
+        const char* p = bases + begin;
+        for (uint64_t j = 0; j < len; ++j) {
+            const char c = p[j];
+            const uint64_t code = base_code(c);
+            x = kmer_roll<W>(x, code, k);
+            x_rc = kmer_roll_rc<W>(x_rc, code, k);
+            valid_len = base_is_valid(c) ? valid_len + 1 : 0;
+            if (j + 1 < k) continue;
+            if (valid_len < k) {  // :59-65 -- invalid k-mer resets the whole state
+                ++c_invalid;
+                in_run = false;
+                neg_unknown_mini = false;
+                continue;
+            }
+            if (in_run && !(ori < 0 && off == 0)) {  // :86-100
+                const uint64_t next = ori > 0 ? off + 1 : off - 1;
+                const window_t<W> w = read_window<W>(d.granules, next, k);
+                if (!w.crosses && (kmer_eq<W>(w.kmer, x) || kmer_eq<W>(w.kmer, x_rc))) {
+                    ++c_extensions;
+                    off = next;
+                    continue;
+                }
+            }
+            /* seed() */
+            const minimizer_t mf = compute_minimizer<W>(x, k, d.m, d.hash_magic);
+            const minimizer_t mr = compute_minimizer<W>(x_rc, k, d.m, d.hash_magic);
+            if (neg_unknown_mini && mf.value == prev_f && mr.value == prev_r) {  // :150-157
+                ++c_negative;
+                in_run = false;
+                continue;
+            }
+            prev_f = mf.value;
+            prev_r = mr.value;
+            const hit_t h = seed_lookup<W, CANON>(d, skew, x, x_rc, mf, mr);
+            if (h.found) {
+                ++c_searches;
+                in_run = true;
+                off = h.kmer_offset;
+                ori = h.orientation;
+                neg_unknown_mini = false;
+            } else {
+                ++c_negative;
+                in_run = false;
+                neg_unknown_mini = !h.minimizer_found;
+            }
+        }
+    }
+    c_kmers = wave_sum(c_kmers);
+    c_invalid = wave_sum(c_invalid);
+    c_negative = wave_sum(c_negative);
+    c_searches = wave_sum(c_searches);
+    c_extensions = wave_sum(c_extensions);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 0), (unsigned long long)c_kmers);
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 1), (unsigned long long)(c_searches + c_extensions));
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 2), (unsigned long long)c_negative);
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 3), (unsigned long long)c_invalid);
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 4), (unsigned long long)c_searches);
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 5), (unsigned long long)c_extensions);
+    }
+}
+
+template <int W, bool CANON>
+void launch_streaming(dict_view const& d, skew_part_dev const* skew, char const* bases, uint64_t const* offsets,
+                      uint64_t n_reads, uint64_t* report, hipStream_t s) {
+    const uint32_t block = 256;
+    uint64_t blocks = (n_reads + block - 1) / block;
+    if (blocks > (uint64_t(1) << 20)) blocks = uint64_t(1) << 20;
+    hipLaunchKernelGGL((streaming_kernel<W, CANON>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases, offsets,
+                       n_reads, report);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+void engine::streaming_query_device(int device, char const* d_bases, uint64_t const* d_read_offsets, uint64_t n_reads,
+                                    uint64_t /*total_bases*/, uint64_t* d_report, void* stream) const {
+    device_replica const* rep = replica(device);
+    if (n_reads == 0) return;
+    int prev = 0;
+    HIP_CHECK(hipGetDevice(&prev));
+    if (prev != device) HIP_CHECK(hipSetDevice(device));
+    dict_view const& d = rep->view;
+    hipStream_t s = hipStream_t(stream);
+    const bool wide = d.k > 31;
+    if (!wide && !d.canonical) launch_streaming<1, false>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
+    else if (!wide && d.canonical) launch_streaming<1, true>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
+    else if (wide && !d.canonical) launch_streaming<2, false>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
+    else launch_streaming<2, true>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
+    if (prev != device) HIP_CHECK(hipSetDevice(prev));
+}
+
+streaming_report engine::streaming_query_host(char const* bases, uint64_t const* read_offsets, uint64_t n_reads) const {
+    streaming_report total;
+    if (n_reads == 0) return total;
+    const std::vector<int> devs = devices();
+    if (devs.empty()) throw std::runtime_error("dictionary is not resident on any device (call sshash_to_device first)");
+    const uint64_t G = devs.size();
+    std::vector<std::string> errors(G);
+    std::vector<streaming_report> partial(G);
+    std::vector<std::thread> workers;
+    for (uint64_t g = 0; g < G; ++g) {
+        workers.emplace_back([&, g] {
+            try {
+                const uint64_t lo = n_reads * g / G, hi = n_reads * (g + 1) / G;
+                if (lo == hi) return;
+                HIP_CHECK(hipSetDevice(devs[g]));
+                hipStream_t s;
+                HIP_CHECK(hipStreamCreate(&s));
+                uint64_t* d_report = nullptr;
+                HIP_CHECK(hipMalloc(&d_report, 6 * sizeof(uint64_t)));
+                HIP_CHECK(hipMemsetAsync(d_report, 0, 6 * sizeof(uint64_t), s));
+                /* chunks of at most ~1 GiB of bases */
+                const uint64_t max_bases = uint64_t(1) << 30;
+                uint64_t at = lo;
+                std::vector<uint64_t> rel;
+                while (at < hi) {
+                    uint64_t end = at;
+                    while (end < hi && (end == at || read_offsets[end + 1] - read_offsets[at] <= max_bases)) ++end;
+                    const uint64_t nb = read_offsets[end] - read_offsets[at];
+                    rel.resize(end - at + 1);
+                    for (uint64_t i = at; i <= end; ++i) rel[i - at] = read_offsets[i] - read_offsets[at];
+                    char* d_bases = nullptr;
+                    uint64_t* d_off = nullptr;
+                    HIP_CHECK(hipMalloc(&d_bases, std::max<uint64_t>(nb, 1)));
+                    HIP_CHECK(hipMalloc(&d_off, rel.size() * sizeof(uint64_t)));
+                    HIP_CHECK(hipMemcpyAsync(d_bases, bases + read_offsets[at], nb, hipMemcpyHostToDevice, s));
+                    HIP_CHECK(hipMemcpyAsync(d_off, rel.data(), rel.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+                    streaming_query_device(devs[g], d_bases, d_off, end - at, nb, d_report, s);
+                    HIP_CHECK(hipStreamSynchronize(s));
+                    HIP_CHECK(hipFree(d_bases));
+                    HIP_CHECK(hipFree(d_off));
+                    at = end;
+                }
+                uint64_t h[6];
+                HIP_CHECK(hipMemcpy(h, d_report, sizeof(h), hipMemcpyDeviceToHost));
+                HIP_CHECK(hipFree(d_report));
+                HIP_CHECK(hipStreamDestroy(s));
+                partial[g].num_kmers = h[0];
+                partial[g].num_positive_kmers = h[1];
+                partial[g].num_negative_kmers = h[2];
+                partial[g].num_invalid_kmers = h[3];
+                partial[g].num_searches = h[4];
+                partial[g].num_extensions = h[5];
+            } catch (std::exception const& e) { errors[g] = e.what(); }
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (auto const& e : errors)
+        if (!e.empty()) throw std::runtime_error(e);
+    for (auto const& p : partial) {
+        total.num_kmers += p.num_kmers;
+        total.num_positive_kmers += p.num_positive_kmers;
+        total.num_negative_kmers += p.num_negative_kmers;
+        total.num_invalid_kmers += p.num_invalid_kmers;
+        total.num_searches += p.num_searches;
+        total.num_extensions += p.num_extensions;
+    }
+    return total;
+}
+
+}  // namespace sshash_amd
