@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass
 from typing import Iterable, Optional, Sequence, Union
 
@@ -83,6 +84,28 @@ class _Report(C.Structure):
 _lib: Optional[C.CDLL] = None
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME
+    as the system one); if libsshash_amd.so pulled in /opt/rocm's copy first, a later `import torch`
+    would load a second runtime and fail with "No HIP GPUs are available" -- and streams / events /
+    synchronisation would not be shared between the two. So when torch is installed, its bundled
+    runtime is loaded first and libsshash_amd.so binds to it (SONAME match); without torch the
+    system ROCm runtime is used."""
+    if "torch" in sys.modules:
+        return  # torch already loaded its runtime; ours will resolve to it
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def _load() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -94,6 +117,7 @@ def _load() -> C.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C sshash_amd/csrc`). "
             "There is no pure-Python / CPU fallback for the lookup path."
         )
+    _preload_hip_runtime()
     lib = C.CDLL(path)
     P = C.c_void_p
     sigs = {

@@ -22,7 +22,7 @@ namespace sshash_amd {
 struct packed_vec {  // bits::compact_vector equivalent
     uint64_t size = 0;
     uint32_t width = 1;
-    std::vector<uint64_t> words;  // + 1 padding word
+    std::vector<uint64_t> words = std::vector<uint64_t>(1, 0);  // + 1 padding word
     void resize(uint64_t n, uint32_t w) {
         size = n;
         width = w;

@@ -1,0 +1,181 @@
+"""Synthetic spectrum-preserving string sets with the size statistics of the reference's datasets.
+
+The reference's benchmark collections (S. enterica pangenome, human, ...) live on Zenodo and are
+not available offline, so bench.py indexes a synthetic stand-in of the same scale instead
+(16.4 M strings, 1.39 G bases, 894 M k-mers, k=31, m=21).
+Three ingredients give the bucket-size skew real collections have:
+
+  * background: uniformly random strings (min length k, geometric tail) -> singleton buckets;
+  * SNP siblings: a short string (k <= len <= 2k-1) copied with ONE base changed at a position
+    covered by all of its k-mers. Every k-mer differs, every m-mer not covering the base is
+    shared -> buckets of 2..4 minimizer positions, as variant bubbles of a pangenome graph do;
+  * hot motifs: low-hash m-mers planted in many strings as  D + motif + D  where D is the base-4
+    spelling of the copy number (10 bases): the motif wins the minimizer election of every window
+    containing it and all those k-mers stay distinct -> MIDLOAD and HEAVYLOAD buckets with a
+    Zipf-like size distribution.
+
+Everything is generated on packed arrays with numpy; output is what sshash_build_from_packed takes.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_MUL = np.uint64(0x517CC1B727220A95)
+
+
+def _xxh64_u64(value: int, seed: int = 0) -> int:
+    """XXH64 of one little-endian u64 (published xxHash algorithm) -- the m-mer hash magic."""
+    M = (1 << 64) - 1
+    P1, P2, P3, P4, P5 = (0x9E3779B185EBCA87, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9, 0x85EBCA77C2B2AE63,
+                          0x27D4EB2F165667C5)
+    rotl = lambda v, r: ((v << r) | (v >> (64 - r))) & M
+    h = (seed + P5 + 8) & M
+    k1 = (rotl((value * P2) & M, 31) * P1) & M
+    h ^= k1
+    h = (rotl(h, 27) * P1 + P4) & M
+    h ^= h >> 33
+    h = (h * P2) & M
+    h ^= h >> 29
+    h = (h * P3) & M
+    h ^= h >> 32
+    return h
+
+
+def pack_codes(codes: np.ndarray) -> np.ndarray:
+    """uint8 base codes (0..3) -> 2-bit packed uint64 words, base i in bits [2i, 2i+1] of word i//32."""
+    n = codes.size
+    pad = (-n) % 32
+    if pad:
+        codes = np.concatenate([codes, np.zeros(pad, dtype=np.uint8)])
+    q = codes.reshape(-1, 4)
+    b = q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)  # little-endian: byte j = bases 4j..4j+3
+    return np.ascontiguousarray(b, dtype=np.uint8).view("<u8").copy()
+
+
+def make_spss(num_bases: int, k: int = 31, m: int = 21, mean_len: float = 85.0, seed: int = 0x5555AAAA,
+              sibling_fraction: float = 0.90, num_motifs: int = 2000, motif_copy_fraction: float = 0.04,
+              max_motif_copies: int = 40000, build_seed: int = 1):
+    """-> (packed words, endpoints). Deterministic for a given argument tuple."""
+    rng = np.random.default_rng(seed)
+    # ---- string lengths -------------------------------------------------------------------
+    est = int(num_bases / mean_len * 1.05) + 16
+    lens = k + rng.geometric(1.0 / max(1.0, mean_len - k + 1), est) - 1
+    lens = lens.astype(np.int64)
+    csum = np.cumsum(lens)
+    n_str = int(np.searchsorted(csum, num_bases)) + 1
+    lens = lens[:n_str]
+    # sibling groups: string i+1 (and sometimes i+2) repeats string i with one base changed
+    cand = np.arange(max(0, n_str - 2))
+    pick = cand[rng.random(cand.size) < sibling_fraction / 2.3]
+    pick = pick[np.concatenate([[True], np.diff(pick) > 2])] if pick.size else pick  # keep groups disjoint
+    triple = rng.random(pick.size) < 0.3
+    lens[pick + 1] = lens[pick]
+    lens[pick[triple] + 2] = lens[pick[triple]]
+    endpoints = np.zeros(n_str + 1, dtype=np.uint64)
+    endpoints[1:] = np.cumsum(lens).astype(np.uint64)
+    total = int(endpoints[-1])
+    codes = rng.integers(0, 4, total, dtype=np.uint8)
+    begin = endpoints[:-1].astype(np.int64)
+
+    def copy_with_snp(src, dst, second):
+        """dst := src with one base changed every 30 positions (so every k-mer window, k >= 31, holds a
+        changed base and differs from its twin, while the m-mers between two changes are shared);
+        `second` applies another substitution at the SAME sites so that the three strings of a group
+        are pairwise different."""
+        spacing = k - 1
+        for L in np.unique(lens[src]):
+            sel = lens[src] == L
+            s, d = begin[src[sel]], begin[dst[sel]]
+            idx = np.arange(L, dtype=np.int64)
+            block = codes[s[:, None] + idx[None, :]]
+            key = block[:, :8].astype(np.int64) @ (4 ** np.arange(8, dtype=np.int64))  # content-derived
+            if L <= 2 * k - 1:
+                p = (L - k) + key % (2 * k - L)  # one site covered by every window
+            else:
+                p = key % spacing
+            first_delta = (1 + (key // 64) % 2).astype(np.uint8)  # 1 or 2
+            delta = np.where(first_delta == 1, np.uint8(2), np.uint8(3)).astype(np.uint8) if second else first_delta
+            rel = idx[None, :] - p[:, None]
+            mask = (rel >= 0) & (rel % spacing == 0)
+            block = np.where(mask, (block + delta[:, None]) & 3, block).astype(np.uint8)
+            codes[d[:, None] + idx[None, :]] = block
+
+    if pick.size:
+        copy_with_snp(pick, pick + 1, False)
+        if triple.any():
+            copy_with_snp(pick[triple], pick[triple] + 2, True)
+
+    # ---- hot motifs ---------------------------------------------------------------------------
+    used = np.zeros(n_str, dtype=bool)
+    if pick.size:
+        used[pick] = used[pick + 1] = True
+        used[pick[triple] + 2] = True
+    flank = 10
+    need = m + 2 * flank
+    hosts = np.nonzero((lens >= need + 2) & ~used)[0]
+    n_copies_total = int(min(hosts.size, motif_copy_fraction * n_str))
+    if num_motifs > 0 and n_copies_total > 0:
+        magic = np.uint64(_xxh64_u64(build_seed, 0))
+        n_try = max(1 << 22, 4000 * num_motifs)
+        cand_m = rng.integers(0, 1 << (2 * m), n_try, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            hashes = (cand_m * _MUL) ^ magic
+        best = np.argsort(hashes)[: num_motifs * 2]
+        motifs = np.unique(cand_m[best])[:num_motifs]
+        rng.shuffle(motifs)
+        # Zipf-like copy counts, at least 2, capped, rescaled to the budget
+        w = 1.0 / np.arange(1, motifs.size + 1) ** 0.9
+        counts = np.maximum(2, (w / w.sum() * n_copies_total).astype(np.int64))
+        counts = np.minimum(counts, min(max_motif_copies, 4 ** flank - 1))
+        while counts.sum() > n_copies_total and counts.max() > 2:
+            counts = np.maximum(2, (counts * 0.95).astype(np.int64))
+        n_used = int(min(counts.sum(), hosts.size))
+        host_ids = rng.choice(hosts, n_used, replace=False)
+        motif_of = np.repeat(np.arange(motifs.size), counts)[:n_used]
+        copy_no = (np.arange(counts.sum()) - np.repeat(np.cumsum(counts) - counts, counts))[:n_used]
+        # segment = D + motif + D
+        seg = np.empty((n_used, need), dtype=np.uint8)
+        digits = np.stack([(copy_no >> (2 * (flank - 1 - j))) & 3 for j in range(flank)], axis=1).astype(np.uint8)
+        mot = np.stack([(motifs[motif_of] >> np.uint64(2 * j)) & np.uint64(3) for j in range(m)], axis=1).astype(np.uint8)
+        seg[:, :flank] = digits
+        seg[:, flank:flank + m] = mot
+        seg[:, flank + m:] = digits
+        at = begin[host_ids] + (lens[host_ids] - need) // 2
+        codes[at[:, None] + np.arange(need)[None, :]] = seg
+    words = pack_codes(codes)
+    return words, endpoints
+
+
+def draw_queries(d, n: int, positive_fraction: float = 0.5, seed: int = 0x5555AAAA) -> np.ndarray:
+    """The reference's benchmark mix (tools/perf.hpp:38-51,67-74): positives = access(random id) with
+    every other one reverse-complemented, negatives = uniformly random k-mers; shuffled; seeded."""
+    rng = np.random.default_rng(seed)
+    W, k = d.words_per_kmer(), d.k()
+    n_pos = int(n * positive_fraction)
+    ids = rng.integers(0, d.num_kmers(), n_pos, dtype=np.uint64)
+    pos = d.access_packed(ids).reshape(n_pos, W)
+    if W == 1:
+        x = pos[::2, 0] ^ np.uint64(0xAAAAAAAAAAAAAAAA)
+        x = x.byteswap()
+        x = ((x & np.uint64(0x0F0F0F0F0F0F0F0F)) << np.uint64(4)) | ((x >> np.uint64(4)) & np.uint64(0x0F0F0F0F0F0F0F0F))
+        x = ((x & np.uint64(0x3333333333333333)) << np.uint64(2)) | ((x >> np.uint64(2)) & np.uint64(0x3333333333333333))
+        pos[::2, 0] = x >> np.uint64(64 - 2 * k)
+    else:
+        def rc64(v):
+            v = v ^ np.uint64(0xAAAAAAAAAAAAAAAA)
+            v = v.byteswap()
+            v = ((v & np.uint64(0x0F0F0F0F0F0F0F0F)) << np.uint64(4)) | ((v >> np.uint64(4)) & np.uint64(0x0F0F0F0F0F0F0F0F))
+            return ((v & np.uint64(0x3333333333333333)) << np.uint64(2)) | ((v >> np.uint64(2)) & np.uint64(0x3333333333333333))
+        lo, hi = pos[::2, 0].copy(), pos[::2, 1].copy()
+        r_hi, r_lo = rc64(lo), rc64(hi)  # word order swaps (reference include/kmer.hpp:162)
+        s = np.uint64(128 - 2 * k)       # 2 <= s < 64 for 33 <= k <= 63
+        pos[::2, 0] = (r_lo >> s) | (r_hi << (np.uint64(64) - s))
+        pos[::2, 1] = r_hi >> s
+    neg = rng.integers(0, 1 << 63, (n - n_pos, W), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (n - n_pos, W), dtype=np.uint64)
+    if W == 1:
+        neg[:, 0] &= np.uint64((1 << (2 * k)) - 1)
+    else:
+        neg[:, 1] &= np.uint64((1 << (2 * k - 64)) - 1)
+    allq = np.concatenate([pos, neg])
+    rng.shuffle(allq, axis=0)
+    return np.ascontiguousarray(allq).reshape(-1)

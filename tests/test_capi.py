@@ -1,0 +1,121 @@
+"""CPU: the C-ABI library loads, exports every symbol include/sshash_amd.h declares, and fails
+loudly (never silently on a CPU path) when there is no GPU."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sshash_amd
+from sshash_amd import _binding
+from conftest import ROOT, has_gpu
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sshash_amd.h")).read()
+    return sorted(set(re.findall(r"\b(sshash_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = ctypes.CDLL(sshash_amd.library_path())
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/sshash_amd.h but not exported"
+    assert set(_binding.C_ABI_SYMBOLS) == set(names)
+
+
+def test_only_c_types_in_signatures():
+    text = open(os.path.join(ROOT, "include", "sshash_amd.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)  # signatures only, comments stripped
+    assert "torch" not in code and "std::" not in code and "hipStream_t" not in code and "hip_runtime" not in code
+
+
+def test_error_codes_and_messages(tmp_path, case_skew_regular):
+    with pytest.raises(sshash_amd.SSHashError) as e:
+        sshash_amd.Dictionary.load(str(tmp_path / "does_not_exist.sshash"))
+    assert e.value.status == 2 and "error in opening the file" in str(e.value)  # src/query.cpp:128 wording
+    junk = tmp_path / "junk.sshash"
+    junk.write_bytes(b"not an index" * 10)
+    with pytest.raises(sshash_amd.SSHashError) as e:
+        sshash_amd.Dictionary.load(str(junk))
+    assert e.value.status == 3
+    # major version mismatch (include/util.hpp:191-195)
+    raw = bytearray(open(case_skew_regular.index_path, "rb").read())
+    raw[8] = 4
+    bad = tmp_path / "old.sshash"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(sshash_amd.SSHashError) as e:
+        sshash_amd.Dictionary.load(str(bad))
+    assert e.value.status == 4 and "MAJOR index version mismatch" in str(e.value)
+    # truncated file
+    cut = tmp_path / "cut.sshash"
+    cut.write_bytes(bytes(raw[: len(raw) // 2]).replace(b"\x04", b"\x05", 1))
+    with pytest.raises(sshash_amd.SSHashError):
+        sshash_amd.Dictionary.load(str(cut))
+    with pytest.raises(sshash_amd.SSHashError) as e:
+        sshash_amd.Dictionary.build(str(tmp_path / "nope.fa"))
+    assert e.value.status == 2
+    short = tmp_path / "short.fa"
+    short.write_text(">\nACGT\n")
+    with pytest.raises(sshash_amd.SSHashError) as e:
+        sshash_amd.Dictionary.build(str(short), k=31, m=13)
+    assert e.value.status == 7
+    with pytest.raises(sshash_amd.SSHashError) as e:
+        case_skew_regular.dict.access(case_skew_regular.gt.num_kmers)
+    assert e.value.status == 1
+
+
+def test_save_load_roundtrip_and_info(case_skew_canonical, tmp_path):
+    d = case_skew_canonical.dict
+    p = str(tmp_path / "again.sshash")
+    d.save(p)
+    assert open(p, "rb").read() == open(case_skew_canonical.index_path, "rb").read()
+    d2 = sshash_amd.Dictionary.load(p)
+    for f in ("k", "m", "canonical", "num_kmers", "num_strings", "num_bases", "num_minimizers", "num_bits", "vnum"):
+        assert getattr(d, f)() == getattr(d2, f)()
+    assert d2.vnum() == (5, 1, 1)
+    ids = np.arange(0, d.num_kmers(), 97, dtype=np.uint64)
+    assert (d.access_packed(ids) == d2.access_packed(ids)).all()
+
+
+def test_fasta_last_line_without_newline_is_dropped(tmp_path):
+    """Reference quirk kept: `if (is.eof()) break;` after reading the sequence line drops a final
+    record that is not newline-terminated (src/builder/encode_strings.cpp:139-140)."""
+    a, b = "ACGTTGCATGCATGCAACGTAGCTAGCTAGGATCGAT", "TTGACCAGTAGGGATACCCATGAGATTTACGGACAGT"
+    f1 = tmp_path / "nl.fa"
+    f1.write_text(f">\n{a}\n>\n{b}\n")
+    f2 = tmp_path / "nonl.fa"
+    f2.write_text(f">\n{a}\n>\n{b}")
+    assert sshash_amd.Dictionary.build(str(f1), k=31, m=13).num_strings() == 2
+    assert sshash_amd.Dictionary.build(str(f2), k=31, m=13).num_strings() == 1
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_lookup_without_gpu_fails_loudly(case_skew_regular):
+    d = case_skew_regular.dict
+    q = case_skew_regular.queries(4, 4)
+    with pytest.raises(sshash_amd.SSHashError) as e:
+        d.to_device(0)
+    assert e.value.status == 5 and "no CPU fallback" in str(e.value)
+    with pytest.raises(sshash_amd.SSHashError) as e:
+        d.lookup(q)
+    assert e.value.status == 5
+    with pytest.raises(sshash_amd.SSHashError):
+        d.is_member(q)
+    with pytest.raises(sshash_amd.SSHashError):
+        d.streaming_query(["ACGT" * 20])
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product path must not include / import / link anything under oracle/."""
+    for base, _, files in os.walk(os.path.join(ROOT, "sshash_amd")):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                assert "oracle" not in text.lower().replace("no pure-python", ""), f"{f} mentions the oracle"
+    hdr = open(os.path.join(ROOT, "include", "sshash_amd.h")).read()
+    assert "oracle" not in hdr.lower()

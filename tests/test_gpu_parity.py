@@ -1,0 +1,173 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the input-order ground truth.
+
+Integer/index work: every comparison is bit-exact.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import sshash_amd
+from conftest import ALL_SMALL_CASES, SE_FASTA, random_dna
+
+pytestmark = pytest.mark.gpu
+
+U64_FIELDS = ["kmer_id", "kmer_id_in_string", "kmer_offset", "string_id", "string_begin", "string_end"]
+
+
+def _check_full(case, queries, check_rc=True):
+    d = case.dict.to_device(0)
+    got = d.lookup(queries, check_reverse_complement=check_rc, full=True)
+    want = case.oracle.lookup_packed(queries, check_rc)
+    for f in U64_FIELDS:
+        assert (getattr(got, f) == want[f]).all(), f"{case.name}: field {f} differs from the oracle"
+    assert (got.kmer_orientation.astype(np.int64) == want["kmer_orientation"]).all(), "orientation differs"
+    assert (got.minimizer_found == want["minimizer_found"]).all(), "minimizer_found differs"
+    # ids-only kernel variant and is_member agree with the full one
+    ids = d.lookup(queries, check_reverse_complement=check_rc).kmer_id
+    assert (ids == want["kmer_id"]).all()
+    mem = d.is_member(queries, check_reverse_complement=check_rc)
+    assert (mem == (want["kmer_id"] != sshash_amd.INVALID_U64)).all()
+    return got, want
+
+
+@pytest.mark.parametrize("case_name", ["case_se_regular", "case_se_canonical"] + ALL_SMALL_CASES + ["case_k63_regular"])
+def test_lookup_matches_oracle_and_ground_truth(case_name, request):
+    case = request.getfixturevalue(case_name)
+    n = 60000 if case.gt.num_kmers > 100000 else 4000
+    queries = case.queries(n, n, seed=11)
+    got, want = _check_full(case, queries)
+    g = case.gt.lookup(queries)
+    for f in U64_FIELDS:
+        assert (getattr(got, f) == g[f]).all(), f"{case.name}: field {f} differs from the ground truth"
+    found = g["found"]
+    assert (got.kmer_orientation[found] == g["kmer_orientation"][found]).all()
+    assert found.sum() >= n  # every positive was found (negatives may collide only by astronomic luck)
+
+
+@pytest.mark.parametrize("case_name", ["case_se_regular", "case_skew_regular"])
+def test_no_reverse_complement_check(case_name, request):
+    case = request.getfixturevalue(case_name)
+    queries = case.queries(3000, 3000, seed=2)
+    got, want = _check_full(case, queries, check_rc=False)
+    # half of the positives were reverse-complemented: they must now be misses
+    assert (got.kmer_id == sshash_amd.INVALID_U64).sum() >= 3000 + 1400
+
+
+@pytest.mark.parametrize("case_name", ["case_skew_regular", "case_skew_canonical", "case_k63_canonical", "case_small_k"])
+def test_every_kmer_of_the_input_in_file_order(case_name, request):
+    """The reference's own contract, test/check_from_file.hpp:38-83: stream the build input, lower-case
+    every other sequence, reverse-complement every other k-mer: ids must be 0,1,2,..."""
+    case = request.getfixturevalue(case_name)
+    d = case.dict.to_device(0)
+    k = case.k
+    comp = str.maketrans("ACGTacgt", "TGCAtgca")
+    kmers, orient = [], []
+    count = 0
+    for s_id, s in enumerate(case.sequences):
+        if s_id % 2 == 0:
+            s = s.lower()
+        for i in range(len(s) - k + 1):
+            x = s[i:i + k]
+            if count % 2 == 0:
+                x = x.translate(comp)[::-1]
+                orient.append(-1)
+            else:
+                orient.append(1)
+            kmers.append(x)
+            count += 1
+    res = d.lookup(kmers, full=True)
+    assert (res.kmer_id == np.arange(count, dtype=np.uint64)).all(), "wrong id assigned"
+    assert (res.kmer_orientation == np.array(orient, dtype=np.int8)).all()
+    sizes = res.string_end - res.string_begin - np.uint64(k - 1)
+    assert (res.kmer_id_in_string < sizes).all()
+    # access round trip: access(lookup(x).kmer_id) is x or its reverse complement (:146-155)
+    for i in range(0, count, max(1, count // 200)):
+        back = d.access(int(res.kmer_id[i]))
+        assert back.upper() in (kmers[i].upper(), kmers[i].upper().translate(comp)[::-1])
+
+
+def test_ascii_entry_point_ignores_case_and_needs_no_terminator(case_skew_regular):
+    case = case_skew_regular
+    d = case.dict.to_device(0)
+    s = case.sequences[3]
+    kmers = [s[i:i + case.k] for i in range(len(s) - case.k + 1)]
+    up = d.lookup(kmers).kmer_id
+    low = d.lookup([x.lower() for x in kmers]).kmer_id
+    assert (up == low).all() and (up != sshash_amd.INVALID_U64).all()
+    # n*k bytes back to back, no NUL: reference reads exactly k chars (src/dictionary.cpp:58-63)
+    flat = np.frombuffer("".join(kmers).encode(), dtype=np.uint8)
+    assert (d.lookup(flat).kmer_id == up).all()
+    want = case.oracle.lookup_ascii(flat)
+    assert (want["kmer_id"] == up).all()
+
+
+def test_invalid_characters_are_silently_mapped(case_skew_regular):
+    """lookup(char const*) does not validate (only streaming_query does): (c>>1)&3 maps any byte."""
+    case = case_skew_regular
+    d = case.dict.to_device(0)
+    s = case.sequences[0][: case.k]
+    weird = "N" + s[1:]  # 'N' = 0x4E -> (0x4E>>1)&3 = 3 = G
+    as_g = "G" + s[1:]
+    a = d.lookup([weird], full=True)
+    b = d.lookup([as_g], full=True)
+    assert a.kmer_id[0] == b.kmer_id[0]
+    assert (case.oracle.lookup_ascii(np.frombuffer(weird.encode(), dtype=np.uint8))["kmer_id"][0] == a.kmer_id[0])
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 257, 1000])
+def test_empty_and_ragged_batches(case_skew_regular, n):
+    case = case_skew_regular
+    d = case.dict.to_device(0)
+    queries = case.queries(n - n // 2, n // 2, seed=n)
+    got = d.lookup(queries).kmer_id
+    assert got.shape == (n,)
+    if n:
+        assert (got == case.oracle.lookup_ids(queries)).all()
+
+
+def test_full_size_roundtrip_every_kmer(case_se_regular, case_se_canonical):
+    """test/check.hpp:29-49 at full size: lookup(access(id)).kmer_id == id for EVERY id (4.79 M k-mers),
+    via device buffers, plus a checksum of the reverse-complemented batch."""
+    import torch
+
+    for case in (case_se_regular, case_se_canonical):
+        d = case.dict.to_device(0)
+        n = d.num_kmers()
+        packed = d.access_packed(np.arange(n, dtype=np.uint64))
+        assert (packed == case.gt.kmers(np.arange(n))).all()
+        dq = torch.from_numpy(packed.view(np.int64)).cuda()
+        out = torch.empty(n, dtype=torch.int64, device="cuda")
+        ori = torch.empty(n, dtype=torch.int8, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        d.lookup_device(0, dq.data_ptr(), n, out.data_ptr(), stream=s, kmer_orientation=ori.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(out, torch.arange(n, dtype=torch.int64, device="cuda"))
+        assert bool((ori == 1).all())
+        from oracle.ground_truth import _revcomp_u64
+
+        rc = torch.from_numpy(_revcomp_u64(packed, case.k).view(np.int64)).cuda()
+        d.lookup_device(0, rc.data_ptr(), n, out.data_ptr(), stream=s, kmer_orientation=ori.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(out, torch.arange(n, dtype=torch.int64, device="cuda"))
+        assert bool((ori == -1).all())
+
+
+def test_negative_batch_full_size(case_se_regular):
+    """test/check.hpp:78-96 with a real ground truth: 1M uniform random 31-mers, none may be found
+    unless the ground truth says so."""
+    case = case_se_regular
+    d = case.dict.to_device(0)
+    rng = np.random.default_rng(123)
+    q = rng.integers(0, 1 << 62, 1_000_000, dtype=np.uint64)
+    got = d.lookup(q).kmer_id
+    g = case.gt.lookup(q)
+    assert (got == g["kmer_id"]).all()
+
+
+def test_index_file_roundtrip_on_gpu(case_skew_canonical, tmp_path):
+    case = case_skew_canonical
+    d2 = sshash_amd.Dictionary.load(case.index_path).to_device(0)
+    q = case.queries(2000, 2000, seed=9)
+    assert (d2.lookup(q).kmer_id == case.oracle.lookup_ids(q)).all()
+    assert (d2.k(), d2.m(), d2.canonical(), d2.num_kmers()) == (case.k, case.m, True, case.gt.num_kmers)

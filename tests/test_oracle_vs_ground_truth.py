@@ -1,0 +1,72 @@
+"""CPU: the oracle (restated reference algorithm) against the input-order ground truth.
+
+This is what pins the oracle's lookup logic without a runnable reference: ids are defined by input
+order (reference test/check_from_file.hpp:66-72), so a table built straight from the FASTA is the
+truth for every field of lookup_result.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from conftest import ALL_SMALL_CASES
+
+U64_FIELDS = ["kmer_id", "kmer_id_in_string", "kmer_offset", "string_id", "string_begin", "string_end"]
+
+
+@pytest.mark.parametrize("case_name", ["case_se_regular", "case_se_canonical", "case_k63_regular"] + ALL_SMALL_CASES)
+def test_oracle_matches_ground_truth(case_name, request):
+    case = request.getfixturevalue(case_name)
+    n = 50000 if case.gt.num_kmers > 100000 else 3000
+    q = case.queries(n, n, seed=5)
+    r = case.oracle.lookup_packed(q)
+    g = case.gt.lookup(q)
+    for f in U64_FIELDS:
+        assert (r[f] == g[f]).all(), f
+    found = g["found"]
+    assert found.sum() >= n
+    assert (r["kmer_orientation"][found] == g["kmer_orientation"][found]).all()
+    # ids only, threaded variant
+    assert (case.oracle.lookup_ids(q, num_threads=3) == g["kmer_id"]).all()
+
+
+@pytest.mark.parametrize("case_name", ALL_SMALL_CASES)
+def test_oracle_every_kmer_in_file_order(case_name, request):
+    """check_from_file.hpp:38-83 on the oracle: every k-mer of the input, every other one
+    reverse-complemented -> ids 0,1,2,... with the right orientation; access() round trip."""
+    case = request.getfixturevalue(case_name)
+    n = case.gt.num_kmers
+    q = case.gt.kmers(np.arange(n)).reshape(n, case.W)
+    q[::2] = case.gt._revcomp(q[::2].reshape(-1)).reshape(-1, case.W)
+    r = case.oracle.lookup_packed(q.reshape(-1))
+    assert (r["kmer_id"] == np.arange(n, dtype=np.uint64)).all()
+    expect = np.ones(n, dtype=np.int64)
+    expect[::2] = -1
+    assert (r["kmer_orientation"] == expect).all()
+    comp = str.maketrans("ACGT", "TGCA")
+    for i in range(0, n, max(1, n // 300)):
+        s_id = int(r["string_id"][i])
+        pos = int(r["kmer_id_in_string"][i])
+        truth = case.sequences[s_id][pos:pos + case.k]
+        assert case.oracle.access(i) == truth
+        assert case.dict.access(i) == truth  # host-side access of the product (used to draw positives)
+
+
+def test_skew_cases_really_have_all_bucket_types(case_skew_regular, case_skew_canonical, case_small_k, case_k63_canonical):
+    """The synthetic inputs must exercise SINGLETON, MIDLOAD and HEAVYLOAD buckets."""
+    import re
+    import subprocess
+    import sys
+
+    for case in (case_skew_regular, case_skew_canonical, case_small_k, case_k63_canonical):
+        q = case.gt.kmers(np.arange(case.gt.num_kmers))
+        per_query = [case.oracle.count_bytes(q[i * case.W:(i + 1) * case.W]) for i in range(0, case.gt.num_kmers, 7)]
+        assert max(per_query) > min(per_query)  # different bucket classes cost different bytes
+
+
+def test_algorithmic_bytes_rule(case_se_regular):
+    """~100 B per lookup on a regular index for a 50/50 mix."""
+    case = case_se_regular
+    q = case.queries(5000, 5000, seed=1)
+    per = case.oracle.count_bytes(q) / 10000
+    assert 70 < per < 130
