@@ -38,6 +38,18 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def effective_cores() -> int:
+    """CPUs this process may actually use: min(affinity, cgroup quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def get_index(args, rank: int, world: int, barrier):
     """Build the synthetic dictionary once (rank 0), cache it on local disk, load it on every rank."""
     import sshash_amd
@@ -157,7 +169,7 @@ def main():
         ora = O.OracleIndex(index_path)
         sample = 200_000
         got = out[:sample].cpu().numpy().view(np.uint64)
-        want = ora.lookup_ids(queries[: sample * W], num_threads=8)
+        want = ora.lookup_ids(queries[: sample * W], num_threads=effective_cores())
         if not (got == want).all():
             raise SystemExit("PARITY FAILURE: GPU ids differ from the CPU oracle")
         found = float((got != np.uint64(0xFFFFFFFFFFFFFFFF)).mean())
@@ -178,7 +190,7 @@ def main():
                     "algorithmic_bytes_per_lookup": round(bytes_per_lookup, 2), "avg_kernel_ms": round(avg_kernel_ms, 3)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
+            cores = effective_cores()
             m = min(args.cpu_sample, n)
             q1 = queries[: m * W]
             t0 = time.perf_counter()
@@ -192,7 +204,8 @@ def main():
             ta = time.perf_counter() - t0
             assert (ids_all[: min(big, n)] == out[:big].cpu().numpy().view(np.uint64)).all()
             cpu = {"value": round(big / ta, 1), "unit": "lookups/s", "cores": cores, "kind": "port",
-                   "sample": f"{big} queries of the same batch on {cores} threads (contiguous chunks); "
+                   "sample": f"{big} queries of the same batch on {cores} threads (= usable CPUs: affinity {os.cpu_count()}, "
+                             f"cgroup quota applied; contiguous chunks); "
                              f"1 thread: {m / t1:.0f} lookups/s = {t1 / m * 1e9:.0f} ns/lookup over {m} queries",
                    "single_thread_value": round(m / t1, 1)}
         total = n * world * args.steps

@@ -39,6 +39,25 @@ static std::vector<granule> make_granules(host_index const& idx, uint32_t num_th
     return g;
 }
 
+/* Widen the packed control codewords to u64 entries carrying the bucket minimizer's fingerprint
+   (device_layout.hpp (3)). One lane per minimizer id; runs once per upload. */
+__global__ void __launch_bounds__(256)
+widen_codewords_kernel(const dict_view d, const uint64_t* __restrict__ packed, const uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t code = packed_get(packed, i, d.cw_width);
+    uint64_t first;  // offset of the bucket's first minimizer position
+    if ((code & 1) == 0) first = code >> 1;
+    else if ((code & 3) == 1) {
+        const uint32_t size = uint32_t((code >> 2) & (MAX_BUCKET_SMALL - 1)) + 2;
+        first = packed_get(d.mid_load, uint64_t(d.begin_buckets_of_size[size]) + (code >> (2 + MIN_L)) * size, d.off_width);
+    } else {
+        first = packed_get(d.heavy_load, code >> 5, d.off_width);
+    }
+    const uint64_t mmer = read_window<1>(d.granules, first, d.m).kmer.w[0];
+    out[i] = code | (minimizer_fingerprint(mmer, d.m, d.canonical != 0, d.cw_width) << d.cw_width);
+}
+
 engine::engine(std::shared_ptr<host_index> idx) : m_idx(std::move(idx)) {}
 engine::~engine() = default;
 
@@ -88,13 +107,30 @@ void engine::to_device(int device) {
     }
     v.endpoints = rep->put(idx.endpoints);
     v.minimizers = rep->put_mphf(idx.minimizers_mphf);
-    v.codewords = rep->put(idx.control_codewords.words);
     v.cw_width = idx.control_codewords.width;
     v.off_width = idx.mid_load_buckets.width;
     v.begin_buckets_of_size = rep->put(idx.begin_buckets_of_size);
     v.mid_load = rep->put(idx.mid_load_buckets.words);
     v.heavy_load = rep->put(idx.heavy_load_buckets.words);
     v.heavy_size = idx.heavy_load_buckets.size;
+    {
+        const uint64_t n = idx.control_codewords.size;
+        uint64_t* packed = nullptr;
+        uint64_t* wide = nullptr;
+        const size_t packed_bytes = idx.control_codewords.words.size() * sizeof(uint64_t);
+        HIP_CHECK(hipMalloc(&packed, packed_bytes));
+        HIP_CHECK(hipMemcpy(packed, idx.control_codewords.words.data(), packed_bytes, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMalloc(&wide, std::max<uint64_t>(n, 1) * sizeof(uint64_t)));
+        rep->allocations.push_back(wide);
+        rep->bytes += std::max<uint64_t>(n, 1) * sizeof(uint64_t);
+        if (n) {
+            hipLaunchKernelGGL(widen_codewords_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, 0, v, packed, n, wide);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+        HIP_CHECK(hipFree(packed));
+        v.codewords = wide;
+    }
     std::vector<skew_part_dev> skew(8);
     for (uint32_t p = 0; p < 8; ++p) {
         std::memset(&skew[p], 0, sizeof(skew_part_dev));

@@ -80,7 +80,8 @@ struct bucket_t {
     uint64_t begin;         // index of the bucket in mid_load (MIDLOAD only)
     uint32_t size;
     bool heavy;
-    bool valid;  // false: skew index pointed outside heavy_load (absent k-mer)
+    bool valid;      // false: skew index pointed outside heavy_load (absent k-mer)
+    bool other_key;  // the codeword's fingerprint proves the bucket belongs to another minimizer
 };
 
 /* minimizer -> MPHF -> control codeword -> bucket (include/sparse_and_skew_index.hpp:112-137) */
@@ -92,8 +93,19 @@ __device__ __forceinline__ bucket_t resolve_bucket(dict_view const& d, skew_part
     b.size = 1;
     b.heavy = false;
     b.valid = true;
+    b.other_key = false;
+    b.first_offset = 0;
     const uint64_t id = mphf_eval(d.minimizers, city128_u64(minimizer, d.minimizers.seed));
-    const uint64_t code = packed_get(d.codewords, id, d.cw_width);
+    const uint64_t entry = d.codewords[id];
+    const uint64_t code = entry & low_mask(d.cw_width);
+    if ((entry >> d.cw_width) != minimizer_fingerprint(minimizer, d.m, d.canonical != 0, d.cw_width)) {
+        /* same outcome as the m-mer comparison at the bucket's first offset failing
+           (spectrum_preserving_string_set.hpp:46-65): a miss whose minimizer_found is true only
+           for HEAVYLOAD buckets */
+        b.other_key = true;
+        b.heavy = (code & 3) == 3;
+        return b;
+    }
     if ((code & 1) == 0) {  // SINGLETON
         b.first_offset = code >> 1;
     } else if ((code & 3) == 1) {  // MIDLOAD
@@ -128,6 +140,7 @@ template <int W>
 __device__ __forceinline__ hit_t probe_regular(dict_view const& d, skew_part_dev const* __restrict__ skew,
                                                kmer_w<W> const& x, minimizer_t mini) {
     const bucket_t b = resolve_bucket<W>(d, skew, mini.value, x);
+    if (b.other_key) return miss(b.heavy);
     if (!b.valid) return miss(true);
     hit_t h = miss(true);
     uint64_t p = b.first_offset;
@@ -165,6 +178,7 @@ __device__ __forceinline__ hit_t probe_canonical(dict_view const& d, skew_part_d
                                                  kmer_w<W> const& x, kmer_w<W> const& x_rc, minimizer_t mini) {
     const kmer_w<W> key = kmer_less<W>(x_rc, x) ? x_rc : x;  // src/dictionary.cpp:53
     const bucket_t b = resolve_bucket<W>(d, skew, mini.value, key);
+    if (b.other_key) return miss(b.heavy);
     if (!b.valid) return miss(true);
     hit_t h = miss(true);
     uint64_t p = b.first_offset;

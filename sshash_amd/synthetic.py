@@ -177,5 +177,5 @@ def draw_queries(d, n: int, positive_fraction: float = 0.5, seed: int = 0x5555AA
     else:
         neg[:, 1] &= np.uint64((1 << (2 * k - 64)) - 1)
     allq = np.concatenate([pos, neg])
-    rng.shuffle(allq, axis=0)
+    allq = allq[rng.permutation(n)]  # (a row shuffle of an (n,1) array is an order of magnitude slower)
     return np.ascontiguousarray(allq).reshape(-1)

@@ -1,0 +1,80 @@
+"""CPU, world_size 2, gloo: the multi-process harness of bench.py (N > 1 path).
+
+What N > 1 adds to the single-GPU path is coordination only (the lookup itself shards with no
+collective): rank 0 builds and caches the index, every rank loads the same file after a barrier, each
+rank draws its OWN query batch, elapsed time is MAX-reduced, totals are summed. That logic is exercised
+here with the CPU oracle standing in for the device (no GPU in this container)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import textwrap
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent(
+    """
+    import argparse, os, sys, time
+    import numpy as np
+    sys.path.insert(0, sys.argv[1])
+    import torch, torch.distributed as dist
+    import bench
+    from sshash_amd.synthetic import draw_queries
+    from oracle import oracle as O
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo")
+    args = argparse.Namespace(bases=300_000, k=31, m=15, canonical=False, seed=77, cache_dir=sys.argv[2], verbose=False)
+    d, path = bench.get_index(args, rank, world, dist.barrier)
+    # every rank sees the same dictionary
+    sig = torch.tensor([d.num_kmers(), d.num_strings(), int(d.access_packed(np.arange(0, d.num_kmers(), 101)).sum() % (1 << 62))], dtype=torch.int64)
+    gathered = [torch.zeros_like(sig) for _ in range(world)]
+    dist.all_gather(gathered, sig)
+    assert all(torch.equal(g, gathered[0]) for g in gathered), "ranks loaded different dictionaries"
+    # each rank draws its own batch (different seed), looks it up, totals are reduced
+    q = draw_queries(d, 20000, 0.5, seed=args.seed + 7919 * rank)
+    first = torch.tensor([int(q[0] >> 1)], dtype=torch.int64)
+    firsts = [torch.zeros_like(first) for _ in range(world)]
+    dist.all_gather(firsts, first)
+    assert len({int(f) for f in firsts}) == world, "ranks drew the same batch"
+    t0 = time.perf_counter()
+    ids = O.OracleIndex(path).lookup_ids(q)
+    elapsed = torch.tensor([time.perf_counter() - t0 + 0.01 * rank], dtype=torch.float64)
+    mine = float(elapsed)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    assert float(elapsed) >= mine
+    found = torch.tensor([int((ids != np.uint64(0xFFFFFFFFFFFFFFFF)).sum())], dtype=torch.int64)
+    dist.all_reduce(found)
+    if rank == 0:
+        assert int(found) == 10000 * world, int(found)
+        print("OK", int(found), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    """
+)
+
+
+def test_two_rank_harness_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(cache)], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert "OK 20000" in outs[0]
+    assert len([f for f in os.listdir(cache) if f.endswith(".sshash")]) == 1  # built once, by rank 0
+
+
+def test_effective_cores_is_positive():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.effective_cores() >= 1
