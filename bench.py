@@ -55,11 +55,12 @@ def get_index(args, rank: int, world: int, barrier):
     import sshash_amd
     from sshash_amd.synthetic import make_spss
 
-    key = f"v3-{args.bases}-{args.k}-{args.m}-{int(args.canonical)}-{args.seed}"
+    mean_len = getattr(args, "mean_len", 85.0)
+    key = f"v3-{args.bases}-{args.k}-{args.m}-{int(args.canonical)}-{args.seed}-{mean_len}"
     path = os.path.join(args.cache_dir, "sshash_amd_bench_" + hashlib.sha1(key.encode()).hexdigest()[:16] + ".sshash")
     if rank == 0 and not os.path.exists(path):
         t0 = time.time()
-        words, endpoints = make_spss(args.bases, k=args.k, m=args.m, seed=args.seed)
+        words, endpoints = make_spss(args.bases, k=args.k, m=args.m, seed=args.seed, mean_len=mean_len)
         log(f"synthetic SPSS: {endpoints.size - 1} strings, {int(endpoints[-1])} bases in {time.time() - t0:.1f}s")
         t0 = time.time()
         d = sshash_amd.Dictionary.build_from_packed(words, endpoints, k=args.k, m=args.m, canonical=args.canonical,
@@ -89,6 +90,7 @@ def main():
     ap.add_argument("--queries", type=int, default=100_000_000, help="queries per GPU per step")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--m", type=int, default=21)
+    ap.add_argument("--mean-len", type=float, default=85.0, help="mean string length of the synthetic SPSS")
     ap.add_argument("--canonical", action="store_true")
     ap.add_argument("--seed", type=int, default=0x5555AAAA)
     ap.add_argument("--cache-dir", default=os.environ.get("SSHASH_BENCH_CACHE", "/tmp"))

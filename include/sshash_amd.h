@@ -131,6 +131,9 @@ sshash_status sshash_is_member_ascii(const sshash_dict* d, const char* kmers, ui
  *      used to draw positive queries as tools/perf.hpp:38-51 does ---------------------------- */
 sshash_status sshash_access(const sshash_dict* d, uint64_t kmer_id, char* out_k_chars);
 sshash_status sshash_access_packed(const sshash_dict* d, const uint64_t* kmer_ids, uint64_t n, uint64_t* out_words);
+/* the same on the GPU: device pointers, asynchronous; an id >= num_kmers yields all-ones words */
+sshash_status sshash_access_packed_device(const sshash_dict* d, int device, const uint64_t* kmer_ids, uint64_t n,
+                                          uint64_t* out_words, void* hip_stream);
 
 /* ---- dictionary::streaming_query_from_file (include/dictionary.hpp:81-82, src/query.cpp:118-175)
  *      and streaming_query<Dict,canonical> over reads in memory (include/streaming_query.hpp) -- */

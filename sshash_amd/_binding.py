@@ -141,6 +141,7 @@ def _load() -> C.CDLL:
         "sshash_is_member_ascii": (C.c_int, [P, P, C.c_uint64, C.c_int, P]),
         "sshash_access": (C.c_int, [P, C.c_uint64, P]),
         "sshash_access_packed": (C.c_int, [P, P, C.c_uint64, P]),
+        "sshash_access_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, P, P]),
         "sshash_streaming_query_from_file": (C.c_int, [P, C.c_char_p, C.c_int, C.POINTER(_Report)]),
         "sshash_streaming_query": (C.c_int, [P, P, P, C.c_uint64, C.POINTER(_Report)]),
         "sshash_streaming_query_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, P, P]),
@@ -159,6 +160,7 @@ C_ABI_SYMBOLS = (
     "sshash_load sshash_free sshash_get_info sshash_device_count sshash_to_device sshash_device_bytes "
     "sshash_lookup_packed_device sshash_lookup_ascii_device sshash_lookup_packed sshash_lookup_ascii "
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
+    "sshash_access_packed_device "
     "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device sshash_set_max_blocks"
 ).split()
 
@@ -376,6 +378,10 @@ class Dictionary:
         out = np.empty(ids.size * self.words_per_kmer(), dtype=np.uint64)
         _check(_load().sshash_access_packed(self._h, ids.ctypes.data, ids.size, out.ctypes.data))
         return out
+
+    def access_packed_device(self, device: int, d_ids: int, n: int, d_out: int, stream: int = 0) -> None:
+        _check(_load().sshash_access_packed_device(self._h, int(device), C.c_void_p(d_ids), int(n), C.c_void_p(d_out),
+                                                   C.c_void_p(stream)))
 
     # ---- streaming query ----------------------------------------------------------------------
     @staticmethod

@@ -254,6 +254,12 @@ sshash_status sshash_access_packed(const sshash_dict* d, const uint64_t* kmer_id
     });
 }
 
+sshash_status sshash_access_packed_device(const sshash_dict* d, int device, const uint64_t* kmer_ids, uint64_t n,
+                                          uint64_t* out_words, void* hip_stream) {
+    if (!d || (!kmer_ids && n) || (!out_words && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->access_packed_device(device, kmer_ids, n, out_words, hip_stream); });
+}
+
 sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char* filename, int multiline,
                                                sshash_streaming_report* report) {
     if (!d || !filename || !report) return fail(SSHASH_ERR_ARGUMENT, "null argument");

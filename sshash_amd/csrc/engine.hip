@@ -243,6 +243,40 @@ void engine::lookup_ascii_device(int device, char const* d_kmers, uint64_t n, bo
     launch_any<true>(mode, rep->view, rep->d_skew, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream), m_max_blocks);
 }
 
+/* ---- access(kmer_id) on the device: include/spectrum_preserving_string_set.hpp:114-118 with
+        offsets::id_to_offset (include/offsets.hpp:41-65) as a binary search over the endpoints ---- */
+
+template <int W>
+__global__ void __launch_bounds__(256)
+access_kernel(const dict_view d, const uint64_t* __restrict__ ids, const uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t id = ids[i];
+    if (id >= d.num_kmers) {
+        for (int j = 0; j < W; ++j) out[i * W + j] = INVALID_U64;
+        return;
+    }
+    const uint64_t km1 = d.k - 1;
+    uint64_t lo = 0, hi = d.num_strings - 1;  // largest s with endpoints[s] - s*(k-1) <= id
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (d.endpoints[mid] - mid * km1 <= id) lo = mid;
+        else hi = mid - 1;
+    }
+    const window_t<W> w = read_window<W>(d.granules, id + lo * km1, d.k);
+    for (int j = 0; j < W; ++j) out[i * W + j] = w.kmer.w[j];
+}
+
+void engine::access_packed_device(int device, uint64_t const* d_ids, uint64_t n, uint64_t* d_out, void* stream) const {
+    device_replica const* rep = replica(device);
+    if (n == 0) return;
+    device_guard guard(device);
+    const dim3 grid(uint32_t((n + 255) / 256)), block(256);
+    if (rep->view.k <= 31) hipLaunchKernelGGL(access_kernel<1>, grid, block, 0, hipStream_t(stream), rep->view, d_ids, n, d_out);
+    else hipLaunchKernelGGL(access_kernel<2>, grid, block, 0, hipStream_t(stream), rep->view, d_ids, n, d_out);
+    HIP_CHECK(hipGetLastError());
+}
+
 /* ---- host-buffer path: shard over replicas, chunk through device staging buffers ---------- */
 
 namespace {

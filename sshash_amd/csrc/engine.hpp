@@ -44,6 +44,10 @@ public:
     void lookup_ascii_device(int device, char const* d_kmers, uint64_t n, bool check_rc, out_mode mode,
                              result_view const& d_out, uint8_t* d_member, void* stream) const;
 
+    /* access(kmer_id) for a batch of ids, device buffers: out gets n*W packed words
+       (all-ones for an id >= num_kmers). */
+    void access_packed_device(int device, uint64_t const* d_ids, uint64_t n, uint64_t* d_out, void* stream) const;
+
     /* Host-buffer entry points: shard the batch over every replica, stream chunks through
        pinned staging buffers, results land in the caller's arrays. */
     void lookup_packed_host(uint64_t const* h_kmers, uint64_t n, bool check_rc, out_mode mode,

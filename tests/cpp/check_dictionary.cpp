@@ -1,0 +1,197 @@
+// check_dictionary.cpp -- the reference's self-consistency checkers, re-expressed over the C++ facade
+// (include/sshash_amd.hpp) with batched calls. What is checked, and where the reference checks it:
+//   [A] streaming the build input: every other sequence lower-cased, every other k-mer
+//       reverse-complemented -> kmer_id == running counter, orientation, kmer_id_in_string /
+//       string_id sequencing, string size, access round trip, is_member
+//       (reference test/check_from_file.hpp:9-171)
+//   [B] for every id: access(id) -> lookup -> same id, is_member      (reference test/check.hpp:7-76)
+//   [C] random negative lookups                                        (reference test/check.hpp:78-96)
+// Usage: check_dictionary <input.fa[.gz]> <k> <m> [--canonical]
+#include <zlib.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "sshash_amd.hpp"
+
+using namespace sshash_amd;
+
+static std::string reverse_complement(std::string const& s) {
+    std::string r(s.size(), 'N');
+    for (size_t i = 0; i < s.size(); ++i) {
+        char c = s[s.size() - 1 - i], o = 0;
+        switch (c) {
+            case 'A': o = 'T'; break;  case 'C': o = 'G'; break;  case 'G': o = 'C'; break;  case 'T': o = 'A'; break;
+            case 'a': o = 't'; break;  case 'c': o = 'g'; break;  case 'g': o = 'c'; break;  case 't': o = 'a'; break;
+        }
+        r[i] = o;
+    }
+    return r;
+}
+
+static std::vector<std::string> read_sequences(std::string const& filename, uint64_t k) {
+    gzFile f = gzopen(filename.c_str(), "rb");
+    if (!f) throw std::runtime_error("error in opening the file '" + filename + "'");
+    std::vector<std::string> seqs;
+    std::vector<char> buf(1 << 20);
+    std::string line;
+    bool header = true;
+    auto flush = [&](bool complete) {
+        if (!header && complete && line.size() >= k) seqs.push_back(line);
+        if (complete) header = !header;
+        line.clear();
+    };
+    while (gzgets(f, buf.data(), int(buf.size()))) {
+        size_t n = strlen(buf.data());
+        bool complete = n && buf[n - 1] == '\n';
+        line.append(buf.data(), complete ? n - 1 : n);
+        if (complete) flush(true);
+    }
+    gzclose(f);
+    return seqs;  // an unterminated last line is not a record (as the builder)
+}
+
+#define FAIL(msg)                                   \
+    do {                                            \
+        std::cout << "ERROR: " << msg << std::endl; \
+        return false;                               \
+    } while (0)
+
+static bool check_lookup_access(dictionary const& dict, std::vector<std::string> const& seqs) {
+    const uint64_t k = dict.k();
+    std::cout << "checking correctness of access, positive lookup, and membership..." << std::endl;
+    uint64_t num_kmers = 0, num_sequences = 0;
+    lookup_result prev;
+    prev.string_id = 0;
+    std::string batch;
+    std::vector<int> expected_orientation;
+    auto run = [&]() -> bool {
+        const uint64_t n = expected_orientation.size();
+        if (!n) return true;
+        auto res = dict.lookup_batch(batch.data(), n);
+        auto member = dict.is_member_batch(batch.data(), n);
+        std::string got(k, 0);
+        for (uint64_t i = 0; i < n; ++i, ++num_kmers) {
+            const lookup_result curr = res[i];
+            if (curr.kmer_id != num_kmers) FAIL("wrong id assigned: got " << curr.kmer_id << " expected " << num_kmers);
+            if (curr.kmer_orientation != expected_orientation[i]) FAIL("got orientation " << curr.kmer_orientation);
+            const uint64_t size = curr.string_end - curr.string_begin - k + 1;
+            if (curr.kmer_id_in_string >= size) FAIL("kmer_id_in_string out of range");
+            if (num_kmers == 0) {
+                if (curr.string_id != 0) FAIL("first string_id must be 0");
+            } else if (curr.string_id == prev.string_id) {
+                if (curr.kmer_id_in_string != prev.kmer_id_in_string + 1) FAIL("kmer_id_in_string not sequential");
+                if (curr.string_end != prev.string_end || curr.string_begin != prev.string_begin) FAIL("string bounds changed");
+            } else {
+                if (curr.string_id != prev.string_id + 1) FAIL("string_id not sequential");
+                if (curr.kmer_id_in_string != 0) FAIL("kmer_id_in_string must restart at 0");
+            }
+            prev = curr;
+            if (!member[i]) FAIL("is_member false for an indexed k-mer");
+            if (num_kmers % 997 == 0) {  // access round trip on a sample (one host call each)
+                dict.access(curr.kmer_id, got.data());
+                std::string q(batch.data() + i * k, k);
+                std::transform(q.begin(), q.end(), q.begin(), [](unsigned char c) { return char(std::toupper(c)); });
+                if (got != q && got != reverse_complement(q)) FAIL("access(" << curr.kmer_id << ") = " << got << " but looked up " << q);
+            }
+        }
+        batch.clear();
+        expected_orientation.clear();
+        return true;
+    };
+    uint64_t counter = 0;
+    for (std::string sequence : seqs) {
+        if ((num_sequences & 1) == 0) std::transform(sequence.begin(), sequence.end(), sequence.begin(), [](unsigned char c) { return char(std::tolower(c)); });
+        ++num_sequences;
+        for (uint64_t i = 0; i + k <= sequence.size(); ++i, ++counter) {
+            std::string kmer = sequence.substr(i, k);
+            int orientation = constants::forward_orientation;
+            if ((counter & 1) == 0) {
+                kmer = reverse_complement(kmer);
+                orientation = constants::backward_orientation;
+            }
+            batch += kmer;
+            expected_orientation.push_back(orientation);
+        }
+        if (expected_orientation.size() >= (1u << 20) && !run()) return false;
+    }
+    if (!run()) return false;
+    if (num_kmers != dict.num_kmers()) FAIL("checked " << num_kmers << " k-mers but the dictionary holds " << dict.num_kmers());
+    std::cout << "checked " << num_kmers << " kmers" << std::endl;
+    return true;
+}
+
+static bool check_every_id(dictionary const& dict) {
+    std::cout << "checking correctness of access and positive lookup for every id..." << std::endl;
+    const uint64_t k = dict.k(), n = dict.num_kmers(), chunk = 1 << 20;
+    std::string batch;
+    for (uint64_t begin = 0; begin < n; begin += chunk) {
+        const uint64_t m = std::min(chunk, n - begin);
+        batch.assign(m * k, 0);
+        for (uint64_t i = 0; i < m; ++i) dict.access(begin + i, &batch[i * k]);
+        auto res = dict.lookup_batch(batch.data(), m);
+        auto member = dict.is_member_batch(batch.data(), m);
+        for (uint64_t i = 0; i < m; ++i) {
+            if (res.kmer_id[i] == constants::invalid_uint64) FAIL("kmer with id " << begin + i << " not found");
+            if (res.kmer_id[i] != begin + i) FAIL("expected id " << begin + i << " but got id " << res.kmer_id[i]);
+            if (!member[i]) FAIL("id " << begin + i << " not found by is_member");
+        }
+    }
+    return true;
+}
+
+static bool check_negative(dictionary const& dict) {
+    std::cout << "checking correctness of negative lookup with random kmers..." << std::endl;
+    const uint64_t k = dict.k(), n = std::min<uint64_t>(1000000, dict.num_kmers());
+    std::string batch(n * k, 'A');
+    srand(42);
+    for (auto& c : batch) c = "ACGT"[rand() % 4];
+    auto res = dict.lookup_batch(batch.data(), n);
+    uint64_t found = 0;
+    for (uint64_t i = 0; i < n; ++i) found += res.kmer_id[i] != constants::invalid_uint64;
+    /* the reference only prints when a random k-mer is found (it has no ground truth at hand);
+       for k >= 21 a hit is astronomically unlikely, so treat it as an error */
+    if (found && k >= 21) FAIL(found << " random kmers found");
+    return true;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        std::cerr << "Usage: " << argv[0] << " <input.fa[.gz]> <k> <m> [--canonical]" << std::endl;
+        return 2;
+    }
+    try {
+        build_configuration cfg;
+        cfg.k = std::stoull(argv[2]);
+        cfg.m = std::stoull(argv[3]);
+        cfg.canonical = argc > 4 && std::string(argv[4]) == "--canonical";
+        cfg.num_threads = 8;
+        dictionary dict;
+        dict.build(argv[1], cfg);
+        dict.to_device(0);
+        auto seqs = read_sequences(argv[1], cfg.k);
+        if (!check_lookup_access(dict, seqs)) return 1;
+        if (!check_every_id(dict)) return 1;
+        if (!check_negative(dict)) return 1;
+        /* error channel: exceptions with the reference's wording */
+        try {
+            dictionary other;
+            other.load("/nonexistent/index.sshash");
+            std::cout << "ERROR: loading a missing file did not throw" << std::endl;
+            return 1;
+        } catch (std::runtime_error const& e) {
+            if (std::string(e.what()).find("error in opening the file") == std::string::npos) return 1;
+        }
+        std::cout << "EVERYTHING OK!" << std::endl;
+    } catch (std::exception const& e) {
+        std::cout << "EXCEPTION: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

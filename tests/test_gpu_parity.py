@@ -171,3 +171,23 @@ def test_index_file_roundtrip_on_gpu(case_skew_canonical, tmp_path):
     q = case.queries(2000, 2000, seed=9)
     assert (d2.lookup(q).kmer_id == case.oracle.lookup_ids(q)).all()
     assert (d2.k(), d2.m(), d2.canonical(), d2.num_kmers()) == (case.k, case.m, True, case.gt.num_kmers)
+
+
+def test_access_on_device(case_se_regular, case_k63_canonical):
+    """access(kmer_id) as a device kernel equals the host access / the ground truth."""
+    import torch
+
+    for case in (case_se_regular, case_k63_canonical):
+        d = case.dict.to_device(0)
+        rng = np.random.default_rng(3)
+        ids = rng.integers(0, case.gt.num_kmers, 50000, dtype=np.uint64)
+        ids[:3] = [0, case.gt.num_kmers - 1, case.gt.num_kmers]  # last entry is out of range
+        d_ids = torch.from_numpy(ids.view(np.int64)).cuda()
+        out = torch.empty(ids.size * case.W, dtype=torch.int64, device="cuda")
+        d.access_packed_device(0, d_ids.data_ptr(), ids.size, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint64).reshape(-1, case.W)
+        assert (got[2] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+        ok = np.ones(ids.size, dtype=bool)
+        ok[2] = False
+        assert (got[ok].reshape(-1) == case.gt.kmers(ids[ok])).all()
