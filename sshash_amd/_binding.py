@@ -132,6 +132,7 @@ def _load() -> C.CDLL:
         "sshash_device_count": (C.c_int, []),
         "sshash_to_device": (C.c_int, [P, C.c_int]),
         "sshash_device_bytes": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64)]),
+        "sshash_device_stats": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64 * 4)]),
         "sshash_lookup_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
         "sshash_lookup_ascii_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
         "sshash_lookup_packed": (C.c_int, [P, P, C.c_uint64, C.c_int, C.POINTER(_Results)]),
@@ -157,7 +158,7 @@ def _load() -> C.CDLL:
 
 C_ABI_SYMBOLS = (
     "sshash_last_error sshash_build_config_default sshash_build_from_fasta sshash_build_from_packed sshash_save "
-    "sshash_load sshash_free sshash_get_info sshash_device_count sshash_to_device sshash_device_bytes "
+    "sshash_load sshash_free sshash_get_info sshash_device_count sshash_to_device sshash_device_bytes sshash_device_stats "
     "sshash_lookup_packed_device sshash_lookup_ascii_device sshash_lookup_packed sshash_lookup_ascii "
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
     "sshash_access_packed_device "
@@ -300,6 +301,12 @@ class Dictionary:
         out = C.c_uint64()
         _check(_load().sshash_device_bytes(self._h, int(device), C.byref(out)))
         return int(out.value)
+
+    def device_stats(self, device: int = 0) -> dict:
+        out = (C.c_uint64 * 4)()
+        _check(_load().sshash_device_stats(self._h, int(device), C.byref(out)))
+        return {"bytes": int(out[0]), "directory_sectors": int(out[1]), "directory_overflow_sectors": int(out[2]),
+                "directory_keys": int(out[3])}
 
     def set_max_blocks(self, n: int) -> None:
         _check(_load().sshash_set_max_blocks(self._h, int(n)))

@@ -180,6 +180,11 @@ sshash_status sshash_device_bytes(const sshash_dict* d, int device, uint64_t* by
     return guarded([&] { *bytes = d->eng->device_bytes(device); });
 }
 
+sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out[4]) {
+    if (!d || !out) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->device_stats(device, out); });
+}
+
 sshash_status sshash_lookup_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
                                           int check_rc, const sshash_results* out, void* hip_stream) {
     if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");

@@ -4,16 +4,23 @@
 // for what bounds this workload on the GPU: the number of *dependent random 64-byte sector
 // fetches* per query, not bytes. Two things differ from the host layout:
 //
-//  (1) `strings` and the string endpoints are fused into 16-byte granules
-//          { u32 rank, u32 marks, u64 bases }      one granule = 32 consecutive bases
-//      bases : the same 2-bit codes, base 32g+i in bits [2i,2i+1]
-//      marks : bit i set iff a string begins at base 32g+i (the final end offset is marked too)
-//      rank  : number of marks at bases < 32g
-//      so that ONE 32-byte read (two granules; three for k > 31) yields the k-mer to compare,
-//      the id of the string it lies in (rank + popcount) and whether it runs across a string
-//      boundary -- the information the reference obtains from `read_kmer_at` plus an Elias-Fano
-//      `locate` (include/util.hpp:248-257, include/offsets.hpp:138-154: 1 + ~3 dependent misses).
-//      Costs 4 bits/base instead of ~2.1; HBM capacity (288 GB) is not the constraint here.
+//  (1) `strings` and the string endpoints are fused so that ONE aligned read yields the k-mer to
+//      compare, the id of the string it lies in (rank + popcount) and whether it runs across a
+//      string boundary -- the information the reference obtains from `read_kmer_at` plus an
+//      Elias-Fano `locate` (include/util.hpp:248-257, include/offsets.hpp:138-154: 1 + ~3
+//      dependent misses):
+//        k <= 31: 32-byte, 32-byte-aligned *atoms*, one per 32 bases, each holding 64 bases
+//                 (its own 32 and a copy of the next 32):
+//                     { u64 bases[2], u64 marks, u32 rank, u32 spare }
+//                 so a k-mer starting at base o lies wholly inside atom o/32: exactly one DRAM
+//                 atom per window (a 32-byte window over 16-byte granules straddles two atoms
+//                 half of the time);
+//        k <= 63: 16-byte granules { u32 rank, u32 marks, u64 bases } per 32 bases; a window reads
+//                 three consecutive granules.
+//      bases : the same 2-bit codes, base i of the block in bits [2i,2i+1]
+//      marks : bit i set iff a string begins at that base (the final end offset is marked too)
+//      rank  : number of marks at bases before the block
+//      Costs 8 (resp. 4) bits/base instead of ~2.1; HBM capacity (288 GB) is not the constraint.
 //  (2) the endpoints themselves are kept as a plain u64 array, touched only when the caller
 //      asks for the full lookup_result (string_begin/string_end).
 //
@@ -27,6 +34,22 @@
 //      answered from the codeword's sector. Equal fingerprints still go through the exact check, so
 //      results are unchanged; only the number of sector fetches per miss drops (3.3 -> 2.1).
 //      The fingerprints are derived on the GPU at upload time from the strings themselves.
+//
+//  (4) a *minimizer directory*: the minimizer -> codeword map once more, as a fingerprinted bucket
+//      table whose buckets are exactly one 32-byte DRAM atom: 4 x u64 entries,
+//          entry = codeword (40 bits) | fingerprint (16 bits) << 40 | meta << 56
+//          meta: bit 0 = slot valid; bit 7 of entry 0 = bucket overflowed
+//      bucket = hash(minimizer) range-reduced, average load 1.5 keys. What bounds this workload is
+//      the number of 32-byte atoms fetched from HBM per lookup (~50 G random atoms/s):
+//      MPHF + codeword array cost two dependent atoms per probe (pilot, then codeword); the
+//      directory answers the same question with ONE. It is an accelerator over the MPHF, not a
+//      replacement: every key stays reachable through the MPHF; a bucket whose keys did not all fit
+//      (Poisson tail, ~1.9 % of buckets) or that held two keys with equal fingerprints carries the
+//      overflow flag, and probes that are not settled there fall back to the MPHF path. A key absent
+//      from a non-overflowed bucket is absent from the dictionary. Used by the ids-only / is_member
+//      / streaming kernels; the full-result kernel keeps the MPHF path because for an absent
+//      minimizer the reference's `minimizer_found` flag depends on which (arbitrary) bucket the
+//      MPHF lands on. Built on the GPU at upload; SSHASH_AMD_DIRECTORY=0 disables it.
 //
 // The remaining packed vectors (bucket offset lists, pilots, skew positions) keep their bit-packed
 // form: one 8-byte read, sometimes two adjacent ones.
@@ -43,6 +66,14 @@ struct alignas(16) granule {
 };
 static_assert(sizeof(granule) == 16, "granule layout");
 
+struct alignas(32) atom32 {  // k <= 31
+    uint64_t bases[2];
+    uint64_t marks;
+    uint32_t rank;
+    uint32_t spare;
+};
+static_assert(sizeof(atom32) == 32, "atom layout");
+
 constexpr uint32_t GRANULE_BASES = 32;
 constexpr uint32_t GRANULE_PAD = 4;  // zero granules after the last real one
 
@@ -58,6 +89,28 @@ SSH_HD uint64_t minimizer_fingerprint(uint64_t minimizer, uint32_t m, bool canon
     return cw_width >= 64 ? 0 : (key * FINGERPRINT_MUL) >> cw_width;
 }
 
+constexpr uint32_t DIR_SLOTS = 4;         // entries per 32-byte bucket
+constexpr uint32_t DIR_CODE_BITS = 40;    // widest control codeword the directory can hold
+constexpr double DIR_LOAD = 1.5;          // average keys per bucket
+
+struct directory_view {
+    uint64_t const* buckets;  // 4 words per bucket
+    uint32_t num_buckets;
+    uint32_t enabled;
+};
+
+/* hash of a minimizer for the directory: high half picks the bucket, low 16 bits are the fingerprint */
+SSH_HD uint64_t directory_hash(uint64_t minimizer) {
+    uint64_t x = minimizer * 0xFF51AFD7ED558CCDULL;
+    x ^= x >> 32;
+    x *= 0xC4CEB9FE1A85EC53ULL;
+    x ^= x >> 29;
+    return x;
+}
+SSH_HD uint32_t directory_bucket(uint64_t h, uint32_t num_buckets) { return mulhi32(uint32_t(h >> 32), num_buckets); }
+SSH_HD uint32_t directory_fingerprint(uint64_t h) { return uint32_t(h) & 0xFFFFu; }
+SSH_HD uint64_t directory_entry(uint64_t code, uint32_t fp) { return code | (uint64_t(fp) << 40) | (uint64_t(1) << 56); }
+
 struct dict_view {
     uint32_t k, m;
     uint32_t canonical;
@@ -65,7 +118,7 @@ struct dict_view {
     uint64_t hash_magic;
     uint64_t num_kmers, num_strings, num_bases;
 
-    granule const* granules;
+    void const* granules;  // atom32[] when k <= 31, granule[] otherwise
     uint64_t const* endpoints;  // num_strings + 1
 
     mphf_view minimizers;
@@ -76,6 +129,7 @@ struct dict_view {
     uint64_t const* mid_load;
     uint64_t const* heavy_load;
     uint64_t heavy_size;
+    directory_view directory;
 
     mphf_view skew_f[8];
     uint64_t const* skew_pos[8];

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -18,7 +19,7 @@ int visible_device_count() {
     return n;
 }
 
-/* strings + endpoints -> granules (device_layout.hpp) */
+/* strings + endpoints -> granules (k > 31) or atoms (k <= 31), device_layout.hpp (1) */
 static std::vector<granule> make_granules(host_index const& idx, uint32_t num_threads) {
     const uint64_t G = idx.num_bases / GRANULE_BASES + 1 + GRANULE_PAD;
     std::vector<granule> g(G);
@@ -39,6 +40,21 @@ static std::vector<granule> make_granules(host_index const& idx, uint32_t num_th
     return g;
 }
 
+static std::vector<atom32> make_atoms(std::vector<granule> const& g, uint32_t num_threads) {
+    const uint64_t A = g.size() - 1;  // every atom also carries the next block
+    std::vector<atom32> a(A);
+    detail::parallel_ranges(A, num_threads, [&](uint64_t b, uint64_t e, uint32_t) {
+        for (uint64_t i = b; i < e; ++i) {
+            a[i].bases[0] = g[i].bases;
+            a[i].bases[1] = g[i + 1].bases;
+            a[i].marks = uint64_t(g[i].marks) | (uint64_t(g[i + 1].marks) << 32);
+            a[i].rank = g[i].rank;
+            a[i].spare = 0;
+        }
+    });
+    return a;
+}
+
 /* Widen the packed control codewords to u64 entries carrying the bucket minimizer's fingerprint
    (device_layout.hpp (3)). One lane per minimizer id; runs once per upload. */
 __global__ void __launch_bounds__(256)
@@ -54,8 +70,77 @@ widen_codewords_kernel(const dict_view d, const uint64_t* __restrict__ packed, c
     } else {
         first = packed_get(d.heavy_load, code >> 5, d.off_width);
     }
-    const uint64_t mmer = read_window<1>(d.granules, first, d.m).kmer.w[0];
+    const uint64_t mmer = read_mmer(d, first);
     out[i] = code | (minimizer_fingerprint(mmer, d.m, d.canonical != 0, d.cw_width) << d.cw_width);
+}
+
+/* ---- minimizer directory construction (device_layout.hpp (4)) --------------------------------- */
+
+/* One lane per minimizer id: recover the key (the m-mer at the bucket's first offset; for canonical
+   indexes whichever of {m-mer, its reverse complement} the MPHF maps back to this id) and claim a
+   slot in its directory bucket. Keys beyond 4 per bucket are dropped: the finalize pass flags the bucket. */
+__global__ void __launch_bounds__(256)
+directory_insert_kernel(const dict_view d, const uint64_t n, uint64_t* __restrict__ buckets, uint32_t* __restrict__ claimed,
+                        const uint32_t num_buckets) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t code = d.codewords[i] & low_mask(d.cw_width);
+    uint64_t first;
+    if ((code & 1) == 0) first = code >> 1;
+    else if ((code & 3) == 1) {
+        const uint32_t size = uint32_t((code >> 2) & (MAX_BUCKET_SMALL - 1)) + 2;
+        first = packed_get(d.mid_load, uint64_t(d.begin_buckets_of_size[size]) + (code >> (2 + MIN_L)) * size, d.off_width);
+    } else {
+        first = packed_get(d.heavy_load, code >> 5, d.off_width);
+    }
+    const uint64_t mmer = read_mmer(d, first);
+    uint64_t keys[2] = {mmer, mmer};
+    int num = 1;
+    if (d.canonical) {
+        const uint64_t rc = mmer_revcomp(mmer, d.m);
+        const bool a = mphf_eval(d.minimizers, city128_u64(mmer, d.minimizers.seed)) == i;
+        const bool b = rc != mmer && mphf_eval(d.minimizers, city128_u64(rc, d.minimizers.seed)) == i;
+        num = 0;
+        if (a) keys[num++] = mmer;
+        if (b) keys[num++] = rc;  // both only when a non-key collides with this id: the MPHF path would behave the same
+    }
+    for (int j = 0; j < num; ++j) {
+        const uint64_t h = directory_hash(keys[j]);
+        const uint32_t b = directory_bucket(h, num_buckets);
+        const uint32_t slot = atomicAdd(claimed + b, 1u);
+        if (slot < DIR_SLOTS) buckets[4 * uint64_t(b) + slot] = directory_entry(code, directory_fingerprint(h));
+    }
+}
+
+/* One lane per bucket: drop entries whose fingerprint repeats inside the bucket (the dropped key stays
+   reachable through the MPHF) and set the overflow flag where anything was lost. */
+__global__ void __launch_bounds__(256)
+directory_finalize_kernel(uint64_t* __restrict__ buckets, const uint32_t* __restrict__ claimed, const uint32_t num_buckets,
+                          unsigned long long* __restrict__ stats) {
+    const uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (s >= num_buckets) return;
+    uint64_t* B = buckets + 4 * s;
+    const uint32_t c = claimed[s];
+    bool overflow = c > DIR_SLOTS;
+    uint32_t count = c > DIR_SLOTS ? DIR_SLOTS : c;
+    uint64_t e[DIR_SLOTS];
+    for (uint32_t j = 0; j < DIR_SLOTS; ++j) e[j] = j < count ? B[j] : 0;
+    for (uint32_t a = 0; a < count; ++a) {
+        for (uint32_t b = a + 1; b < count;) {
+            if (((e[a] >> 40) & 0xFFFF) == ((e[b] >> 40) & 0xFFFF)) {
+                e[b] = e[count - 1];
+                e[count - 1] = 0;
+                --count;
+                overflow = true;
+            } else {
+                ++b;
+            }
+        }
+    }
+    if (overflow) e[0] |= uint64_t(1) << 63;
+    for (uint32_t j = 0; j < DIR_SLOTS; ++j) B[j] = e[j];
+    if (overflow) atomicAdd(stats, 1ull);
+    atomicAdd(stats + 1, (unsigned long long)count);
 }
 
 engine::engine(std::shared_ptr<host_index> idx) : m_idx(std::move(idx)) {}
@@ -74,6 +159,14 @@ std::vector<int> engine::devices() const {
 }
 
 uint64_t engine::device_bytes(int device) const { return replica(device)->bytes; }
+
+void engine::device_stats(int device, uint64_t out[4]) const {
+    device_replica const* r = replica(device);
+    out[0] = r->bytes;
+    out[1] = r->view.directory.enabled ? r->view.directory.num_buckets : 0;
+    out[2] = r->directory_overflowed;
+    out[3] = r->directory_entries;
+}
 
 device_replica const* engine::replica(int device) const {
     for (auto const& r : m_replicas)
@@ -103,7 +196,13 @@ void engine::to_device(int device) {
     {
         const uint32_t nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         std::vector<granule> g = make_granules(idx, nt);
-        v.granules = rep->put(g);
+        if (idx.k <= 31) {
+            std::vector<atom32> a = make_atoms(g, nt);
+            std::vector<granule>().swap(g);
+            v.granules = rep->put(a);
+        } else {
+            v.granules = rep->put(g);
+        }
     }
     v.endpoints = rep->put(idx.endpoints);
     v.minimizers = rep->put_mphf(idx.minimizers_mphf);
@@ -130,6 +229,41 @@ void engine::to_device(int device) {
         }
         HIP_CHECK(hipFree(packed));
         v.codewords = wide;
+    }
+    /* minimizer directory (device_layout.hpp (4)) */
+    v.directory.buckets = nullptr;
+    v.directory.num_buckets = 0;
+    v.directory.enabled = 0;
+    {
+        const char* env = std::getenv("SSHASH_AMD_DIRECTORY");
+        const bool want = !(env && env[0] == '0');
+        const uint64_t n = idx.control_codewords.size;
+        const uint64_t nb = uint64_t(double(n) / DIR_LOAD) + 1;
+        if (want && n && nb < (uint64_t(1) << 32) && v.cw_width <= DIR_CODE_BITS) {
+            uint64_t* buckets = nullptr;
+            uint32_t* claimed = nullptr;
+            unsigned long long* stats = nullptr;
+            HIP_CHECK(hipMalloc(&buckets, nb * 32));
+            HIP_CHECK(hipMalloc(&claimed, nb * 4));
+            HIP_CHECK(hipMalloc(&stats, 16));
+            HIP_CHECK(hipMemset(buckets, 0, nb * 32));
+            HIP_CHECK(hipMemset(claimed, 0, nb * 4));
+            HIP_CHECK(hipMemset(stats, 0, 16));
+            rep->allocations.push_back(buckets);
+            rep->bytes += nb * 32;
+            hipLaunchKernelGGL(directory_insert_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, 0, v, n, buckets, claimed, uint32_t(nb));
+            hipLaunchKernelGGL(directory_finalize_kernel, dim3(uint32_t((nb + 255) / 256)), dim3(256), 0, 0, buckets, claimed, uint32_t(nb), stats);
+            HIP_CHECK(hipGetLastError());
+            unsigned long long h_stats[2];
+            HIP_CHECK(hipMemcpy(h_stats, stats, 16, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipFree(stats));
+            HIP_CHECK(hipFree(claimed));
+            rep->directory_overflowed = h_stats[0];
+            rep->directory_entries = h_stats[1];
+            v.directory.buckets = buckets;
+            v.directory.num_buckets = uint32_t(nb);
+            v.directory.enabled = 1;
+        }
     }
     std::vector<skew_part_dev> skew(8);
     for (uint32_t p = 0; p < 8; ++p) {
@@ -176,7 +310,8 @@ lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const v
             for (int j = 0; j < W; ++j) x.w[j] = q[j];
             x = kmer_take_chars<W>(x, d.k);
         }
-        const hit_t h = lookup_one<W, CANON>(d, skew, x, check_rc);
+        /* the full-result kernel keeps the MPHF path: exact `minimizer_found` (device_layout.hpp (4)) */
+        const hit_t h = lookup_one<W, CANON, MODE != int(out_mode::full)>(d, skew, x, check_rc);
         if constexpr (MODE == int(out_mode::member)) {
             member[i] = h.found ? 1 : 0;
         } else {
@@ -185,10 +320,98 @@ lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const v
     }
 }
 
+constexpr uint32_t DEFER_SHARDS = 2048;  // power of two
+
+template <int W, bool ASCII>
+__device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries, uint64_t i, uint32_t k) {
+    kmer_w<W> x;
+    if constexpr (ASCII) {
+        x = kmer_from_ascii<W>(static_cast<const char*>(queries) + i * k, k);
+    } else {
+        const uint64_t* q = static_cast<const uint64_t*>(queries) + i * W;
+        for (int j = 0; j < W; ++j) x.w[j] = q[j];
+        x = kmer_take_chars<W>(x, k);
+    }
+    return x;
+}
+
+/* Phase 1 of the two-phase lookup (lookup_device.hpp): one query per lane, common case only. Queries it
+   cannot settle are appended to `queue` (their index in the batch). MODE: ids or member. */
 template <int W, bool CANON, int MODE, bool ASCII>
-static void launch(dict_view const& d, skew_part_dev const* skew, void const* q, uint64_t n, bool check_rc,
+__global__ void __launch_bounds__(256)
+fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const uint64_t n, const bool check_rc,
+                   uint64_t* __restrict__ ids, uint8_t* __restrict__ member, uint32_t* __restrict__ queue,
+                   uint32_t* __restrict__ queue_counts, const uint32_t shard_capacity) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const kmer_w<W> x = load_query<W, ASCII>(queries, i, d.k);
+    const fast_t r = fast_lookup_one<W, CANON>(d, x, check_rc);
+    /* every lane stores first (a deferred lane's value is a placeholder that phase 2 overwrites), the
+       queue push comes last: no lane leaves the wave between the probe and its store */
+    if constexpr (MODE == int(out_mode::member)) {
+        member[i] = r.outcome == FAST_HIT ? 1 : 0;
+    } else {
+        ids[i] = r.outcome == FAST_HIT ? r.kmer_offset - uint64_t(r.string_id) * (d.k - 1) : INVALID_U64;
+    }
+    if (r.outcome == FAST_DEFER) {
+        /* the queue is sharded by workgroup: one hot counter would serialise at ~90 atomics/us */
+        const uint32_t shard = blockIdx.x & (DEFER_SHARDS - 1);
+        queue[uint64_t(shard) * shard_capacity + atomicAdd(queue_counts + shard, 1u)] = uint32_t(i);
+    }
+}
+
+/* Phase 2: the deferred queries, compacted, through the complete lookup. */
+template <int W, bool CANON, int MODE, bool ASCII>
+__global__ void __launch_bounds__(256)
+deferred_lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const void* __restrict__ queries,
+                       const bool check_rc, uint64_t* __restrict__ ids, uint8_t* __restrict__ member,
+                       const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queue_counts,
+                       const uint32_t shard_capacity) {
+    const uint32_t total = queue_counts[blockIdx.x];  // one workgroup per shard
+    const uint32_t* mine = queue + uint64_t(blockIdx.x) * shard_capacity;
+    for (uint32_t j = threadIdx.x; j < total; j += blockDim.x) {
+        const uint64_t i = mine[j];
+        const kmer_w<W> x = load_query<W, ASCII>(queries, i, d.k);
+        const hit_t h = lookup_one<W, CANON, true>(d, skew, x, check_rc);
+        if constexpr (MODE == int(out_mode::member)) {
+            member[i] = h.found ? 1 : 0;
+        } else {
+            ids[i] = h.found ? h.kmer_offset - uint64_t(h.string_id) * (d.k - 1) : INVALID_U64;
+        }
+    }
+}
+
+template <int W, bool CANON, int MODE, bool ASCII>
+static void launch(device_replica const* rep, void const* q, uint64_t n, bool check_rc,
                    result_view const& out, uint8_t* member, hipStream_t stream, uint32_t max_blocks) {
+    dict_view const& d = rep->view;
+    skew_part_dev const* skew = rep->d_skew;
     const uint32_t block = 256;
+    if constexpr (MODE != int(out_mode::full)) {
+        if (d.directory.enabled && !max_blocks) {
+            /* two-phase: at most 2^31 queries per launch pair so that queue indices fit 32 bits */
+            const uint64_t piece = uint64_t(1) << 31;
+            const size_t qbytes = size_t(W) * 8, kbytes = d.k;
+            for (uint64_t at = 0; at < n; at += piece) {
+                const uint64_t m = std::min(piece, n - at);
+                const uint32_t nblocks = uint32_t((m + block - 1) / block);
+                const uint32_t shard_capacity = ((nblocks + DEFER_SHARDS - 1) / DEFER_SHARDS) * block;
+                uint32_t* scratch = static_cast<uint32_t*>(
+                    rep->scratch_for(stream, (uint64_t(DEFER_SHARDS) * shard_capacity + DEFER_SHARDS) * sizeof(uint32_t)));
+                HIP_CHECK(hipMemsetAsync(scratch, 0, DEFER_SHARDS * sizeof(uint32_t), stream));
+                const void* qa = static_cast<const char*>(q) + at * (ASCII ? kbytes : qbytes);
+                uint64_t* ids = out.kmer_id ? out.kmer_id + at : nullptr;
+                uint8_t* mem = member ? member + at : nullptr;
+                static const uint32_t lds_pad = std::getenv("SSHASH_AMD_LDS_PAD") ? uint32_t(atoi(std::getenv("SSHASH_AMD_LDS_PAD"))) : 0;  // occupancy experiment knob
+                hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII>), dim3(nblocks), dim3(block), lds_pad, stream, d, qa, m,
+                                   check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
+                hipLaunchKernelGGL((deferred_lookup_kernel<W, CANON, MODE, ASCII>), dim3(DEFER_SHARDS), dim3(block), 0, stream, d,
+                                   skew, qa, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
+                HIP_CHECK(hipGetLastError());
+            }
+            return;
+        }
+    }
     uint64_t blocks = (n + block - 1) / block;
     const uint64_t cap = max_blocks ? max_blocks : (uint64_t(1) << 22);
     if (blocks > cap) blocks = cap;
@@ -198,23 +421,24 @@ static void launch(dict_view const& d, skew_part_dev const* skew, void const* q,
 }
 
 template <int W, bool CANON, bool ASCII>
-static void launch_mode(out_mode mode, dict_view const& d, skew_part_dev const* skew, void const* q, uint64_t n,
+static void launch_mode(out_mode mode, device_replica const* rep, void const* q, uint64_t n,
                         bool check_rc, result_view const& out, uint8_t* member, hipStream_t s, uint32_t mb) {
     switch (mode) {
-        case out_mode::ids: launch<W, CANON, 0, ASCII>(d, skew, q, n, check_rc, out, member, s, mb); break;
-        case out_mode::full: launch<W, CANON, 1, ASCII>(d, skew, q, n, check_rc, out, member, s, mb); break;
-        case out_mode::member: launch<W, CANON, 2, ASCII>(d, skew, q, n, check_rc, out, member, s, mb); break;
+        case out_mode::ids: launch<W, CANON, 0, ASCII>(rep, q, n, check_rc, out, member, s, mb); break;
+        case out_mode::full: launch<W, CANON, 1, ASCII>(rep, q, n, check_rc, out, member, s, mb); break;
+        case out_mode::member: launch<W, CANON, 2, ASCII>(rep, q, n, check_rc, out, member, s, mb); break;
     }
 }
 
 template <bool ASCII>
-static void launch_any(out_mode mode, dict_view const& d, skew_part_dev const* skew, void const* q, uint64_t n,
+static void launch_any(out_mode mode, device_replica const* rep, void const* q, uint64_t n,
                        bool check_rc, result_view const& out, uint8_t* member, hipStream_t s, uint32_t mb) {
+    dict_view const& d = rep->view;
     const bool wide = d.k > 31;
-    if (!wide && !d.canonical) launch_mode<1, false, ASCII>(mode, d, skew, q, n, check_rc, out, member, s, mb);
-    else if (!wide && d.canonical) launch_mode<1, true, ASCII>(mode, d, skew, q, n, check_rc, out, member, s, mb);
-    else if (wide && !d.canonical) launch_mode<2, false, ASCII>(mode, d, skew, q, n, check_rc, out, member, s, mb);
-    else launch_mode<2, true, ASCII>(mode, d, skew, q, n, check_rc, out, member, s, mb);
+    if (!wide && !d.canonical) launch_mode<1, false, ASCII>(mode, rep, q, n, check_rc, out, member, s, mb);
+    else if (!wide && d.canonical) launch_mode<1, true, ASCII>(mode, rep, q, n, check_rc, out, member, s, mb);
+    else if (wide && !d.canonical) launch_mode<2, false, ASCII>(mode, rep, q, n, check_rc, out, member, s, mb);
+    else launch_mode<2, true, ASCII>(mode, rep, q, n, check_rc, out, member, s, mb);
 }
 
 static void check_outputs(out_mode mode, result_view const& out, uint8_t* member) {
@@ -231,7 +455,7 @@ void engine::lookup_packed_device(int device, uint64_t const* d_kmers, uint64_t 
     check_outputs(mode, d_out, d_member);
     if (n == 0) return;
     device_guard guard(device);
-    launch_any<false>(mode, rep->view, rep->d_skew, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream), m_max_blocks);
+    launch_any<false>(mode, rep, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream), m_max_blocks);
 }
 
 void engine::lookup_ascii_device(int device, char const* d_kmers, uint64_t n, bool check_rc, out_mode mode,
@@ -240,7 +464,7 @@ void engine::lookup_ascii_device(int device, char const* d_kmers, uint64_t n, bo
     check_outputs(mode, d_out, d_member);
     if (n == 0) return;
     device_guard guard(device);
-    launch_any<true>(mode, rep->view, rep->d_skew, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream), m_max_blocks);
+    launch_any<true>(mode, rep, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream), m_max_blocks);
 }
 
 /* ---- access(kmer_id) on the device: include/spectrum_preserving_string_set.hpp:114-118 with

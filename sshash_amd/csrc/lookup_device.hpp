@@ -40,34 +40,53 @@ __device__ __forceinline__ uint64_t funnel_shr(uint64_t lo, uint64_t hi, uint32_
     return (lo >> s) | ((hi << 1) << (63 - s));
 }
 
+/* k <= 31: one aligned 32-byte atom holds the whole window (device_layout.hpp (1)) */
 template <int W>
-__device__ __forceinline__ window_t<W> read_window(granule const* __restrict__ granules, uint64_t off, uint32_t k) {
-    const uint4* G = reinterpret_cast<const uint4*>(granules) + (off >> 5);
+__device__ __forceinline__ window_t<W> read_window(void const* __restrict__ blocks, uint64_t off, uint32_t k);
+
+template <>
+__device__ __forceinline__ window_t<1> read_window<1>(void const* __restrict__ blocks, uint64_t off, uint32_t k) {
+    const uint4* A = reinterpret_cast<const uint4*>(blocks) + 2 * (off >> 5);
+    const uint32_t r = uint32_t(off) & 31u;
+    const uint4 q0 = A[0];  // bases[0], bases[1]
+    const uint4 q1 = A[1];  // marks, rank, spare
+    const uint64_t b0 = uint64_t(q0.x) | (uint64_t(q0.y) << 32);
+    const uint64_t b1 = uint64_t(q0.z) | (uint64_t(q0.w) << 32);
+    window_t<1> w;
+    w.kmer.w[0] = funnel_shr(b0, b1, 2 * r) & low_mask(2 * k);
+    const uint64_t marks = uint64_t(q1.x) | (uint64_t(q1.y) << 32);
+    w.crosses = ((marks >> (r + 1)) & low_mask(k - 1)) != 0;
+    w.string_id = q1.z + __popc(q1.x & uint32_t((uint64_t(2) << r) - 1)) - 1;
+    return w;
+}
+
+/* k <= 63: three consecutive 16-byte granules */
+template <>
+__device__ __forceinline__ window_t<2> read_window<2>(void const* __restrict__ blocks, uint64_t off, uint32_t k) {
+    const uint4* G = reinterpret_cast<const uint4*>(blocks) + (off >> 5);
     const uint32_t r = uint32_t(off) & 31u;
     const uint32_t s = 2 * r;
     const uint4 g0 = G[0];
     const uint4 g1 = G[1];
+    const uint4 g2 = G[2];
     const uint64_t b0 = uint64_t(g0.z) | (uint64_t(g0.w) << 32);
     const uint64_t b1 = uint64_t(g1.z) | (uint64_t(g1.w) << 32);
-    window_t<W> w;
-    uint64_t following;  // mark bits of the positions off+1, off+2, ...
-    if constexpr (W == 1) {
-        w.kmer.w[0] = funnel_shr(b0, b1, s) & low_mask(2 * k);
-        const uint64_t marks = uint64_t(g0.y) | (uint64_t(g1.y) << 32);
-        following = marks >> (r + 1);
-    } else {
-        const uint4 g2 = G[2];
-        const uint64_t b2 = uint64_t(g2.z) | (uint64_t(g2.w) << 32);
-        w.kmer.w[0] = funnel_shr(b0, b1, s);
-        w.kmer.w[1] = funnel_shr(b1, b2, s);
-        w.kmer = kmer_take_chars<2>(w.kmer, k);
-        const uint64_t m_lo = uint64_t(g0.y) | (uint64_t(g1.y) << 32);
-        const uint64_t m_hi = uint64_t(g2.y);
-        following = (m_lo >> (r + 1)) | (m_hi << (63 - r));
-    }
+    const uint64_t b2 = uint64_t(g2.z) | (uint64_t(g2.w) << 32);
+    window_t<2> w;
+    w.kmer.w[0] = funnel_shr(b0, b1, s);
+    w.kmer.w[1] = funnel_shr(b1, b2, s);
+    w.kmer = kmer_take_chars<2>(w.kmer, k);
+    const uint64_t m_lo = uint64_t(g0.y) | (uint64_t(g1.y) << 32);
+    const uint64_t m_hi = uint64_t(g2.y);
+    const uint64_t following = (m_lo >> (r + 1)) | (m_hi << (63 - r));  // mark bits of off+1, off+2, ...
     w.crosses = (following & low_mask(k - 1)) != 0;
     w.string_id = g0.x + __popc(g0.y & uint32_t((uint64_t(2) << r) - 1)) - 1;
     return w;
+}
+
+/* the m-mer (m <= 31) starting at base `off`, whatever the block layout */
+__device__ __forceinline__ uint64_t read_mmer(dict_view const& d, uint64_t off) {
+    return d.k <= 31 ? read_window<1>(d.granules, off, d.m).kmer.w[0] : read_window<2>(d.granules, off, d.m).kmer.w[0];
 }
 
 template <int W>
@@ -81,20 +100,50 @@ struct bucket_t {
     uint32_t size;
     bool heavy;
     bool valid;      // false: skew index pointed outside heavy_load (absent k-mer)
-    bool other_key;  // the codeword's fingerprint proves the bucket belongs to another minimizer
+    bool other_key;  // the map proves that this minimizer has no bucket here
+    bool retry;      // directory sector overflowed: the MPHF path must have the last word
 };
 
-/* minimizer -> MPHF -> control codeword -> bucket (include/sparse_and_skew_index.hpp:112-137) */
+/* control codeword -> bucket (include/sparse_and_skew_index.hpp:112-137, skew :34-44) */
 template <int W>
-__device__ __forceinline__ bucket_t resolve_bucket(dict_view const& d, skew_part_dev const* __restrict__ skew,
-                                                   uint64_t minimizer, kmer_w<W> const& skew_key) {
+__device__ __forceinline__ void decode_codeword(dict_view const& d, skew_part_dev const* __restrict__ skew, uint64_t code,
+                                                kmer_w<W> const& skew_key, bucket_t& b) {
+    if ((code & 1) == 0) {  // SINGLETON
+        b.first_offset = code >> 1;
+    } else if ((code & 3) == 1) {  // MIDLOAD
+        b.size = uint32_t((code >> 2) & (MAX_BUCKET_SMALL - 1)) + 2;
+        b.begin = uint64_t(d.begin_buckets_of_size[b.size]) + (code >> (2 + MIN_L)) * b.size;
+        b.first_offset = packed_get(d.mid_load, b.begin, d.off_width);
+    } else {  // HEAVYLOAD: second MPHF keyed by the k-mer
+        b.heavy = true;
+        const skew_part_dev sp = skew[(code >> 2) & 7];
+        const uint64_t kid = mphf_eval(sp.f, city128_kmer<W>(skew_key, sp.f.seed));
+        const uint64_t at = (code >> 5) + packed_get(sp.positions, kid, sp.pos_width);
+        /* for a k-mer that is not a key the position is arbitrary and may fall outside the
+           array (spectrum_preserving_string_set.hpp:51-64): treat as a miss */
+        b.valid = at < d.heavy_size;
+        b.first_offset = b.valid ? packed_get(d.heavy_load, at, d.off_width) : 0;
+    }
+}
+
+__device__ __forceinline__ bucket_t empty_bucket() {
     bucket_t b;
+    b.first_offset = 0;
     b.begin = 0;
     b.size = 1;
     b.heavy = false;
     b.valid = true;
     b.other_key = false;
-    b.first_offset = 0;
+    b.retry = false;
+    return b;
+}
+
+/* minimizer -> MPHF -> control codeword (+ fingerprint) -> bucket:
+   minimizers_control_map::lookup, include/minimizers_control_map.hpp:36-39 */
+template <int W>
+__device__ __forceinline__ bucket_t resolve_bucket_mphf(dict_view const& d, skew_part_dev const* __restrict__ skew,
+                                                        uint64_t minimizer, kmer_w<W> const& skew_key) {
+    bucket_t b = empty_bucket();
     const uint64_t id = mphf_eval(d.minimizers, city128_u64(minimizer, d.minimizers.seed));
     const uint64_t entry = d.codewords[id];
     const uint64_t code = entry & low_mask(d.cw_width);
@@ -106,22 +155,50 @@ __device__ __forceinline__ bucket_t resolve_bucket(dict_view const& d, skew_part
         b.heavy = (code & 3) == 3;
         return b;
     }
-    if ((code & 1) == 0) {  // SINGLETON
-        b.first_offset = code >> 1;
-    } else if ((code & 3) == 1) {  // MIDLOAD
-        b.size = uint32_t((code >> 2) & (MAX_BUCKET_SMALL - 1)) + 2;
-        b.begin = uint64_t(d.begin_buckets_of_size[b.size]) + (code >> (2 + MIN_L)) * b.size;
-        b.first_offset = packed_get(d.mid_load, b.begin, d.off_width);
-    } else {  // HEAVYLOAD: second MPHF keyed by the k-mer (:34-44)
-        b.heavy = true;
-        const skew_part_dev sp = skew[(code >> 2) & 7];
-        const uint64_t kid = mphf_eval(sp.f, city128_kmer<W>(skew_key, sp.f.seed));
-        const uint64_t at = (code >> 5) + packed_get(sp.positions, kid, sp.pos_width);
-        /* for a k-mer that is not a key the position is arbitrary and may fall outside the
-           array (spectrum_preserving_string_set.hpp:51-64): treat as a miss */
-        b.valid = at < d.heavy_size;
-        b.first_offset = b.valid ? packed_get(d.heavy_load, at, d.off_width) : 0;
+    decode_codeword<W>(d, skew, code, skew_key, b);
+    return b;
+}
+
+struct dir_answer {
+    uint64_t code;   // control codeword of the matching entry
+    bool present;    // a fingerprint matched
+    bool overflow;   // bucket flagged: a negative answer is not final
+};
+
+/* one 32-byte atom: four entries, fingerprints compared in 32-bit arithmetic */
+__device__ __forceinline__ dir_answer directory_probe(dict_view const& d, uint64_t minimizer) {
+    const uint64_t h = directory_hash(minimizer);
+    const uint4* B = reinterpret_cast<const uint4*>(d.directory.buckets + 4 * uint64_t(directory_bucket(h, d.directory.num_buckets)));
+    const uint4 q0 = B[0], q1 = B[1];
+    const uint32_t want = (directory_fingerprint(h) << 8) | (1u << 24);  // fingerprint + valid bit, as laid out in the high dword
+    const uint32_t mask = 0x01FFFF00u;
+    const bool m0 = (q0.y & mask) == want, m1 = (q0.w & mask) == want, m2 = (q1.y & mask) == want, m3 = (q1.w & mask) == want;
+    uint32_t lo = 0, hi = 0;  // fingerprints are unique inside a bucket: at most one match
+    lo = m0 ? q0.x : lo;  hi = m0 ? q0.y : hi;
+    lo = m1 ? q0.z : lo;  hi = m1 ? q0.w : hi;
+    lo = m2 ? q1.x : lo;  hi = m2 ? q1.y : hi;
+    lo = m3 ? q1.z : lo;  hi = m3 ? q1.w : hi;
+    dir_answer a;
+    a.present = m0 || m1 || m2 || m3;
+    a.code = uint64_t(lo) | (uint64_t(hi & 0xFFu) << 32);
+    uint32_t flag = q0.y >> 31;
+    asm volatile("" : "+v"(flag));  // materialise now: the probe's registers are recycled by the bucket scan
+    a.overflow = flag != 0;
+    return a;
+}
+
+/* minimizer -> directory bucket (one 32-byte fetch) -> control codeword -> bucket */
+template <int W>
+__device__ __forceinline__ bucket_t resolve_bucket_directory(dict_view const& d, skew_part_dev const* __restrict__ skew,
+                                                             uint64_t minimizer, kmer_w<W> const& skew_key) {
+    bucket_t b = empty_bucket();
+    const dir_answer a = directory_probe(d, minimizer);
+    b.retry = a.overflow;
+    if (!a.present) {
+        b.other_key = true;  // (unless retry) the minimizer is not in the dictionary at all
+        return b;
     }
+    decode_codeword<W>(d, skew, a.code, skew_key, b);
     return b;
 }
 
@@ -137,9 +214,7 @@ __device__ __forceinline__ hit_t miss(bool minimizer_found) {
 
 /* spss::lookup_regular (include/spectrum_preserving_string_set.hpp:29-73,213-235) */
 template <int W>
-__device__ __forceinline__ hit_t probe_regular(dict_view const& d, skew_part_dev const* __restrict__ skew,
-                                               kmer_w<W> const& x, minimizer_t mini) {
-    const bucket_t b = resolve_bucket<W>(d, skew, mini.value, x);
+__device__ __forceinline__ hit_t scan_regular(dict_view const& d, bucket_t const& b, kmer_w<W> const& x, minimizer_t mini) {
     if (b.other_key) return miss(b.heavy);
     if (!b.valid) return miss(true);
     hit_t h = miss(true);
@@ -172,12 +247,26 @@ __device__ __forceinline__ hit_t probe_regular(dict_view const& d, skew_part_dev
     return h;
 }
 
+template <int W, bool DIRECTORY>
+__device__ __forceinline__ hit_t probe_regular(dict_view const& d, skew_part_dev const* __restrict__ skew,
+                                               kmer_w<W> const& x, minimizer_t mini) {
+    if constexpr (DIRECTORY) {
+        if (d.directory.enabled) {
+            const bucket_t b = resolve_bucket_directory<W>(d, skew, mini.value, x);
+            hit_t h = scan_regular<W>(d, b, x, mini);
+            if (h.found || !b.retry) {
+                if (!h.found && b.other_key) h.minimizer_found = false;
+                return h;
+            }
+        }
+    }
+    return scan_regular<W>(d, resolve_bucket_mphf<W>(d, skew, mini.value, x), x, mini);
+}
+
 /* spss::lookup_canonical (include/spectrum_preserving_string_set.hpp:75-112,237-275) */
 template <int W>
-__device__ __forceinline__ hit_t probe_canonical(dict_view const& d, skew_part_dev const* __restrict__ skew,
-                                                 kmer_w<W> const& x, kmer_w<W> const& x_rc, minimizer_t mini) {
-    const kmer_w<W> key = kmer_less<W>(x_rc, x) ? x_rc : x;  // src/dictionary.cpp:53
-    const bucket_t b = resolve_bucket<W>(d, skew, mini.value, key);
+__device__ __forceinline__ hit_t scan_canonical(dict_view const& d, bucket_t const& b, kmer_w<W> const& x,
+                                                kmer_w<W> const& x_rc, minimizer_t mini) {
     if (b.other_key) return miss(b.heavy);
     if (!b.valid) return miss(true);
     hit_t h = miss(true);
@@ -206,27 +295,134 @@ __device__ __forceinline__ hit_t probe_canonical(dict_view const& d, skew_part_d
     return h;
 }
 
-/* dictionary::lookup(Kmer, bool) -- src/dictionary.cpp:64-78 and :24-42 */
-template <int W, bool CANON>
+template <int W, bool DIRECTORY>
+__device__ __forceinline__ hit_t probe_canonical(dict_view const& d, skew_part_dev const* __restrict__ skew,
+                                                 kmer_w<W> const& x, kmer_w<W> const& x_rc, minimizer_t mini) {
+    const kmer_w<W> key = kmer_less<W>(x_rc, x) ? x_rc : x;  // src/dictionary.cpp:53
+    if constexpr (DIRECTORY) {
+        if (d.directory.enabled) {
+            const bucket_t b = resolve_bucket_directory<W>(d, skew, mini.value, key);
+            hit_t h = scan_canonical<W>(d, b, x, x_rc, mini);
+            if (h.found || !b.retry) {
+                if (!h.found && b.other_key) h.minimizer_found = false;
+                return h;
+            }
+        }
+    }
+    return scan_canonical<W>(d, resolve_bucket_mphf<W>(d, skew, mini.value, key), x, x_rc, mini);
+}
+
+/* dictionary::lookup(Kmer, bool) -- src/dictionary.cpp:64-78 and :24-42.
+   DIRECTORY: resolve minimizers through the one-sector directory (device_layout.hpp (4)). */
+template <int W, bool CANON, bool DIRECTORY>
 __device__ __forceinline__ hit_t lookup_one(dict_view const& d, skew_part_dev const* __restrict__ skew,
                                             kmer_w<W> const& x, bool check_rc) {
     if constexpr (CANON) {
         const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
         const minimizer_t mf = compute_minimizer<W>(x, d.k, d.m, d.hash_magic);
         const minimizer_t mr = compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic);
-        if (mf.value < mr.value) return probe_canonical<W>(d, skew, x, x_rc, mf);
-        if (mr.value < mf.value) return probe_canonical<W>(d, skew, x, x_rc, mr);
-        hit_t h = probe_canonical<W>(d, skew, x, x_rc, mf);
-        if (!h.found) h = probe_canonical<W>(d, skew, x, x_rc, mr);
+        if (mf.value < mr.value) return probe_canonical<W, DIRECTORY>(d, skew, x, x_rc, mf);
+        if (mr.value < mf.value) return probe_canonical<W, DIRECTORY>(d, skew, x, x_rc, mr);
+        hit_t h = probe_canonical<W, DIRECTORY>(d, skew, x, x_rc, mf);
+        if (!h.found) h = probe_canonical<W, DIRECTORY>(d, skew, x, x_rc, mr);
         return h;
     } else {
-        hit_t h = probe_regular<W>(d, skew, x, compute_minimizer<W>(x, d.k, d.m, d.hash_magic));
+        hit_t h = probe_regular<W, DIRECTORY>(d, skew, x, compute_minimizer<W>(x, d.k, d.m, d.hash_magic));
         if (!h.found && check_rc) {
             const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
-            h = probe_regular<W>(d, skew, x_rc, compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic));
+            h = probe_regular<W, DIRECTORY>(d, skew, x_rc, compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic));
             h.orientation = -1;
         }
         return h;
+    }
+}
+
+/* ---- two-phase lookup: the common case in a lean kernel, everything else deferred ------------
+   The generic `lookup_one` above carries the code of every rare case (MIDLOAD scans, the skew index,
+   the MPHF fallback of overflowed directory sectors); a wave executes all of it as soon as ONE of its
+   64 lanes needs it. `fast_probe_*` resolves: minimizer absent (the directory says so), SINGLETON and
+   MIDLOAD buckets -- ~98 % of the probes of a random batch -- and reports DEFER for the rest (HEAVYLOAD
+   buckets, probes left open by an overflowed directory bucket, canonical minimizer ties); deferred
+   queries are compacted into a queue and re-run through `lookup_one` by a second, small launch. */
+
+enum fast_outcome : int { FAST_MISS = 0, FAST_HIT = 1, FAST_DEFER = 2 };
+
+struct fast_t {
+    uint64_t kmer_offset;
+    uint32_t string_id;
+    int outcome;
+    int8_t orientation;
+};
+
+/* directory answer -> SINGLETON / MIDLOAD bucket; false when the probe has to be deferred (HEAVYLOAD) */
+__device__ __forceinline__ bool fast_bucket(dict_view const& d, uint64_t code, bucket_t& b) {
+    b = empty_bucket();
+    if ((code & 1) == 0) {
+        b.first_offset = code >> 1;
+        return true;
+    }
+    if ((code & 3) == 3) return false;
+    b.size = uint32_t((code >> 2) & (MAX_BUCKET_SMALL - 1)) + 2;
+    b.begin = uint64_t(d.begin_buckets_of_size[b.size]) + (code >> (2 + MIN_L)) * b.size;
+    b.first_offset = packed_get(d.mid_load, b.begin, d.off_width);
+    return true;
+}
+
+__device__ __forceinline__ fast_t fast_result(hit_t const& h, bool overflow) {
+    fast_t r;
+    r.kmer_offset = h.kmer_offset;
+    r.string_id = h.string_id;
+    r.orientation = h.orientation;
+    /* a miss whose minimizer check failed was a fingerprint false positive: final only if the
+       directory bucket never overflowed */
+    r.outcome = h.found ? FAST_HIT : ((!h.minimizer_found && overflow) ? FAST_DEFER : FAST_MISS);
+    return r;
+}
+
+__device__ __forceinline__ fast_t fast_unsettled(bool defer) {
+    fast_t r;
+    r.kmer_offset = 0;
+    r.string_id = 0;
+    r.orientation = 1;
+    r.outcome = defer ? FAST_DEFER : FAST_MISS;
+    return r;
+}
+
+template <int W>
+__device__ __forceinline__ fast_t fast_probe_regular(dict_view const& d, kmer_w<W> const& x, minimizer_t mini) {
+    const dir_answer a = directory_probe(d, mini.value);
+    if (!a.present) return fast_unsettled(a.overflow);
+    bucket_t b;
+    if (!fast_bucket(d, a.code, b)) return fast_unsettled(true);
+    return fast_result(scan_regular<W>(d, b, x, mini), a.overflow);
+}
+
+template <int W>
+__device__ __forceinline__ fast_t fast_probe_canonical(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc,
+                                                       minimizer_t mini) {
+    const dir_answer a = directory_probe(d, mini.value);
+    if (!a.present) return fast_unsettled(a.overflow);
+    bucket_t b;
+    if (!fast_bucket(d, a.code, b)) return fast_unsettled(true);
+    return fast_result(scan_canonical<W>(d, b, x, x_rc, mini), a.overflow);
+}
+
+template <int W, bool CANON>
+__device__ __forceinline__ fast_t fast_lookup_one(dict_view const& d, kmer_w<W> const& x, bool check_rc) {
+    if constexpr (CANON) {
+        const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
+        const minimizer_t mf = compute_minimizer<W>(x, d.k, d.m, d.hash_magic);
+        const minimizer_t mr = compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic);
+        if (mf.value == mr.value) return fast_unsettled(true);  // tie: both alignments (src/dictionary.cpp:35-40)
+        return fast_probe_canonical<W>(d, x, x_rc, mf.value < mr.value ? mf : mr);
+    } else {
+        fast_t r = fast_probe_regular<W>(d, x, compute_minimizer<W>(x, d.k, d.m, d.hash_magic));
+        if (r.outcome == FAST_MISS && check_rc) {
+            const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
+            r = fast_probe_regular<W>(d, x_rc, compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic));
+            r.orientation = -1;
+        }
+        return r;
     }
 }
 

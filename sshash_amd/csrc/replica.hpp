@@ -3,8 +3,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "lookup_device.hpp"
@@ -34,7 +36,28 @@ struct device_replica {
     uint64_t bytes = 0;
     dict_view view{};
     skew_part_dev* d_skew = nullptr;
+    uint64_t directory_overflowed = 0;  // sectors carrying the overflow flag
+    uint64_t directory_entries = 0;     // keys resident in the directory
     std::vector<void*> allocations;
+
+    /* Per-stream scratch for the deferred-query queue of the two-phase lookup. Work on one stream is
+       ordered, so a buffer keyed by the stream can be reused without synchronisation; it only grows
+       (hipFree of the old block synchronises implicitly). */
+    mutable std::mutex scratch_mutex;
+    mutable std::unordered_map<void*, std::pair<void*, size_t>> scratch;
+    void* scratch_for(void* stream, size_t bytes) const {
+        std::lock_guard<std::mutex> lock(scratch_mutex);
+        auto& slot = scratch[stream];
+        if (slot.second < bytes) {
+            if (slot.first) HIP_CHECK(hipFree(slot.first));
+            slot.first = nullptr;
+            slot.second = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            HIP_CHECK(hipMalloc(&slot.first, want));
+            slot.second = want;
+        }
+        return slot.first;
+    }
 
     template <typename T>
     T* put(std::vector<T> const& v) {
@@ -62,6 +85,8 @@ struct device_replica {
         if (hipGetDevice(&prev) != hipSuccess) return;
         (void)hipSetDevice(device);
         for (void* p : allocations) (void)hipFree(p);
+        for (auto& kv : scratch)
+            if (kv.second.first) (void)hipFree(kv.second.first);
         (void)hipSetDevice(prev);
     }
 };

@@ -28,16 +28,16 @@ template <int W, bool CANON>
 __device__ __forceinline__ hit_t seed_lookup(dict_view const& d, skew_part_dev const* __restrict__ skew,
                                              kmer_w<W> const& x, kmer_w<W> const& x_rc, minimizer_t mf, minimizer_t mr) {
     if constexpr (CANON) {  // include/streaming_query.hpp:159-169
-        if (mf.value < mr.value) return probe_canonical<W>(d, skew, x, x_rc, mf);
-        if (mr.value < mf.value) return probe_canonical<W>(d, skew, x, x_rc, mr);
-        hit_t h = probe_canonical<W>(d, skew, x, x_rc, mf);
-        if (!h.found) h = probe_canonical<W>(d, skew, x, x_rc, mr);
+        if (mf.value < mr.value) return probe_canonical<W, true>(d, skew, x, x_rc, mf);
+        if (mr.value < mf.value) return probe_canonical<W, true>(d, skew, x, x_rc, mr);
+        hit_t h = probe_canonical<W, true>(d, skew, x, x_rc, mf);
+        if (!h.found) h = probe_canonical<W, true>(d, skew, x, x_rc, mr);
         return h;
     } else {  // :170-180
-        hit_t h = probe_regular<W>(d, skew, x, mf);
+        hit_t h = probe_regular<W, true>(d, skew, x, mf);
         if (!h.found) {
             const bool mf_found = h.minimizer_found;
-            h = probe_regular<W>(d, skew, x_rc, mr);
+            h = probe_regular<W, true>(d, skew, x_rc, mr);
             h.orientation = -1;
             h.minimizer_found = h.minimizer_found || mf_found;
         }

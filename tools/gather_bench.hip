@@ -6,7 +6,7 @@
 // G reads/s and in GB/s of 64-byte sectors. Used by DESIGN.md to relate achieved Lookups/s to what the
 // memory system can deliver for this granularity.
 //
-//   gather_bench <array MiB> <lanes> <depth> <width bytes> [repeats]
+//   gather_bench <array MiB> <lanes> <depth> <width: 8|16|32|64, or 65 = 16 B + dependent 8 B in the same sector> [repeats]
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -42,10 +42,19 @@ __global__ void __launch_bounds__(256) chase(const uint64_t* __restrict__ a, uin
         } else if constexpr (WIDTH == 16) {
             const uint4 v = reinterpret_cast<const uint4*>(a)[unit];
             acc += v.x ^ v.w;
-        } else {
+        } else if constexpr (WIDTH == 32) {
             const uint4 v0 = reinterpret_cast<const uint4*>(a)[2 * unit];
             const uint4 v1 = reinterpret_cast<const uint4*>(a)[2 * unit + 1];
             acc += v0.x ^ v1.w;
+        } else if constexpr (WIDTH == 64) {  // a whole sector as four 16-byte loads
+            const uint4* p = reinterpret_cast<const uint4*>(a) + 4 * unit;
+            const uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+            acc += (v0.x ^ v1.w) + (v2.y ^ v3.z);
+        } else {  // 65: 16 bytes, then a DEPENDENT 8-byte read elsewhere in the same sector
+            const uint4* p = reinterpret_cast<const uint4*>(a) + 4 * unit;
+            const uint4 v0 = p[0];
+            const uint64_t* q = reinterpret_cast<const uint64_t*>(p) + 2 + (v0.x % 6);
+            acc += v0.w ^ q[0];
         }
         x = mix(x + acc + d);  // next address depends on the loaded value
     }
@@ -70,7 +79,7 @@ int main(int argc, char** argv) {
         for (uint64_t off = 0; off < bytes; off += h.size() * 8)
             CHECK(hipMemcpy(reinterpret_cast<char*>(a) + off, h.data(), std::min<uint64_t>(h.size() * 8, bytes - off), hipMemcpyHostToDevice));
     }
-    const uint64_t n_units = bytes / uint64_t(width);
+    const uint64_t n_units = bytes / uint64_t(width == 65 ? 64 : width);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -80,7 +89,9 @@ int main(int argc, char** argv) {
         CHECK(hipEventRecord(e0));
         if (width == 8) hipLaunchKernelGGL(chase<8>, grid, block, 0, 0, a, n_units, depth, out);
         else if (width == 16) hipLaunchKernelGGL(chase<16>, grid, block, 0, 0, a, n_units, depth, out);
-        else hipLaunchKernelGGL(chase<32>, grid, block, 0, 0, a, n_units, depth, out);
+        else if (width == 32) hipLaunchKernelGGL(chase<32>, grid, block, 0, 0, a, n_units, depth, out);
+        else if (width == 64) hipLaunchKernelGGL(chase<64>, grid, block, 0, 0, a, n_units, depth, out);
+        else hipLaunchKernelGGL(chase<65>, grid, block, 0, 0, a, n_units, depth, out);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
