@@ -111,12 +111,16 @@ def main():
         raise SystemExit("bench.py needs a GPU: the lookup path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL group is always created, also for one rank, so
+    # that the very same code path runs at N = 1, 2, 4, 8
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     from sshash_amd.synthetic import draw_queries
@@ -156,7 +160,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_begin
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -188,7 +192,8 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel": "lookup_kernel<W=%d,canonical=%d,ids>" % (W, int(d.canonical())),
+                    "kernel": "fast_lookup_kernel<W=%d,canonical=%d,ids> + deferred_lookup_kernel (one pair per step; "
+                              "avg_kernel_ms = HIP-event time around the pair)" % (W, int(d.canonical())),
                     "algorithmic_bytes_per_lookup": round(bytes_per_lookup, 2), "avg_kernel_ms": round(avg_kernel_ms, 3)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -235,7 +240,7 @@ def main():
             "cpu_baseline": cpu,
         }
     barrier()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -343,8 +343,44 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
                    uint64_t* __restrict__ ids, uint8_t* __restrict__ member, uint32_t* __restrict__ queue,
                    uint32_t* __restrict__ queue_counts, const uint32_t shard_capacity) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const kmer_w<W> x = load_query<W, ASCII>(queries, i, d.k);
+    kmer_w<W> x;
+    if constexpr (ASCII) {
+        /* util::string_to_uint_kmer (include/util.hpp:207-213) for a whole workgroup: the 256*k
+           characters of this workgroup's queries are one contiguous run of the input; it is staged in
+           LDS with 16-byte loads and every lane then packs its own k characters, four at a time */
+        __shared__ uint32_t tile[64 * (W == 1 ? 31 : 63) + 8];
+        const uint64_t first = uint64_t(blockIdx.x) * blockDim.x;
+        const uint32_t count = uint32_t(n - first < blockDim.x ? n - first : blockDim.x);
+        const uint32_t bytes = count * d.k;
+        const char* src = static_cast<const char*>(queries) + first * d.k;
+        if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            for (uint32_t c = threadIdx.x; c * 16 < bytes; c += blockDim.x) {
+                if (c * 16 + 16 <= bytes) {
+                    reinterpret_cast<uint4*>(tile)[c] = reinterpret_cast<const uint4*>(src)[c];
+                } else {
+                    for (uint32_t b = c * 16; b < bytes; ++b) reinterpret_cast<char*>(tile)[b] = src[b];
+                }
+            }
+        } else {
+            for (uint32_t b = threadIdx.x; b < bytes; b += blockDim.x) reinterpret_cast<char*>(tile)[b] = src[b];
+        }
+        __syncthreads();
+        if (i >= n) return;
+        x = kmer_zero<W>();
+        const uint32_t start = threadIdx.x * d.k, w0 = start >> 2, sh = start & 3;
+        for (uint32_t j = 0; 4 * j < d.k; ++j) {
+            const uint32_t four = __builtin_amdgcn_alignbyte(tile[w0 + j + 1], tile[w0 + j], sh);
+            uint32_t c = (four >> 1) & 0x03030303u;  // (c >> 1) & 3 for four characters at once
+            c = (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xFFu;
+            const uint32_t rem = d.k - 4 * j;
+            if (rem < 4) c &= (1u << (2 * rem)) - 1;
+            if (8 * j < 64) x.w[0] |= uint64_t(c) << (8 * j);
+            else if constexpr (W == 2) x.w[1] |= uint64_t(c) << (8 * j - 64);
+        }
+    } else {
+        if (i >= n) return;
+        x = load_query<W, false>(queries, i, d.k);
+    }
     const fast_t r = fast_lookup_one<W, CANON>(d, x, check_rc);
     /* every lane stores first (a deferred lane's value is a placeholder that phase 2 overwrites), the
        queue push comes last: no lane leaves the wave between the probe and its store */
