@@ -340,7 +340,7 @@ __device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries
 template <int W, bool CANON, int MODE, bool ASCII>
 __global__ void __launch_bounds__(256)
 fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const uint64_t n, const bool check_rc,
-                   uint64_t* __restrict__ ids, uint8_t* __restrict__ member, uint32_t* __restrict__ queue,
+                   const result_view out, uint8_t* __restrict__ member, uint32_t* __restrict__ queue,
                    uint32_t* __restrict__ queue_counts, const uint32_t shard_capacity) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     kmer_w<W> x;
@@ -387,7 +387,13 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
     if constexpr (MODE == int(out_mode::member)) {
         member[i] = r.outcome == FAST_HIT ? 1 : 0;
     } else {
-        ids[i] = r.outcome == FAST_HIT ? r.kmer_offset - uint64_t(r.string_id) * (d.k - 1) : INVALID_U64;
+        hit_t h;
+        h.kmer_offset = r.kmer_offset;
+        h.string_id = r.string_id;
+        h.orientation = r.orientation;
+        h.found = r.outcome == FAST_HIT;
+        h.minimizer_found = true;  // never stored on this path (see launch())
+        store_result<MODE == int(out_mode::full)>(d, out, i, h);
     }
     if (r.outcome == FAST_DEFER) {
         /* the queue is sharded by workgroup: one hot counter would serialise at ~90 atomics/us */
@@ -400,7 +406,7 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
 template <int W, bool CANON, int MODE, bool ASCII>
 __global__ void __launch_bounds__(256)
 deferred_lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const void* __restrict__ queries,
-                       const bool check_rc, uint64_t* __restrict__ ids, uint8_t* __restrict__ member,
+                       const bool check_rc, const result_view out, uint8_t* __restrict__ member,
                        const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queue_counts,
                        const uint32_t shard_capacity) {
     const uint32_t total = queue_counts[blockIdx.x];  // one workgroup per shard
@@ -412,9 +418,21 @@ deferred_lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew
         if constexpr (MODE == int(out_mode::member)) {
             member[i] = h.found ? 1 : 0;
         } else {
-            ids[i] = h.found ? h.kmer_offset - uint64_t(h.string_id) * (d.k - 1) : INVALID_U64;
+            store_result<MODE == int(out_mode::full)>(d, out, i, h);
         }
     }
+}
+
+static result_view advance(result_view v, uint64_t at) {
+    if (v.kmer_id) v.kmer_id += at;
+    if (v.kmer_id_in_string) v.kmer_id_in_string += at;
+    if (v.kmer_offset) v.kmer_offset += at;
+    if (v.string_id) v.string_id += at;
+    if (v.string_begin) v.string_begin += at;
+    if (v.string_end) v.string_end += at;
+    if (v.kmer_orientation) v.kmer_orientation += at;
+    if (v.minimizer_found) v.minimizer_found += at;
+    return v;
 }
 
 template <int W, bool CANON, int MODE, bool ASCII>
@@ -423,8 +441,11 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
     dict_view const& d = rep->view;
     skew_part_dev const* skew = rep->d_skew;
     const uint32_t block = 256;
-    if constexpr (MODE != int(out_mode::full)) {
-        if (d.directory.enabled && !max_blocks) {
+    /* Two-phase lookup through the minimizer directory -- unless the caller wants `minimizer_found`:
+       for an absent minimizer the reference's flag depends on which (arbitrary) bucket the MPHF lands
+       on, so only the MPHF path can reproduce it (device_layout.hpp (4)). */
+    {
+        if (d.directory.enabled && !max_blocks && !(MODE == int(out_mode::full) && out.minimizer_found)) {
             /* two-phase: at most 2^31 queries per launch pair so that queue indices fit 32 bits */
             const uint64_t piece = uint64_t(1) << 31;
             const size_t qbytes = size_t(W) * 8, kbytes = d.k;
@@ -436,7 +457,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                     rep->scratch_for(stream, (uint64_t(DEFER_SHARDS) * shard_capacity + DEFER_SHARDS) * sizeof(uint32_t)));
                 HIP_CHECK(hipMemsetAsync(scratch, 0, DEFER_SHARDS * sizeof(uint32_t), stream));
                 const void* qa = static_cast<const char*>(q) + at * (ASCII ? kbytes : qbytes);
-                uint64_t* ids = out.kmer_id ? out.kmer_id + at : nullptr;
+                const result_view ids = advance(out, at);
                 uint8_t* mem = member ? member + at : nullptr;
                 static const uint32_t lds_pad = std::getenv("SSHASH_AMD_LDS_PAD") ? uint32_t(atoi(std::getenv("SSHASH_AMD_LDS_PAD"))) : 0;  // occupancy experiment knob
                 hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII>), dim3(nblocks), dim3(block), lds_pad, stream, d, qa, m,

@@ -204,3 +204,26 @@ def test_repeated_launches_are_deterministic(case_se_regular):
     for _ in range(5):
         assert (d.lookup(q).kmer_id == want).all()
         assert d.is_member(q).all()
+
+
+@pytest.mark.parametrize("case_name", ["case_se_regular", "case_skew_canonical", "case_k63_canonical"])
+def test_full_result_without_minimizer_found_uses_the_same_values(case_name, request):
+    """Asking for every field except `minimizer_found` goes through the two-phase kernels; the values
+    must equal the oracle's all the same."""
+    import torch
+
+    case = request.getfixturevalue(case_name)
+    d = case.dict.to_device(0)
+    n = 20000 if case.gt.num_kmers > 100000 else 3000
+    q = case.queries(n, n, seed=21)
+    want = case.oracle.lookup_packed(q)
+    dq = torch.from_numpy(q.view(np.int64)).cuda()
+    bufs = {f: torch.empty(2 * n, dtype=torch.int64, device="cuda") for f in U64_FIELDS}
+    ori = torch.empty(2 * n, dtype=torch.int8, device="cuda")
+    extra = {f: t.data_ptr() for f, t in bufs.items() if f != "kmer_id"}
+    d.lookup_device(0, dq.data_ptr(), 2 * n, bufs["kmer_id"].data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
+                    kmer_orientation=ori.data_ptr(), **extra)
+    torch.cuda.synchronize()
+    for f in U64_FIELDS:
+        assert (bufs[f].cpu().numpy().view(np.uint64) == want[f]).all(), f
+    assert (ori.cpu().numpy().astype(np.int64) == want["kmer_orientation"]).all()

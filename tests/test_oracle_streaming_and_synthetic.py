@@ -1,0 +1,83 @@
+"""CPU: the oracle's streaming state machine against its own point lookups (the reference asserts this
+equality at include/streaming_query.hpp:107), and the synthetic benchmark generator."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from conftest import random_dna
+
+
+@pytest.mark.parametrize("case_name", ["case_skew_regular", "case_skew_canonical", "case_k63_canonical", "case_small_k"])
+def test_streaming_results_equal_point_lookups(case_name, request):
+    case = request.getfixturevalue(case_name)
+    rng = np.random.default_rng(4)
+    comp = str.maketrans("ACGT", "TGCA")
+    total = {"pos": 0, "neg": 0, "inv": 0}
+    for t in range(60):
+        s = case.sequences[int(rng.integers(0, len(case.sequences)))]
+        read = s
+        if t % 3 == 0:
+            read = s.translate(comp)[::-1]
+        if t % 4 == 1 and len(read) > case.k + 4:
+            i = int(rng.integers(0, len(read)))
+            read = read[:i] + "N" + read[i + 1:]
+        if t % 5 == 2:
+            read = read + random_dna(rng, case.k + 7)
+        res = case.oracle.streaming_read(read)
+        valid = set("ACGTacgt")
+        for i in range(len(read) - case.k + 1):
+            kmer = read[i:i + case.k]
+            if not all(c in valid for c in kmer):
+                assert res["kmer_id"][i] == np.uint64(0xFFFFFFFFFFFFFFFF)
+                total["inv"] += 1
+                continue
+            point = case.oracle.lookup_ascii(np.frombuffer(kmer.encode(), dtype=np.uint8))[0]
+            # equal_lookup_result, include/util.hpp:107-141
+            for f in ("kmer_id", "kmer_id_in_string", "string_id", "string_begin", "string_end"):
+                assert res[f][i] == point[f], (case_name, t, i, f)
+            if point["kmer_id"] != np.uint64(0xFFFFFFFFFFFFFFFF):
+                assert res["kmer_orientation"][i] == point["kmer_orientation"]
+                total["pos"] += 1
+            else:
+                total["neg"] += 1
+    assert total["pos"] > 100 and total["inv"] > 0
+
+
+def test_streaming_counters_identities(case_skew_regular):
+    case = case_skew_regular
+    rng = np.random.default_rng(8)
+    reads = [case.sequences[i % len(case.sequences)] for i in range(40)] + [random_dna(rng, 90) for _ in range(40)] + ["", "ACG", "N" * 50]
+    rep = case.oracle.streaming_query(reads)
+    assert rep["num_kmers"] == sum(max(0, len(r) - case.k + 1) for r in reads)  # src/query.cpp:93-94
+    assert rep["num_kmers"] == rep["num_positive_kmers"] + rep["num_negative_kmers"] + rep["num_invalid_kmers"]
+    assert rep["num_positive_kmers"] == rep["num_searches"] + rep["num_extensions"]  # streaming_query.hpp:113
+    assert rep["num_extensions"] > rep["num_searches"] > 0  # whole strings: almost everything extends
+
+
+def test_synthetic_spss_has_no_duplicate_kmers_and_all_bucket_classes():
+    import sshash_amd
+    from oracle.ground_truth import _revcomp_u64
+    from sshash_amd.synthetic import draw_queries, make_spss
+
+    k = 31
+    words, ends = make_spss(3_000_000, k=k, m=15, num_motifs=60, seed=5)
+    codes = ((words[:, None] >> (np.arange(32, dtype=np.uint64) * np.uint64(2))) & np.uint64(3)).reshape(-1)[: int(ends[-1])]
+    n = codes.size - k + 1
+    km = np.zeros(n, dtype=np.uint64)
+    for j in range(k):
+        km |= codes[j:j + n] << np.uint64(2 * j)
+    inner = ends[1:-1].astype(np.int64)
+    starts = np.zeros(codes.size + 2, dtype=np.int32)
+    np.add.at(starts, np.maximum(inner - k + 1, 0), 1)
+    np.add.at(starts, inner, -1)
+    km = km[np.cumsum(starts)[:n] == 0]
+    canon = np.minimum(km, _revcomp_u64(km, k))
+    assert np.unique(canon).size == km.size  # a spectrum-preserving string set: every canonical k-mer once
+    d = sshash_amd.Dictionary.build_from_packed(words, ends, k=k, m=15, num_threads=4)
+    assert d.num_kmers() == km.size
+    q = draw_queries(d, 10000, 0.5, seed=1)
+    assert q.size == 10000 and q.dtype == np.uint64
+    # positives really are k-mers of the set (either strand)
+    qc = np.minimum(q, _revcomp_u64(q, k))
+    assert 4900 <= int(np.isin(qc, canon).sum()) <= 5100
