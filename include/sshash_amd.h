@@ -48,6 +48,10 @@ typedef struct sshash_build_config {
     double lambda;        /* default 5.0 */
     uint32_t verbose;
     uint32_t reserved;
+    /* minimizer-sharded build for dictionaries larger than one GPU's HBM: keep only the buckets of the
+     * minimizers owned by shard `shard_id` of `num_shards` (strings stay complete). 0/1 = whole index. */
+    uint32_t num_shards;
+    uint32_t shard_id;
 } sshash_build_config;
 
 /* accessors of dictionary (include/dictionary.hpp:31-38) */
@@ -60,6 +64,8 @@ typedef struct sshash_info {
     uint64_t num_bits;      /* dictionary::num_bits(), host representation */
     uint32_t skew_partitions;
     uint32_t reserved;
+    uint32_t num_shards; /* 1 unless built as one shard of a minimizer-partitioned index */
+    uint32_t shard_id;
 } sshash_info;
 
 /* lookup_result (include/util.hpp:38-62) as a struct of arrays: one entry per query.
@@ -148,6 +154,13 @@ sshash_status sshash_streaming_query(const sshash_dict* d, const char* bases, co
 sshash_status sshash_streaming_query_device(const sshash_dict* d, int device, const char* bases,
                                             const uint64_t* read_offsets, uint64_t num_reads, uint64_t* report,
                                             void* hip_stream);
+
+/* ---- routing for a minimizer-sharded index: owner shard of the forward
+ *      minimizer and of the reverse-complement minimizer of every query (equal for canonical
+ *      dictionaries: the smaller-valued minimizer decides). Device pointers, asynchronous. ----------- */
+sshash_status sshash_route_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                         uint32_t num_shards, uint32_t* owner_forward, uint32_t* owner_reverse,
+                                         void* hip_stream);
 
 /* ---- tuning knob for experiments: maximum workgroups per launch (0 = default) ------------- */
 sshash_status sshash_set_max_blocks(sshash_dict* d, uint32_t max_blocks);

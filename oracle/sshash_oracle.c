@@ -47,7 +47,7 @@ typedef struct {
 } mphf;
 
 struct oracle_index {
-    uint32_t k, m, canonical, W, skew_parts;
+    uint32_t k, m, canonical, W, skew_parts, num_shards, shard_id;
     uint64_t num_kmers, num_strings, num_bases, hash_magic, build_seed;
     uint64_t* strings;
     uint64_t strings_words, strings_num_bits;
@@ -767,7 +767,7 @@ int oracle_load(const char* filename, oracle_index** out, char* err, int err_len
     uint8_t hdr[4];
     uint32_t kms[3];
     rd_raw(&r, magic, 8);
-    if (!r.ok || memcmp(magic, "SSHAMD\x01\x00", 8) != 0) {
+    if (!r.ok || memcmp(magic, "SSHAMD\x02\x00", 8) != 0) {
         snprintf(err, (size_t)err_len, "not an sshash_amd index file");
         fclose(f);
         free(d);
@@ -792,6 +792,11 @@ int oracle_load(const char* filename, oracle_index** out, char* err, int err_len
     d->hash_magic = rd_u64(&r);
     d->build_seed = rd_u64(&r);
     d->strings_num_bits = rd_u64(&r);
+    {
+        const uint64_t sh = rd_u64(&r); /* num_shards | shard_id << 32: which minimizers this index holds */
+        d->num_shards = (uint32_t)sh;
+        d->shard_id = (uint32_t)(sh >> 32);
+    }
     uint64_t cnt;
     d->strings = (uint64_t*)rd_vec(&r, 8, &d->strings_words);
     d->endpoints = (uint64_t*)rd_vec(&r, 8, &cnt);

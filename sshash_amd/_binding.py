@@ -37,6 +37,8 @@ class _BuildConfig(C.Structure):
         ("lambda_", C.c_double),
         ("verbose", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("num_shards", C.c_uint32),
+        ("shard_id", C.c_uint32),
     ]
 
 
@@ -54,6 +56,8 @@ class _Info(C.Structure):
         ("num_bits", C.c_uint64),
         ("skew_partitions", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("num_shards", C.c_uint32),
+        ("shard_id", C.c_uint32),
     ]
 
 
@@ -147,6 +151,7 @@ def _load() -> C.CDLL:
         "sshash_streaming_query": (C.c_int, [P, P, P, C.c_uint64, C.POINTER(_Report)]),
         "sshash_streaming_query_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, P, P]),
         "sshash_set_max_blocks": (C.c_int, [P, C.c_uint32]),
+        "sshash_route_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_uint32, P, P, P]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here == ABI symbol missing: fail loudly
@@ -162,7 +167,8 @@ C_ABI_SYMBOLS = (
     "sshash_lookup_packed_device sshash_lookup_ascii_device sshash_lookup_packed sshash_lookup_ascii "
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
     "sshash_access_packed_device "
-    "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device sshash_set_max_blocks"
+    "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device sshash_set_max_blocks "
+    "sshash_route_packed_device"
 ).split()
 
 
@@ -226,9 +232,10 @@ class Dictionary:
 
     # ---- construction / persistence ------------------------------------------------------
     @staticmethod
-    def _config(k, m, seed, canonical, num_threads, lambda_, verbose) -> _BuildConfig:
+    def _config(k, m, seed, canonical, num_threads, lambda_, verbose, num_shards=1, shard_id=0) -> _BuildConfig:
         cfg = _BuildConfig()
         _load().sshash_build_config_default(C.byref(cfg))
+        cfg.num_shards, cfg.shard_id = int(num_shards), int(shard_id)
         cfg.k, cfg.m, cfg.seed = int(k), int(m), int(seed)
         cfg.canonical = 1 if canonical else 0
         cfg.num_threads = int(num_threads)
@@ -238,9 +245,11 @@ class Dictionary:
 
     @classmethod
     def build(cls, input_filename: str, k: int = 31, m: int = 20, seed: int = 1, canonical: bool = False,
-              num_threads: int = 0, lambda_: float = 5.0, verbose: bool = False) -> "Dictionary":
-        """dictionary::build(input_filename, build_configuration) -- reference include/dictionary.hpp:28."""
-        cfg = cls._config(k, m, seed, canonical, num_threads, lambda_, verbose)
+              num_threads: int = 0, lambda_: float = 5.0, verbose: bool = False, num_shards: int = 1,
+              shard_id: int = 0) -> "Dictionary":
+        """dictionary::build(input_filename, build_configuration) -- reference include/dictionary.hpp:28.
+        num_shards > 1: build only the part of the sparse-and-skew index owned by `shard_id`."""
+        cfg = cls._config(k, m, seed, canonical, num_threads, lambda_, verbose, num_shards, shard_id)
         h = C.c_void_p()
         _check(_load().sshash_build_from_fasta(os.fsencode(input_filename), C.byref(cfg), C.byref(h)))
         return cls(h.value)
@@ -248,13 +257,13 @@ class Dictionary:
     @classmethod
     def build_from_packed(cls, words: np.ndarray, endpoints: np.ndarray, k: int = 31, m: int = 20, seed: int = 1,
                           canonical: bool = False, num_threads: int = 0, lambda_: float = 5.0,
-                          verbose: bool = False) -> "Dictionary":
+                          verbose: bool = False, num_shards: int = 1, shard_id: int = 0) -> "Dictionary":
         words = np.ascontiguousarray(words, dtype=np.uint64)
         endpoints = np.ascontiguousarray(endpoints, dtype=np.uint64)
         need = (2 * int(endpoints[-1]) + 63) // 64
         if words.size < need:
             raise ValueError("packed words shorter than endpoints[-1] bases")
-        cfg = cls._config(k, m, seed, canonical, num_threads, lambda_, verbose)
+        cfg = cls._config(k, m, seed, canonical, num_threads, lambda_, verbose, num_shards, shard_id)
         h = C.c_void_p()
         _check(_load().sshash_build_from_packed(words.ctypes.data, endpoints.ctypes.data, endpoints.size - 1,
                                                 C.byref(cfg), C.byref(h)))
@@ -291,6 +300,8 @@ class Dictionary:
     def num_bits(self) -> int: return int(self._info.num_bits)
     def words_per_kmer(self) -> int: return int(self._info.words_per_kmer)
     def vnum(self): return tuple(self._info.version)
+    def num_shards(self) -> int: return int(self._info.num_shards)
+    def shard_id(self) -> int: return int(self._info.shard_id)
 
     # ---- device residency -----------------------------------------------------------------
     def to_device(self, device: int = 0) -> "Dictionary":
@@ -385,6 +396,12 @@ class Dictionary:
         out = np.empty(ids.size * self.words_per_kmer(), dtype=np.uint64)
         _check(_load().sshash_access_packed(self._h, ids.ctypes.data, ids.size, out.ctypes.data))
         return out
+
+    def route_device(self, device: int, d_kmers: int, n: int, num_shards: int, d_owner_fwd: int, d_owner_rc: int,
+                     stream: int = 0) -> None:
+        """Owner shard of each query's forward / reverse-complement minimizer (uint32 device arrays)."""
+        _check(_load().sshash_route_packed_device(self._h, int(device), C.c_void_p(d_kmers), int(n), int(num_shards),
+                                                  C.c_void_p(d_owner_fwd), C.c_void_p(d_owner_rc), C.c_void_p(stream)))
 
     def access_packed_device(self, device: int, d_ids: int, n: int, d_out: int, stream: int = 0) -> None:
         _check(_load().sshash_access_packed_device(self._h, int(device), C.c_void_p(d_ids), int(n), C.c_void_p(d_out),

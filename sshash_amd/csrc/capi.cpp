@@ -37,7 +37,8 @@ sshash_status classify(std::exception const& e) {
         return SSHASH_ERR_NO_DEVICE;
     if (m.find("HIP error") != std::string::npos) return SSHASH_ERR_HIP;
     if (m.find("mphf") != std::string::npos || m.find("shorter than k") != std::string::npos ||
-        m.find("must be") != std::string::npos || m.find("no sequences") != std::string::npos)
+        m.find("must be") != std::string::npos || m.find("no sequences") != std::string::npos ||
+        m.find("shard") != std::string::npos)
         return SSHASH_ERR_BUILD;
     if (m.find("out of range") != std::string::npos || m.find("null") != std::string::npos) return SSHASH_ERR_ARGUMENT;
     return SSHASH_ERR_INTERNAL;
@@ -63,6 +64,8 @@ build_options to_options(sshash_build_config const* cfg) {
         o.num_threads = cfg->num_threads ? cfg->num_threads : std::max(1u, std::thread::hardware_concurrency());
         if (cfg->lambda > 0) o.lambda = cfg->lambda;
         o.verbose = cfg->verbose != 0;
+        o.num_shards = cfg->num_shards ? cfg->num_shards : 1;
+        o.shard_id = cfg->shard_id;
     }
     return o;
 }
@@ -108,6 +111,7 @@ void sshash_build_config_default(sshash_build_config* cfg) {
     cfg->seed = 1;
     cfg->num_threads = 1;
     cfg->lambda = 5.0;
+    cfg->num_shards = 1;
 }
 
 sshash_status sshash_build_from_fasta(const char* filename, const sshash_build_config* cfg, sshash_dict** out) {
@@ -165,6 +169,8 @@ sshash_status sshash_get_info(const sshash_dict* d, sshash_info* info) {
     info->num_minimizers = x.num_minimizers();
     info->num_bits = x.num_bits();
     info->skew_partitions = x.skew_num_partitions;
+    info->num_shards = x.num_shards;
+    info->shard_id = x.shard_id;
     return SSHASH_OK;
 }
 
@@ -306,6 +312,13 @@ sshash_status sshash_streaming_query_device(const sshash_dict* d, int device, co
                                             void* hip_stream) {
     if (!d || !report || (num_reads && (!bases || !read_offsets))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
     return guarded([&] { d->eng->streaming_query_device(device, bases, read_offsets, num_reads, 0, report, hip_stream); });
+}
+
+sshash_status sshash_route_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                         uint32_t num_shards, uint32_t* owner_forward, uint32_t* owner_reverse,
+                                         void* hip_stream) {
+    if (!d || (n && (!kmers || !owner_forward || !owner_reverse)) || num_shards == 0) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->route_packed_device(device, kmers, n, num_shards, owner_forward, owner_reverse, hip_stream); });
 }
 
 sshash_status sshash_set_max_blocks(sshash_dict* d, uint32_t max_blocks) {

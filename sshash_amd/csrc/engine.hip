@@ -524,6 +524,36 @@ void engine::lookup_ascii_device(int device, char const* d_kmers, uint64_t n, bo
     launch_any<true>(mode, rep, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream), m_max_blocks);
 }
 
+/* ---- routing of queries to the owners of their minimizers (minimizer-sharded index) ------------ */
+
+template <int W>
+__global__ void __launch_bounds__(256)
+route_kernel(const dict_view d, const uint64_t* __restrict__ kmers, const uint64_t n, const uint32_t num_shards,
+             uint32_t* __restrict__ owner_fwd, uint32_t* __restrict__ owner_rc) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const kmer_w<W> x = load_query<W, false>(kmers, i, d.k);
+    const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
+    uint64_t f = compute_minimizer<W>(x, d.k, d.m, d.hash_magic).value;
+    uint64_t r = compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic).value;
+    if (d.canonical) f = r = (r < f ? r : f);  // src/dictionary.cpp:31-40: the smaller-valued minimizer is probed
+    owner_fwd[i] = shard_of_minimizer(f, num_shards);
+    owner_rc[i] = shard_of_minimizer(r, num_shards);
+}
+
+void engine::route_packed_device(int device, uint64_t const* d_kmers, uint64_t n, uint32_t num_shards,
+                                 uint32_t* d_owner_fwd, uint32_t* d_owner_rc, void* stream) const {
+    device_replica const* rep = replica(device);
+    if (n == 0) return;
+    device_guard guard(device);
+    const dim3 grid(uint32_t((n + 255) / 256)), block(256);
+    if (rep->view.k <= 31)
+        hipLaunchKernelGGL(route_kernel<1>, grid, block, 0, hipStream_t(stream), rep->view, d_kmers, n, num_shards, d_owner_fwd, d_owner_rc);
+    else
+        hipLaunchKernelGGL(route_kernel<2>, grid, block, 0, hipStream_t(stream), rep->view, d_kmers, n, num_shards, d_owner_fwd, d_owner_rc);
+    HIP_CHECK(hipGetLastError());
+}
+
 /* ---- access(kmer_id) on the device: include/spectrum_preserving_string_set.hpp:114-118 with
         offsets::id_to_offset (include/offsets.hpp:41-65) as a binary search over the endpoints ---- */
 

@@ -168,7 +168,8 @@ void tuples_of_strings(host_index const& idx, uint64_t s_begin, uint64_t s_end, 
 template <int W>
 void build_skew_index(host_index& idx, std::vector<mini_tuple> const& tuples,
                       std::vector<uint64_t> const& heavy_order /* bucket ids, size ascending */,
-                      std::vector<uint64_t> const& bucket_begin, std::vector<uint32_t> const& bucket_size,
+                      std::vector<uint64_t> const& bucket_begin, std::vector<uint64_t> const& bucket_end,
+                      std::vector<uint32_t> const& bucket_size,
                       std::vector<uint32_t> const& heavy_partition /* per entry of heavy_order */,
                       build_options const& opt, uint64_t mphf_seed) {
     const uint32_t k = idx.k;
@@ -182,7 +183,7 @@ void build_skew_index(host_index& idx, std::vector<mini_tuple> const& tuples,
             const uint64_t b = heavy_order[h];
             uint64_t prev_pos = INVALID_U64;
             uint32_t pib = uint32_t(-1);
-            for (uint64_t t = bucket_begin[b]; t < bucket_begin[b + 1]; ++t) {
+            for (uint64_t t = bucket_begin[b]; t < bucket_end[b]; ++t) {
                 auto const& mt = tuples[t];
                 if (mt.pos() != prev_pos) {
                     prev_pos = mt.pos();
@@ -241,7 +242,10 @@ void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, st
     idx.k = opt.k;
     idx.m = opt.m;
     idx.canonical = opt.canonical;
+    if (opt.num_shards == 0 || opt.shard_id >= opt.num_shards) throw std::runtime_error("shard_id must be < num_shards");
     idx.build_seed = opt.seed;
+    idx.num_shards = opt.num_shards;
+    idx.shard_id = opt.shard_id;
     idx.hash_magic = xxh64_of_u64(opt.seed, 0);  // include/hash_util.hpp:88
     idx.endpoints = std::move(endpoints);
     idx.num_strings = idx.endpoints.size() - 1;
@@ -292,7 +296,7 @@ void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, st
     /* 2. buckets = runs of equal minimizer; size = number of DISTINCT positions
           (include/builder/util.hpp:61-78) */
     std::vector<uint64_t> keys;
-    std::vector<uint64_t> bucket_begin;
+    std::vector<uint64_t> bucket_begin, bucket_end;
     std::vector<uint32_t> bucket_size;
     for (uint64_t t = 0; t < tuples.size();) {
         uint64_t e = t;
@@ -305,12 +309,15 @@ void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, st
             }
             ++e;
         }
-        keys.push_back(tuples[t].minimizer);
-        bucket_begin.push_back(t);
-        bucket_size.push_back(distinct);
+        if (opt.num_shards == 1 || shard_of_minimizer(tuples[t].minimizer, opt.num_shards) == opt.shard_id) {
+            keys.push_back(tuples[t].minimizer);
+            bucket_begin.push_back(t);
+            bucket_end.push_back(e);
+            bucket_size.push_back(distinct);
+        }
         t = e;
     }
-    bucket_begin.push_back(tuples.size());
+    if (keys.empty()) throw std::runtime_error("no minimizer falls into this shard: the input is too small to be sharded this way");
     const uint64_t num_minimizers = keys.size();
 
     /* 3. minimizers MPHF (include/minimizers_control_map.hpp:6-34) */
@@ -411,7 +418,7 @@ void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, st
             const uint64_t list_id = code[b] >> (2 + MIN_L);
             uint64_t at = idx.begin_buckets_of_size[s] + list_id * s;
             uint64_t prev = INVALID_U64;
-            for (uint64_t t = bucket_begin[b]; t < bucket_begin[b + 1]; ++t) {
+            for (uint64_t t = bucket_begin[b]; t < bucket_end[b]; ++t) {
                 if (tuples[t].pos() != prev) {
                     prev = tuples[t].pos();
                     idx.mid_load_buckets.set(at++, prev);
@@ -422,7 +429,7 @@ void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, st
             const uint64_t b = heavy_order[h];
             uint64_t at = heavy_begin[h];
             uint64_t prev = INVALID_U64;
-            for (uint64_t t = bucket_begin[b]; t < bucket_begin[b + 1]; ++t) {
+            for (uint64_t t = bucket_begin[b]; t < bucket_end[b]; ++t) {
                 if (tuples[t].pos() != prev) {
                     prev = tuples[t].pos();
                     idx.heavy_load_buckets.set(at++, prev);
@@ -437,8 +444,8 @@ void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, st
 
     /* 5. skew index (:261-478) */
     if (num_partitions) {
-        if (W == 1) build_skew_index<1>(idx, tuples, heavy_order, bucket_begin, bucket_size, heavy_partition, opt, mphf_seed);
-        else build_skew_index<2>(idx, tuples, heavy_order, bucket_begin, bucket_size, heavy_partition, opt, mphf_seed);
+        if (W == 1) build_skew_index<1>(idx, tuples, heavy_order, bucket_begin, bucket_end, bucket_size, heavy_partition, opt, mphf_seed);
+        else build_skew_index<2>(idx, tuples, heavy_order, bucket_begin, bucket_end, bucket_size, heavy_partition, opt, mphf_seed);
         if (opt.verbose) fprintf(stderr, "[build] skew index (%u partitions) in %.2fs\n", num_partitions, tm.lap());
     }
 }
@@ -540,9 +547,9 @@ void access_kmer(host_index const& idx, uint64_t kmer_id, char* out) {
 /* ---- (de)serialisation ----------------------------------------------------------------- */
 //
 // File layout (all little-endian, every section 8-byte aligned):
-//   "SSHAMD\x01\x00"  magic
+//   "SSHAMD\x02\x00"  magic
 //   u8 version[3], u8 canonical, u32 k, u32 m, u32 skew_num_partitions
-//   u64 num_kmers, num_strings, num_bases, hash_magic, build_seed, strings_num_bits
+//   u64 num_kmers, num_strings, num_bases, hash_magic, build_seed, strings_num_bits, num_shards | shard_id << 32
 //   vec<u64> strings, vec<u64> endpoints
 //   mphf minimizers, packed control_codewords, vec<u32> begin_buckets_of_size, packed mid_load_buckets
 //   skew_num_partitions x { mphf, packed positions }, packed heavy_load_buckets
@@ -616,7 +623,7 @@ struct reader {
         vec(m.free_slots);
     }
 };
-const char FILE_MAGIC[8] = {'S', 'S', 'H', 'A', 'M', 'D', 1, 0};
+const char FILE_MAGIC[8] = {'S', 'S', 'H', 'A', 'M', 'D', 2, 0};
 }  // namespace
 
 void save_index(host_index const& idx, std::string const& filename) {
@@ -635,6 +642,7 @@ void save_index(host_index const& idx, std::string const& filename) {
         w.u64(idx.hash_magic);
         w.u64(idx.build_seed);
         w.u64(idx.strings_num_bits);
+        w.u64(uint64_t(idx.num_shards) | (uint64_t(idx.shard_id) << 32));
         w.vec(idx.strings);
         w.vec(idx.endpoints);
         w.mphf(idx.minimizers_mphf);
@@ -683,6 +691,12 @@ void load_index(host_index& idx, std::string const& filename) {
         idx.hash_magic = r.u64();
         idx.build_seed = r.u64();
         idx.strings_num_bits = r.u64();
+        {
+            const uint64_t sh = r.u64();
+            idx.num_shards = uint32_t(sh);
+            idx.shard_id = uint32_t(sh >> 32);
+            if (idx.num_shards == 0 || idx.shard_id >= idx.num_shards) throw std::runtime_error("index file corrupt (shard)");
+        }
         r.vec(idx.strings);
         r.vec(idx.endpoints);
         r.mphf(idx.minimizers_mphf);

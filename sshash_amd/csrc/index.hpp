@@ -41,6 +41,10 @@ struct build_options {
     uint32_t num_threads = 1;
     double lambda = 5.0;        // include/constants.hpp:10
     bool verbose = false;
+    /* minimizer-sharded build: keep only the buckets of minimizers owned by `shard_id`
+       (shard_of_minimizer); strings and endpoints stay complete. num_shards = 1: the whole index. */
+    uint32_t num_shards = 1;
+    uint32_t shard_id = 0;
 };
 
 struct host_index {
@@ -53,6 +57,7 @@ struct host_index {
     bool canonical = false;
     uint64_t hash_magic = 0;  // mixer_64::m_magic
     uint64_t build_seed = 0;
+    uint32_t num_shards = 1, shard_id = 0;  // which part of the minimizer space this index holds
 
     /* spectrum-preserving string set */
     std::vector<uint64_t> strings;  // 2 bits/base, LSB first, + zero sentinel words

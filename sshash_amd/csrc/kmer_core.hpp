@@ -219,6 +219,13 @@ SSH_HD minimizer_t compute_minimizer(kmer_w<W> x, uint32_t k, uint32_t m, uint64
     return r;
 }
 
+/* Owner shard of a minimizer when the sparse-and-skew index is partitioned by minimizer over several
+   GPUs. Independent of the MPHF / directory hashes. */
+SSH_HD uint32_t shard_of_minimizer(uint64_t minimizer, uint32_t num_shards) {
+    const uint64_t h = minimizer * 0xA24BAED4963EE407ULL;
+    return uint32_t((uint64_t(uint32_t(h >> 32) ^ uint32_t(h >> 11)) * num_shards) >> 32);
+}
+
 /* XXH64 of one little-endian 64-bit word (published xxHash algorithm). The reference
    derives the m-mer hash magic as xxhash_64(seed, 0) (include/hash_util.hpp:88). */
 inline uint64_t xxh64_of_u64(uint64_t value, uint64_t seed) {

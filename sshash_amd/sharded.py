@@ -1,0 +1,130 @@
+"""Minimizer-sharded dictionary: one shard of the sparse-and-skew index per GPU, queries routed with
+an all-to-all (BASELINE.json config 5: an index larger than one GPU's HBM).
+
+The replicated mode (bench.py) needs no collective. This mode is for dictionaries whose
+minimizer-side structures (directory / MPHF / control codewords / bucket lists, ~70 % of the index) do
+not fit one HBM: rank r holds only the buckets of the minimizers with ``shard_of_minimizer(mu, R) == r``
+(``Dictionary.build(..., num_shards=R, shard_id=r)``), plus the complete strings.
+
+Lookup of a local batch on rank r (all device-side except the split-size exchange):
+
+ 1. route      ``sshash_route_packed_device``: owner of the forward minimizer and of the reverse-complement
+               minimizer of every query (equal for canonical dictionaries);
+ 2. exchange   one message per (query, distinct owner): the packed k-mer; ``all_to_all_single`` over
+               RCCL (xGMI) -- 8*W bytes per message out, 8 bytes back;
+ 3. lookup     every rank runs the ordinary batched lookup on what it received: a probe whose minimizer
+               lives on another shard simply misses (its fingerprint is not there);
+ 4. return     ids travel back with the inverse all-to-all;
+ 5. combine    the reply of the forward-minimizer owner wins when it found the k-mer (that is the
+               reference's forward probe, src/dictionary.cpp:70), else the reverse owner's reply.
+
+Results are identical to the unsharded dictionary: ids derive from string offsets, which are global.
+torch is used for what it is good at here -- sort / bincount / index plumbing and ``torch.distributed``;
+the k-mer work stays in the HIP kernels behind the C ABI. With a ``gloo`` group (tests) the payloads are
+staged through host memory.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from ._binding import INVALID_U64, Dictionary
+
+
+class ShardedDictionary:
+    def __init__(self, shard: Dictionary, device: int, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.shard = shard
+        self.device = int(device)
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        if shard.num_shards() != self.world or shard.shard_id() != self.rank:
+            raise ValueError(f"rank {self.rank}/{self.world} was given shard {shard.shard_id()}/{shard.num_shards()}")
+        self._on_host = dist.get_backend(group) == "gloo"
+        self._dev = torch.device("cuda", self.device)
+        shard.to_device(self.device)
+
+    @classmethod
+    def build(cls, input_filename: str, device: int, group=None, **build_kwargs) -> "ShardedDictionary":
+        import torch.distributed as dist
+
+        shard = Dictionary.build(input_filename, num_shards=dist.get_world_size(group), shard_id=dist.get_rank(group),
+                                 **build_kwargs)
+        return cls(shard, device, group)
+
+    # -- collectives -----------------------------------------------------------------------------
+    def _all_to_all(self, send, send_counts, recv_counts):
+        import torch
+        import torch.distributed as dist
+
+        width = send.shape[1:]
+        if self._on_host:
+            s = send.cpu().contiguous()
+            r = torch.empty((int(sum(recv_counts)),) + tuple(width), dtype=send.dtype)
+            dist.all_to_all_single(r, s, list(recv_counts), list(send_counts), group=self.group)
+            return r.to(self._dev)
+        r = torch.empty((int(sum(recv_counts)),) + tuple(width), dtype=send.dtype, device=self._dev)
+        dist.all_to_all_single(r, send.contiguous(), list(recv_counts), list(send_counts), group=self.group)
+        return r
+
+    def _exchange_counts(self, send_counts):
+        import torch
+        import torch.distributed as dist
+
+        s = torch.tensor(send_counts, dtype=torch.int64, device="cpu" if self._on_host else self._dev)
+        r = torch.empty_like(s)
+        dist.all_to_all_single(r, s, group=self.group)
+        return [int(x) for x in r.tolist()]
+
+    # -- lookup ----------------------------------------------------------------------------------------
+    def lookup_device(self, d_kmers, check_reverse_complement: bool = True):
+        """d_kmers: int64 CUDA tensor of n*W packed words on this rank's device -> int64 CUDA tensor of n ids
+        (bit pattern of the uint64 ids; INVALID_U64 == -1)."""
+        import torch
+
+        W = self.shard.words_per_kmer()
+        n = d_kmers.numel() // W
+        stream = torch.cuda.current_stream(self._dev).cuda_stream
+        q = d_kmers.view(n, W)
+        owner_f = torch.empty(n, dtype=torch.int32, device=self._dev)
+        owner_r = torch.empty(n, dtype=torch.int32, device=self._dev)
+        if n:
+            self.shard.route_device(self.device, d_kmers.data_ptr(), n, self.world, owner_f.data_ptr(), owner_r.data_ptr(),
+                                    stream=stream)
+        if not check_reverse_complement:
+            owner_r = owner_f
+        second = (owner_r != owner_f).nonzero(as_tuple=True)[0]
+        slot = torch.cat([torch.arange(n, device=self._dev), second])            # which local query a message is about
+        dest = torch.cat([owner_f.long(), owner_r.long()[second]])
+        order = torch.sort(dest, stable=True)[1]
+        slot, dest = slot[order], dest[order]
+        send_counts = torch.bincount(dest, minlength=self.world).tolist()
+        recv_counts = self._exchange_counts(send_counts)
+        received = self._all_to_all(q[slot], send_counts, recv_counts)            # (m, W) packed k-mers to look up here
+        m = received.shape[0]
+        ids = torch.full((max(m, 1),), -1, dtype=torch.int64, device=self._dev)
+        if m:
+            received = received.contiguous()
+            self.shard.lookup_device(self.device, received.data_ptr(), m, ids.data_ptr(),
+                                     check_reverse_complement=check_reverse_complement, stream=stream)
+        replies = self._all_to_all(ids[:m].view(m, 1), recv_counts, send_counts).view(-1)  # aligned with `slot`
+        out = torch.full((n,), -1, dtype=torch.int64, device=self._dev)
+        is_first = order < n                                                       # message went to the forward owner
+        found = replies != -1
+        back = found & ~is_first
+        out[slot[back]] = replies[back]                                            # reverse-complement owner's answer ...
+        front = found & is_first
+        out[slot[front]] = replies[front]                                          # ... unless the forward probe hit
+        return out
+
+    def lookup(self, kmers: np.ndarray, check_reverse_complement: bool = True) -> np.ndarray:
+        """Host convenience wrapper: packed uint64 words in, uint64 ids out."""
+        import torch
+
+        a = np.ascontiguousarray(kmers, dtype=np.uint64)
+        d = torch.from_numpy(a.view(np.int64)).to(self._dev)
+        return self.lookup_device(d, check_reverse_complement).cpu().numpy().view(np.uint64)

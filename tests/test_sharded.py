@@ -1,0 +1,108 @@
+"""Minimizer-sharded index. CPU part: the shards partition the
+minimizer space and their union answers like the whole dictionary (checked with the oracle). GPU part:
+two ranks (gloo group, both on cuda:0) route, exchange with all_to_all, look up and combine."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import sshash_amd
+from conftest import ROOT, SE_FASTA
+
+
+@pytest.mark.parametrize("case_name,S", [("case_skew_regular", 2), ("case_skew_canonical", 3)])
+def test_shards_partition_the_dictionary(case_name, S, request, tmp_path):
+    from oracle import oracle as O
+
+    case = request.getfixturevalue(case_name)
+    shards = []
+    for r in range(S):
+        d = sshash_amd.Dictionary.build(case.fasta, k=case.k, m=case.m, canonical=case.canonical, num_threads=2,
+                                        num_shards=S, shard_id=r)
+        assert (d.num_shards(), d.shard_id()) == (S, r)
+        assert d.num_kmers() == case.gt.num_kmers  # strings stay complete
+        p = str(tmp_path / f"shard{r}.sshash")
+        d.save(p)
+        d2 = sshash_amd.Dictionary.load(p)
+        assert (d2.num_shards(), d2.shard_id(), d2.num_minimizers()) == (S, r, d.num_minimizers())
+        shards.append((d, O.OracleIndex(p)))
+    assert sum(d.num_minimizers() for d, _ in shards) == case.dict.num_minimizers()
+    assert all(d.num_minimizers() > 0 for d, _ in shards)
+    q = case.queries(3000, 3000, seed=31)
+    full = case.oracle.lookup_ids(q)
+    per_shard = np.stack([o.lookup_ids(q) for _, o in shards])
+    found = per_shard != np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert (found.sum(axis=0) <= 1).all()  # a k-mer is answered by exactly one owner (or by none)
+    combined = np.where(found.any(axis=0), per_shard.min(axis=0), np.uint64(0xFFFFFFFFFFFFFFFF))
+    assert (combined == full).all()
+
+
+def test_bad_shard_arguments(case_skew_regular):
+    with pytest.raises(sshash_amd.SSHashError) as e:
+        sshash_amd.Dictionary.build(case_skew_regular.fasta, k=31, m=11, num_shards=2, shard_id=2)
+    assert e.value.status == 7
+
+
+WORKER = textwrap.dedent(
+    """
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, sys.argv[1])
+    import torch, torch.distributed as dist
+    import sshash_amd
+    from sshash_amd.sharded import ShardedDictionary
+    from oracle import oracle as O
+    from oracle.ground_truth import GroundTruth, read_fasta_sequences, _revcomp_u64
+
+    fasta, canonical = sys.argv[2], sys.argv[3] == "1"
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    sd = ShardedDictionary.build(fasta, device=0, k=31, m=13, canonical=canonical, num_threads=4)
+    # expected ids: the whole dictionary through the oracle
+    whole = sshash_amd.Dictionary.build(fasta, k=31, m=13, canonical=canonical, num_threads=4)
+    path = f"/tmp/sshash_sharded_test_{os.getpid()}.sshash"
+    whole.save(path)
+    ora = O.OracleIndex(path)
+    os.unlink(path)
+    rng = np.random.default_rng(100 + rank)  # every rank looks up its OWN batch
+    n = whole.num_kmers()
+    ids = rng.integers(0, n, 30000, dtype=np.uint64)
+    pos = whole.access_packed(ids)
+    pos[::2] = _revcomp_u64(pos[::2], 31)
+    neg = rng.integers(0, 1 << 62, 30000, dtype=np.uint64)
+    q = np.concatenate([pos, neg])
+    rng.shuffle(q)
+    got = sd.lookup(q)
+    want = ora.lookup_ids(q)
+    assert (got == want).all(), f"rank {rank}: sharded ids differ"
+    got2 = sd.lookup(q, check_reverse_complement=False)
+    assert (got2 == ora.lookup_ids(q, check_rc=False)).all()
+    assert sd.lookup(np.zeros(0, dtype=np.uint64)).size == 0  # an empty local batch still takes part in the exchange
+    found = int((got != np.uint64(0xFFFFFFFFFFFFFFFF)).sum())
+    t = torch.tensor([found]); dist.all_reduce(t)
+    if rank == 0:
+        print("SHARDED OK", int(t), sd.shard.num_minimizers(), whole.num_minimizers(), flush=True)
+    dist.barrier(); dist.destroy_process_group()
+    """
+)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("canonical", [False, True])
+def test_two_rank_sharded_lookup_on_gpu(canonical, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541" if canonical else "29540", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, SE_FASTA, "1" if canonical else "0"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    assert "SHARDED OK 60000" in outs[0]
