@@ -162,9 +162,6 @@ sshash_status sshash_route_packed_device(const sshash_dict* d, int device, const
                                          uint32_t num_shards, uint32_t* owner_forward, uint32_t* owner_reverse,
                                          void* hip_stream);
 
-/* ---- tuning knob for experiments: maximum workgroups per launch (0 = default) ------------- */
-sshash_status sshash_set_max_blocks(sshash_dict* d, uint32_t max_blocks);
-
 #ifdef __cplusplus
 }
 #endif

@@ -150,7 +150,6 @@ def _load() -> C.CDLL:
         "sshash_streaming_query_from_file": (C.c_int, [P, C.c_char_p, C.c_int, C.POINTER(_Report)]),
         "sshash_streaming_query": (C.c_int, [P, P, P, C.c_uint64, C.POINTER(_Report)]),
         "sshash_streaming_query_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, P, P]),
-        "sshash_set_max_blocks": (C.c_int, [P, C.c_uint32]),
         "sshash_route_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_uint32, P, P, P]),
     }
     for name, (res, args) in sigs.items():
@@ -167,7 +166,7 @@ C_ABI_SYMBOLS = (
     "sshash_lookup_packed_device sshash_lookup_ascii_device sshash_lookup_packed sshash_lookup_ascii "
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
     "sshash_access_packed_device "
-    "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device sshash_set_max_blocks "
+    "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device "
     "sshash_route_packed_device"
 ).split()
 
@@ -318,9 +317,6 @@ class Dictionary:
         _check(_load().sshash_device_stats(self._h, int(device), C.byref(out)))
         return {"bytes": int(out[0]), "directory_sectors": int(out[1]), "directory_overflow_sectors": int(out[2]),
                 "directory_keys": int(out[3])}
-
-    def set_max_blocks(self, n: int) -> None:
-        _check(_load().sshash_set_max_blocks(self._h, int(n)))
 
     # ---- lookups ---------------------------------------------------------------------------
     def _as_batch(self, kmers: KmerBatch):

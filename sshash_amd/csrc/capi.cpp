@@ -321,10 +321,4 @@ sshash_status sshash_route_packed_device(const sshash_dict* d, int device, const
     return guarded([&] { d->eng->route_packed_device(device, kmers, n, num_shards, owner_forward, owner_reverse, hip_stream); });
 }
 
-sshash_status sshash_set_max_blocks(sshash_dict* d, uint32_t max_blocks) {
-    if (!d) return fail(SSHASH_ERR_ARGUMENT, "null argument");
-    d->eng->set_block_cap(max_blocks);
-    return SSHASH_OK;
-}
-
 }  // extern "C"

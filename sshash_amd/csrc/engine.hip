@@ -437,7 +437,7 @@ static result_view advance(result_view v, uint64_t at) {
 
 template <int W, bool CANON, int MODE, bool ASCII>
 static void launch(device_replica const* rep, void const* q, uint64_t n, bool check_rc,
-                   result_view const& out, uint8_t* member, hipStream_t stream, uint32_t max_blocks) {
+                   result_view const& out, uint8_t* member, hipStream_t stream) {
     dict_view const& d = rep->view;
     skew_part_dev const* skew = rep->d_skew;
     const uint32_t block = 256;
@@ -445,7 +445,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
        for an absent minimizer the reference's flag depends on which (arbitrary) bucket the MPHF lands
        on, so only the MPHF path can reproduce it (device_layout.hpp (4)). */
     {
-        if (d.directory.enabled && !max_blocks && !(MODE == int(out_mode::full) && out.minimizer_found)) {
+        if (d.directory.enabled && !(MODE == int(out_mode::full) && out.minimizer_found)) {
             /* two-phase: at most 2^31 queries per launch pair so that queue indices fit 32 bits */
             const uint64_t piece = uint64_t(1) << 31;
             const size_t qbytes = size_t(W) * 8, kbytes = d.k;
@@ -459,8 +459,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 const void* qa = static_cast<const char*>(q) + at * (ASCII ? kbytes : qbytes);
                 const result_view ids = advance(out, at);
                 uint8_t* mem = member ? member + at : nullptr;
-                static const uint32_t lds_pad = std::getenv("SSHASH_AMD_LDS_PAD") ? uint32_t(atoi(std::getenv("SSHASH_AMD_LDS_PAD"))) : 0;  // occupancy experiment knob
-                hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII>), dim3(nblocks), dim3(block), lds_pad, stream, d, qa, m,
+                hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII>), dim3(nblocks), dim3(block), 0, stream, d, qa, m,
                                    check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
                 hipLaunchKernelGGL((deferred_lookup_kernel<W, CANON, MODE, ASCII>), dim3(DEFER_SHARDS), dim3(block), 0, stream, d,
                                    skew, qa, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
@@ -470,8 +469,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
         }
     }
     uint64_t blocks = (n + block - 1) / block;
-    const uint64_t cap = max_blocks ? max_blocks : (uint64_t(1) << 22);
-    if (blocks > cap) blocks = cap;
+    if (blocks > (uint64_t(1) << 22)) blocks = uint64_t(1) << 22;  // grid-stride beyond 2^30 queries
     hipLaunchKernelGGL((lookup_kernel<W, CANON, MODE, ASCII>), dim3(uint32_t(blocks)), dim3(block), 0, stream, d, skew,
                        q, n, check_rc, out, member);
     HIP_CHECK(hipGetLastError());
@@ -479,23 +477,23 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
 
 template <int W, bool CANON, bool ASCII>
 static void launch_mode(out_mode mode, device_replica const* rep, void const* q, uint64_t n,
-                        bool check_rc, result_view const& out, uint8_t* member, hipStream_t s, uint32_t mb) {
+                        bool check_rc, result_view const& out, uint8_t* member, hipStream_t s) {
     switch (mode) {
-        case out_mode::ids: launch<W, CANON, 0, ASCII>(rep, q, n, check_rc, out, member, s, mb); break;
-        case out_mode::full: launch<W, CANON, 1, ASCII>(rep, q, n, check_rc, out, member, s, mb); break;
-        case out_mode::member: launch<W, CANON, 2, ASCII>(rep, q, n, check_rc, out, member, s, mb); break;
+        case out_mode::ids: launch<W, CANON, 0, ASCII>(rep, q, n, check_rc, out, member, s); break;
+        case out_mode::full: launch<W, CANON, 1, ASCII>(rep, q, n, check_rc, out, member, s); break;
+        case out_mode::member: launch<W, CANON, 2, ASCII>(rep, q, n, check_rc, out, member, s); break;
     }
 }
 
 template <bool ASCII>
 static void launch_any(out_mode mode, device_replica const* rep, void const* q, uint64_t n,
-                       bool check_rc, result_view const& out, uint8_t* member, hipStream_t s, uint32_t mb) {
+                       bool check_rc, result_view const& out, uint8_t* member, hipStream_t s) {
     dict_view const& d = rep->view;
     const bool wide = d.k > 31;
-    if (!wide && !d.canonical) launch_mode<1, false, ASCII>(mode, rep, q, n, check_rc, out, member, s, mb);
-    else if (!wide && d.canonical) launch_mode<1, true, ASCII>(mode, rep, q, n, check_rc, out, member, s, mb);
-    else if (wide && !d.canonical) launch_mode<2, false, ASCII>(mode, rep, q, n, check_rc, out, member, s, mb);
-    else launch_mode<2, true, ASCII>(mode, rep, q, n, check_rc, out, member, s, mb);
+    if (!wide && !d.canonical) launch_mode<1, false, ASCII>(mode, rep, q, n, check_rc, out, member, s);
+    else if (!wide && d.canonical) launch_mode<1, true, ASCII>(mode, rep, q, n, check_rc, out, member, s);
+    else if (wide && !d.canonical) launch_mode<2, false, ASCII>(mode, rep, q, n, check_rc, out, member, s);
+    else launch_mode<2, true, ASCII>(mode, rep, q, n, check_rc, out, member, s);
 }
 
 static void check_outputs(out_mode mode, result_view const& out, uint8_t* member) {
@@ -512,7 +510,7 @@ void engine::lookup_packed_device(int device, uint64_t const* d_kmers, uint64_t 
     check_outputs(mode, d_out, d_member);
     if (n == 0) return;
     device_guard guard(device);
-    launch_any<false>(mode, rep, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream), m_max_blocks);
+    launch_any<false>(mode, rep, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream));
 }
 
 void engine::lookup_ascii_device(int device, char const* d_kmers, uint64_t n, bool check_rc, out_mode mode,
@@ -521,7 +519,7 @@ void engine::lookup_ascii_device(int device, char const* d_kmers, uint64_t n, bo
     check_outputs(mode, d_out, d_member);
     if (n == 0) return;
     device_guard guard(device);
-    launch_any<true>(mode, rep, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream), m_max_blocks);
+    launch_any<true>(mode, rep, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream));
 }
 
 /* ---- routing of queries to the owners of their minimizers (minimizer-sharded index) ------------ */

@@ -68,14 +68,10 @@ public:
     void streaming_query_device(int device, char const* d_bases, uint64_t const* d_read_offsets, uint64_t n_reads,
                                 uint64_t total_bases, uint64_t* d_report, void* stream) const;
 
-    /* Tunables (set before launching; defaults are the measured best). */
-    void set_block_cap(uint32_t max_blocks) { m_max_blocks = max_blocks; }
-
 private:
     device_replica const* replica(int device) const;
     std::shared_ptr<host_index> m_idx;
     std::vector<std::unique_ptr<device_replica>> m_replicas;
-    uint32_t m_max_blocks = 0;
 };
 
 int visible_device_count();  // 0 when no GPU / no driver
