@@ -321,6 +321,7 @@ lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const v
 }
 
 constexpr uint32_t DEFER_SHARDS = 2048;  // power of two
+constexpr uint32_t DEFER_BLOCKS_PER_SHARD = 4;
 
 template <int W, bool ASCII>
 __device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries, uint64_t i, uint32_t k) {
@@ -409,9 +410,12 @@ deferred_lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew
                        const bool check_rc, const result_view out, uint8_t* __restrict__ member,
                        const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queue_counts,
                        const uint32_t shard_capacity) {
-    const uint32_t total = queue_counts[blockIdx.x];  // one workgroup per shard
-    const uint32_t* mine = queue + uint64_t(blockIdx.x) * shard_capacity;
-    for (uint32_t j = threadIdx.x; j < total; j += blockDim.x) {
+    /* DEFER_BLOCKS_PER_SHARD workgroups share a shard: the deferred queries are the ones with the longest
+       dependent chains, so they get as many lanes as there are entries rather than a few busy ones */
+    const uint32_t shard = blockIdx.x & (DEFER_SHARDS - 1), part = blockIdx.x / DEFER_SHARDS;
+    const uint32_t total = queue_counts[shard];
+    const uint32_t* mine = queue + uint64_t(shard) * shard_capacity;
+    for (uint32_t j = part * blockDim.x + threadIdx.x; j < total; j += DEFER_BLOCKS_PER_SHARD * blockDim.x) {
         const uint64_t i = mine[j];
         const kmer_w<W> x = load_query<W, ASCII>(queries, i, d.k);
         const hit_t h = lookup_one<W, CANON, true>(d, skew, x, check_rc);
@@ -446,8 +450,9 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
        on, so only the MPHF path can reproduce it (device_layout.hpp (4)). */
     {
         if (d.directory.enabled && !(MODE == int(out_mode::full) && out.minimizer_found)) {
-            /* two-phase: at most 2^31 queries per launch pair so that queue indices fit 32 bits */
-            const uint64_t piece = uint64_t(1) << 31;
+            /* two-phase: at most 2^27 queries per launch pair (queue indices are 32-bit; the scratch
+               queue stays at 0.5 GiB) */
+            const uint64_t piece = uint64_t(1) << 27;
             const size_t qbytes = size_t(W) * 8, kbytes = d.k;
             for (uint64_t at = 0; at < n; at += piece) {
                 const uint64_t m = std::min(piece, n - at);
@@ -461,7 +466,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 uint8_t* mem = member ? member + at : nullptr;
                 hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII>), dim3(nblocks), dim3(block), 0, stream, d, qa, m,
                                    check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
-                hipLaunchKernelGGL((deferred_lookup_kernel<W, CANON, MODE, ASCII>), dim3(DEFER_SHARDS), dim3(block), 0, stream, d,
+                hipLaunchKernelGGL((deferred_lookup_kernel<W, CANON, MODE, ASCII>), dim3(DEFER_SHARDS * DEFER_BLOCKS_PER_SHARD), dim3(block), 0, stream, d,
                                    skew, qa, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
                 HIP_CHECK(hipGetLastError());
             }

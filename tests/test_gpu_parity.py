@@ -228,3 +228,27 @@ def test_full_result_without_minimizer_found_uses_the_same_values(case_name, req
     for f in U64_FIELDS:
         assert (bufs[f].cpu().numpy().view(np.uint64) == want[f]).all(), f
     assert (ori.cpu().numpy().astype(np.int64) == want["kmer_orientation"]).all()
+
+
+def test_batch_larger_than_one_launch_piece(case_se_regular):
+    """More than 2^27 queries in one call: the two-phase path splits the batch into launch pairs; ids at
+    and around the seam must be right (positives planted there, oracle on a sample of the rest)."""
+    import torch
+
+    case = case_se_regular
+    d = case.dict.to_device(0)
+    n = (1 << 27) + 70001
+    rng = np.random.default_rng(77)
+    q = rng.integers(0, 1 << 62, n, dtype=np.uint64)
+    ids = rng.integers(0, case.gt.num_kmers, 200000, dtype=np.uint64)
+    where = np.concatenate([np.arange((1 << 27) - 50000, (1 << 27) + 50000), rng.choice((1 << 27) - 50000, 100000, replace=False)])
+    q[where] = case.gt.kmers(ids)
+    dq = torch.from_numpy(q.view(np.int64)).cuda()
+    out = torch.full((n,), -3, dtype=torch.int64, device="cuda")
+    d.lookup_device(0, dq.data_ptr(), n, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    assert (got[where] == ids).all()
+    sample = np.concatenate([np.arange(0, n, 997), np.arange((1 << 27) - 3000, (1 << 27) + 3000)])
+    assert (got[sample] == case.oracle.lookup_ids(q[sample])).all()
+    assert int((got == np.uint64(0xFFFFFFFFFFFFFFFD)).sum()) == 0  # nothing left unwritten
