@@ -25,22 +25,8 @@ sshash_status fail(sshash_status s, std::string const& msg) {
 }
 
 sshash_status classify(std::exception const& e) {
-    const std::string m = e.what();
-    g_last_error = m;
-    if (m.find("MAJOR index version") != std::string::npos) return SSHASH_ERR_VERSION;
-    if (m.find("error in opening") != std::string::npos || m.find("cannot open") != std::string::npos ||
-        m.find("write error") != std::string::npos)
-        return SSHASH_ERR_IO;
-    if (m.find("index file") != std::string::npos) return SSHASH_ERR_FORMAT;
-    if (m.find("no HIP device") != std::string::npos || m.find("not resident") != std::string::npos ||
-        m.find("invalid device") != std::string::npos)
-        return SSHASH_ERR_NO_DEVICE;
-    if (m.find("HIP error") != std::string::npos) return SSHASH_ERR_HIP;
-    if (m.find("mphf") != std::string::npos || m.find("shorter than k") != std::string::npos ||
-        m.find("must be") != std::string::npos || m.find("no sequences") != std::string::npos ||
-        m.find("shard") != std::string::npos)
-        return SSHASH_ERR_BUILD;
-    if (m.find("out of range") != std::string::npos || m.find("null") != std::string::npos) return SSHASH_ERR_ARGUMENT;
+    g_last_error = e.what();
+    if (auto const* typed = dynamic_cast<error const*>(&e)) return sshash_status(int(typed->kind));
     return SSHASH_ERR_INTERNAL;
 }
 
@@ -261,7 +247,7 @@ sshash_status sshash_access_packed(const sshash_dict* d, const uint64_t* kmer_id
                 for (uint64_t i = b; i < e; ++i) access_kmer_packed(*d->idx, kmer_ids[i], out_words + i * W);
             } catch (std::exception const& ex) { err = ex.what(); }
         });
-        if (!err.empty()) throw std::runtime_error(err);
+        if (!err.empty()) throw error(error_kind::argument, err);
     });
 }
 

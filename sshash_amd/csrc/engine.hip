@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <exception>
 #include <stdexcept>
 #include <thread>
 
@@ -30,7 +31,7 @@ static std::vector<granule> make_granules(host_index const& idx, uint32_t num_th
             g[i].bases = i < idx.strings.size() ? idx.strings[i] : 0;
         }
     });
-    if (idx.endpoints.size() >= (uint64_t(1) << 32)) throw std::runtime_error("more than 2^32 strings");
+    if (idx.endpoints.size() >= (uint64_t(1) << 32)) throw error(error_kind::build, "more than 2^32 strings");
     for (uint64_t e : idx.endpoints) g[e >> 5].marks |= 1u << (e & 31);
     uint32_t acc = 0;
     for (uint64_t i = 0; i < G; ++i) {
@@ -171,15 +172,15 @@ void engine::device_stats(int device, uint64_t out[4]) const {
 device_replica const* engine::replica(int device) const {
     for (auto const& r : m_replicas)
         if (r->device == device) return r.get();
-    throw std::runtime_error("dictionary is not resident on device " + std::to_string(device) +
+    throw error(error_kind::no_device, "dictionary is not resident on device " + std::to_string(device) +
                              " (call sshash_to_device first)");
 }
 
 void engine::to_device(int device) {
     if (on_device(device)) return;
     const int count = visible_device_count();
-    if (count == 0) throw std::runtime_error("no HIP device visible: the lookup path requires an MI355X (no CPU fallback)");
-    if (device < 0 || device >= count) throw std::runtime_error("invalid device ordinal " + std::to_string(device));
+    if (count == 0) throw error(error_kind::no_device, "no HIP device visible: the lookup path requires an MI355X (no CPU fallback)");
+    if (device < 0 || device >= count) throw error(error_kind::no_device, "invalid device ordinal " + std::to_string(device));
     device_guard guard(device);
     host_index const& idx = *m_idx;
     auto rep = std::make_unique<device_replica>();
@@ -503,9 +504,9 @@ static void launch_any(out_mode mode, device_replica const* rep, void const* q, 
 
 static void check_outputs(out_mode mode, result_view const& out, uint8_t* member) {
     if (mode == out_mode::member) {
-        if (!member) throw std::runtime_error("is_member output pointer is null");
+        if (!member) throw error(error_kind::argument, "is_member output pointer is null");
     } else if (!out.kmer_id) {
-        throw std::runtime_error("kmer_id output pointer is null");
+        throw error(error_kind::argument, "kmer_id output pointer is null");
     }
 }
 
@@ -624,10 +625,10 @@ static void host_lookup(engine const& eng, std::vector<int> const& devs, void co
                         uint64_t n, bool check_rc, out_mode mode, result_view const& h_out, uint8_t* h_member) {
     check_outputs(mode, h_out, h_member);
     if (n == 0) return;
-    if (devs.empty()) throw std::runtime_error("dictionary is not resident on any device (call sshash_to_device first)");
+    if (devs.empty()) throw error(error_kind::no_device, "dictionary is not resident on any device (call sshash_to_device first)");
     const uint64_t G = devs.size();
     const uint64_t chunk = uint64_t(1) << 24;  // queries per device round
-    std::vector<std::string> errors(G);
+    std::vector<std::exception_ptr> errors(G);
     std::vector<std::thread> workers;
     for (uint64_t g = 0; g < G; ++g) {
         workers.emplace_back([&, g] {
@@ -680,14 +681,17 @@ static void host_lookup(engine const& eng, std::vector<int> const& devs, void co
                         HIP_CHECK(hipStreamSynchronize(s));
                     }
                 }
+                eng.release_stream(devs[g], s);
                 HIP_CHECK(hipStreamDestroy(s));
-            } catch (std::exception const& e) { errors[g] = e.what(); }
+            } catch (...) { errors[g] = std::current_exception(); }
         });
     }
     for (auto& w : workers) w.join();
     for (auto const& e : errors)
-        if (!e.empty()) throw std::runtime_error(e);
+        if (e) std::rethrow_exception(e);
 }
+
+void engine::release_stream(int device, void* stream) const { replica(device)->scratch_release(stream); }
 
 void engine::lookup_packed_host(uint64_t const* h_kmers, uint64_t n, bool check_rc, out_mode mode,
                                 result_view const& h_out, uint8_t* h_member) const {

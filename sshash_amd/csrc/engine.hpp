@@ -70,6 +70,11 @@ public:
 
 private:
     device_replica const* replica(int device) const;
+public:
+    /* drop the per-stream scratch of a stream the caller is about to destroy */
+    void release_stream(int device, void* stream) const;
+
+private:
     std::shared_ptr<host_index> m_idx;
     std::vector<std::unique_ptr<device_replica>> m_replicas;
 };

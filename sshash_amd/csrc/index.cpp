@@ -233,16 +233,16 @@ uint64_t host_index::num_bits() const {
 
 void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, std::vector<uint64_t>&& endpoints,
                        build_options const& opt) {
-    if (opt.k < 1 || opt.k > 63 || (opt.k % 2) == 0) throw std::runtime_error("k must be odd and in [1,63]");
-    if (opt.m < 1 || opt.m > 31 || opt.m > opt.k) throw std::runtime_error("m must be in [1,min(31,k)]");
-    if (opt.k - opt.m + 1 >= 256) throw std::runtime_error("k-m+1 does not fit 8 bits");
-    if (endpoints.size() < 2 || endpoints.front() != 0) throw std::runtime_error("bad endpoints");
+    if (opt.k < 1 || opt.k > 63 || (opt.k % 2) == 0) throw error(error_kind::build, "k must be odd and in [1,63]");
+    if (opt.m < 1 || opt.m > 31 || opt.m > opt.k) throw error(error_kind::build, "m must be in [1,min(31,k)]");
+    if (opt.k - opt.m + 1 >= 256) throw error(error_kind::build, "k-m+1 does not fit 8 bits");
+    if (endpoints.size() < 2 || endpoints.front() != 0) throw error(error_kind::build, "bad endpoints");
     timer tm;
     idx = host_index();
     idx.k = opt.k;
     idx.m = opt.m;
     idx.canonical = opt.canonical;
-    if (opt.num_shards == 0 || opt.shard_id >= opt.num_shards) throw std::runtime_error("shard_id must be < num_shards");
+    if (opt.num_shards == 0 || opt.shard_id >= opt.num_shards) throw error(error_kind::build, "shard_id must be < num_shards");
     idx.build_seed = opt.seed;
     idx.num_shards = opt.num_shards;
     idx.shard_id = opt.shard_id;
@@ -253,7 +253,7 @@ void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, st
     idx.num_kmers = 0;
     for (uint64_t s = 0; s < idx.num_strings; ++s) {
         const uint64_t len = idx.endpoints[s + 1] - idx.endpoints[s];
-        if (len < opt.k) throw std::runtime_error("input string shorter than k");
+        if (len < opt.k) throw error(error_kind::build, "input string shorter than k");
         idx.num_kmers += len - opt.k + 1;
     }
     const uint32_t W = idx.words_per_kmer();
@@ -317,7 +317,7 @@ void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, st
         }
         t = e;
     }
-    if (keys.empty()) throw std::runtime_error("no minimizer falls into this shard: the input is too small to be sharded this way");
+    if (keys.empty()) throw error(error_kind::build, "no minimizer falls into this shard: the input is too small to be sharded this way");
     const uint64_t num_minimizers = keys.size();
 
     /* 3. minimizers MPHF (include/minimizers_control_map.hpp:6-34) */
@@ -361,7 +361,7 @@ void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, st
     {
         uint64_t acc = 0;
         for (uint32_t s = 2; s <= MAX_BUCKET_SMALL; ++s) {
-            if (acc >= (uint64_t(1) << 32)) throw std::runtime_error("mid_load_buckets exceeds 2^32 entries");
+            if (acc >= (uint64_t(1) << 32)) throw error(error_kind::build, "mid_load_buckets exceeds 2^32 entries");
             idx.begin_buckets_of_size[s] = uint32_t(acc);
             acc += count_of_size[s] * s;
         }
@@ -470,7 +470,7 @@ void build_from_sequences(host_index& idx, std::vector<std::string> const& seqs,
 
 void build_from_fasta(host_index& idx, std::string const& filename, build_options const& opt) {
     gzFile f = gzopen(filename.c_str(), "rb");  // transparently reads plain or gzip
-    if (!f) throw std::runtime_error("error in opening the file '" + filename + "'");
+    if (!f) throw error(error_kind::io, "error in opening the file '" + filename + "'");
     gzbuffer(f, 1 << 20);
     std::vector<uint64_t> words, endpoints{0};
     uint64_t num_bases = 0;
@@ -501,13 +501,13 @@ void build_from_fasta(host_index& idx, std::string const& filename, build_option
         if (!seq.empty() && seq.back() == '\r') seq.pop_back();
         if (seq.size() < opt.k) {
             gzclose(f);
-            throw std::runtime_error("input sequence shorter than k");
+            throw error(error_kind::build, "input sequence shorter than k");
         }
         pack_append(words, num_bases, seq.data(), seq.size());
         endpoints.push_back(num_bases);
     }
     gzclose(f);
-    if (endpoints.size() < 2) throw std::runtime_error("no sequences in '" + filename + "'");
+    if (endpoints.size() < 2) throw error(error_kind::build, "no sequences in '" + filename + "'");
     build_from_packed(idx, std::move(words), std::move(endpoints), opt);
 }
 
@@ -526,7 +526,7 @@ static uint64_t id_to_offset(host_index const& idx, uint64_t kmer_id) {
 }
 
 void access_kmer_packed(host_index const& idx, uint64_t kmer_id, uint64_t* out) {
-    if (kmer_id >= idx.num_kmers) throw std::runtime_error("kmer_id out of range");
+    if (kmer_id >= idx.num_kmers) throw error(error_kind::argument, "kmer_id out of range");
     const uint64_t off = id_to_offset(idx, kmer_id);
     if (idx.words_per_kmer() == 1) {
         out[0] = read_kmer<1>(idx.strings.data(), off, idx.k).w[0];
@@ -538,7 +538,7 @@ void access_kmer_packed(host_index const& idx, uint64_t kmer_id, uint64_t* out) 
 }
 
 void access_kmer(host_index const& idx, uint64_t kmer_id, char* out) {
-    if (kmer_id >= idx.num_kmers) throw std::runtime_error("kmer_id out of range");
+    if (kmer_id >= idx.num_kmers) throw error(error_kind::argument, "kmer_id out of range");
     const uint64_t off = id_to_offset(idx, kmer_id);
     static const char alphabet[] = "ACTG";  // include/kmer.hpp:118
     for (uint32_t i = 0; i < idx.k; ++i) out[i] = alphabet[base_at(idx.strings.data(), off + i)];
@@ -562,7 +562,7 @@ namespace {
 struct writer {
     FILE* f;
     void raw(void const* p, size_t n) {
-        if (n && fwrite(p, 1, n, f) != n) throw std::runtime_error("write error");
+        if (n && fwrite(p, 1, n, f) != n) throw error(error_kind::io, "write error");
     }
     void u64(uint64_t v) { raw(&v, 8); }
     template <typename T>
@@ -590,7 +590,7 @@ struct writer {
 struct reader {
     FILE* f;
     void raw(void* p, size_t n) {
-        if (n && fread(p, 1, n, f) != n) throw std::runtime_error("index file truncated");
+        if (n && fread(p, 1, n, f) != n) throw error(error_kind::format, "index file truncated");
     }
     uint64_t u64() {
         uint64_t v;
@@ -600,7 +600,7 @@ struct reader {
     template <typename T>
     void vec(std::vector<T>& v) {
         const uint64_t n = u64();
-        if (n > (uint64_t(1) << 40)) throw std::runtime_error("index file corrupt");
+        if (n > (uint64_t(1) << 40)) throw error(error_kind::format, "index file corrupt");
         v.resize(n);
         raw(v.data(), n * sizeof(T));
         const size_t pad = (8 - (n * sizeof(T)) % 8) % 8;
@@ -612,7 +612,7 @@ struct reader {
         p.width = uint32_t(u64());
         vec(p.words);
         if (p.width < 1 || p.width > 64 || p.words.size() < (p.size * p.width + 63) / 64 + 1)
-            throw std::runtime_error("index file corrupt (packed vector)");
+            throw error(error_kind::format, "index file corrupt (packed vector)");
     }
     void mphf(mphf_host& m) {
         m.seed = u64();
@@ -628,7 +628,7 @@ const char FILE_MAGIC[8] = {'S', 'S', 'H', 'A', 'M', 'D', 2, 0};
 
 void save_index(host_index const& idx, std::string const& filename) {
     FILE* f = fopen(filename.c_str(), "wb");
-    if (!f) throw std::runtime_error("cannot open '" + filename + "' for writing");
+    if (!f) throw error(error_kind::io, "cannot open '" + filename + "' for writing");
     try {
         writer w{f};
         w.raw(FILE_MAGIC, 8);
@@ -663,17 +663,17 @@ void save_index(host_index const& idx, std::string const& filename) {
 
 void load_index(host_index& idx, std::string const& filename) {
     FILE* f = fopen(filename.c_str(), "rb");
-    if (!f) throw std::runtime_error("error in opening the file '" + filename + "'");
+    if (!f) throw error(error_kind::io, "error in opening the file '" + filename + "'");
     try {
         reader r{f};
         idx = host_index();
         char magic[8];
         r.raw(magic, 8);
-        if (memcmp(magic, FILE_MAGIC, 8) != 0) throw std::runtime_error("not an sshash_amd index file");
+        if (memcmp(magic, FILE_MAGIC, 8) != 0) throw error(error_kind::format, "not an sshash_amd index file");
         uint8_t hdr[4];
         r.raw(hdr, 4);
         /* util::check_version_number, include/util.hpp:191-195 */
-        if (hdr[0] != 5) throw std::runtime_error("MAJOR index version mismatch: SSHash index needs rebuilding");
+        if (hdr[0] != 5) throw error(error_kind::version, "MAJOR index version mismatch: SSHash index needs rebuilding");
         idx.version[0] = hdr[0];
         idx.version[1] = hdr[1];
         idx.version[2] = hdr[2];
@@ -684,7 +684,7 @@ void load_index(host_index& idx, std::string const& filename) {
         idx.m = kms[1];
         idx.skew_num_partitions = kms[2];
         if (idx.k < 1 || idx.k > 63 || idx.m < 1 || idx.m > 31 || idx.m > idx.k || idx.skew_num_partitions > 8)
-            throw std::runtime_error("index file corrupt (header)");
+            throw error(error_kind::format, "index file corrupt (header)");
         idx.num_kmers = r.u64();
         idx.num_strings = r.u64();
         idx.num_bases = r.u64();
@@ -695,7 +695,7 @@ void load_index(host_index& idx, std::string const& filename) {
             const uint64_t sh = r.u64();
             idx.num_shards = uint32_t(sh);
             idx.shard_id = uint32_t(sh >> 32);
-            if (idx.num_shards == 0 || idx.shard_id >= idx.num_shards) throw std::runtime_error("index file corrupt (shard)");
+            if (idx.num_shards == 0 || idx.shard_id >= idx.num_shards) throw error(error_kind::format, "index file corrupt (shard)");
         }
         r.vec(idx.strings);
         r.vec(idx.endpoints);
@@ -709,9 +709,9 @@ void load_index(host_index& idx, std::string const& filename) {
         }
         r.packed(idx.heavy_load_buckets);
         if (idx.endpoints.size() != idx.num_strings + 1 || idx.begin_buckets_of_size.size() != MAX_BUCKET_SMALL + 1)
-            throw std::runtime_error("index file corrupt (sizes)");
+            throw error(error_kind::format, "index file corrupt (sizes)");
         char extra;
-        if (fread(&extra, 1, 1, f) != 0) throw std::runtime_error("index file has trailing bytes");
+        if (fread(&extra, 1, 1, f) != 0) throw error(error_kind::format, "index file has trailing bytes");
     } catch (...) {
         fclose(f);
         throw;

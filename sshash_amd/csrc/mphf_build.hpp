@@ -13,6 +13,7 @@
 #include <thread>
 #include <vector>
 
+#include "errors.hpp"
 #include "mphf.hpp"
 
 namespace sshash_amd {
@@ -199,7 +200,7 @@ inline void parallel_ranges(uint64_t n, uint32_t num_threads, Fn&& fn) {
 }  // namespace detail
 
 /* Build over `n` keys; `hash_of(i)` returns the 128-bit base hash of key i under `seed`.
-   Throws std::runtime_error when a partition cannot be completed (caller re-seeds). */
+   Throws error(build) when a partition cannot be completed (caller re-seeds). */
 template <typename HashOf>
 inline void mphf_build_once(mphf_host& f, uint64_t n, HashOf&& hash_of, mphf_build_config const& cfg) {
     f = mphf_host();
@@ -224,8 +225,8 @@ inline void mphf_build_once(mphf_host& f, uint64_t n, HashOf&& hash_of, mphf_bui
         for (uint32_t p = 0; p < P; ++p) {
             uint64_t c = 0;
             for (auto& v : counts) c += v[p];
-            if (c >= (uint64_t(1) << 31)) throw std::runtime_error("mphf: partition too large");
-            if (c == 0 && n != 0) throw std::runtime_error("mphf: empty partition");
+            if (c >= (uint64_t(1) << 31)) throw error(error_kind::build, "mphf: partition too large");
+            if (c == 0 && n != 0) throw error(error_kind::build, "mphf: empty partition");
             f.parts[p].num_keys = uint32_t(c);
         }
     }
@@ -267,7 +268,7 @@ inline void mphf_build_once(mphf_host& f, uint64_t n, HashOf&& hash_of, mphf_bui
     });
     uint32_t max_pilot = 0;
     for (auto& r : results) {
-        if (!r.ok) throw std::runtime_error("mphf: pilot search failed");
+        if (!r.ok) throw error(error_kind::build, "mphf: pilot search failed");
         max_pilot = std::max(max_pilot, r.max_pilot);
     }
     f.pilot_width = bits_for(max_pilot);
@@ -289,9 +290,9 @@ inline void mphf_build(mphf_host& f, uint64_t n, MakeHashOf&& make_hash_of, mphf
         try {
             mphf_build_once(f, n, make_hash_of(cfg.seed), cfg);
             return;
-        } catch (std::runtime_error const&) { cfg.seed += 0x9E3779B97F4A7C15ULL; }
+        } catch (error const&) { cfg.seed += 0x9E3779B97F4A7C15ULL; }
     }
-    throw std::runtime_error("mphf: construction failed after 16 seeds");
+    throw error(error_kind::build, "mphf: construction failed after 16 seeds");
 }
 
 }  // namespace sshash_amd

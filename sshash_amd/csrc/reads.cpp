@@ -1,6 +1,8 @@
 // reads.cpp -- see reads.hpp.
 #include "reads.hpp"
 
+#include "errors.hpp"
+
 #include <zlib.h>
 
 #include <cstring>
@@ -20,7 +22,7 @@ struct line_reader {
     std::vector<char> buf;
     explicit line_reader(std::string const& filename) : buf(1 << 16) {
         f = gzopen(filename.c_str(), "rb");
-        if (!f) throw std::runtime_error("error in opening the file '" + filename + "'");
+        if (!f) throw error(error_kind::io, "error in opening the file '" + filename + "'");
         gzbuffer(f, 1 << 20);
     }
     ~line_reader() { gzclose(f); }

@@ -15,7 +15,7 @@
 namespace sshash_amd {
 
 inline void hip_check(hipError_t e, char const* what) {
-    if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+    if (e != hipSuccess) throw error(error_kind::hip, std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
 }
 #define HIP_CHECK(x) ::sshash_amd::hip_check((x), #x)
 
@@ -57,6 +57,15 @@ struct device_replica {
             slot.second = want;
         }
         return slot.first;
+    }
+
+    /* a stream that is about to be destroyed gives its scratch back (the caller has synchronised it) */
+    void scratch_release(void* stream) const {
+        std::lock_guard<std::mutex> lock(scratch_mutex);
+        auto it = scratch.find(stream);
+        if (it == scratch.end()) return;
+        if (it->second.first) (void)hipFree(it->second.first);
+        scratch.erase(it);
     }
 
     template <typename T>

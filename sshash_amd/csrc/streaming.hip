@@ -14,6 +14,7 @@
 // Output: the six counters of streaming_query_report (include/util.hpp:21-36).
 #include <hip/hip_runtime.h>
 
+#include <exception>
 #include <stdexcept>
 #include <thread>
 
@@ -164,9 +165,9 @@ streaming_report engine::streaming_query_host(char const* bases, uint64_t const*
     streaming_report total;
     if (n_reads == 0) return total;
     const std::vector<int> devs = devices();
-    if (devs.empty()) throw std::runtime_error("dictionary is not resident on any device (call sshash_to_device first)");
+    if (devs.empty()) throw error(error_kind::no_device, "dictionary is not resident on any device (call sshash_to_device first)");
     const uint64_t G = devs.size();
-    std::vector<std::string> errors(G);
+    std::vector<std::exception_ptr> errors(G);
     std::vector<streaming_report> partial(G);
     std::vector<std::thread> workers;
     for (uint64_t g = 0; g < G; ++g) {
@@ -212,12 +213,12 @@ streaming_report engine::streaming_query_host(char const* bases, uint64_t const*
                 partial[g].num_invalid_kmers = h[3];
                 partial[g].num_searches = h[4];
                 partial[g].num_extensions = h[5];
-            } catch (std::exception const& e) { errors[g] = e.what(); }
+            } catch (...) { errors[g] = std::current_exception(); }
         });
     }
     for (auto& w : workers) w.join();
     for (auto const& e : errors)
-        if (!e.empty()) throw std::runtime_error(e);
+        if (e) std::rethrow_exception(e);
     for (auto const& p : partial) {
         total.num_kmers += p.num_kmers;
         total.num_positive_kmers += p.num_positive_kmers;
