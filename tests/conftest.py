@@ -172,4 +172,12 @@ def case_small_k(tmp_session):
     return Case("small_k", skewed_sequences(15, 7, seed=13, n_heavy=80, n_plain=40), 15, 7, False, tmp_session)
 
 
-ALL_SMALL_CASES = ["case_skew_regular", "case_skew_canonical", "case_k63_canonical", "case_small_k"]
+@pytest.fixture(scope="session")
+def case_m_equals_k(tmp_session):
+    """m == k: one m-mer per k-mer, the minimizer IS the k-mer (every bucket a singleton)."""
+    rng = np.random.default_rng(21)
+    seqs = [random_dna(rng, int(rng.integers(21, 200))) for _ in range(150)] + [random_dna(rng, 21)]
+    return Case("m_equals_k", seqs, 21, 21, True, tmp_session)
+
+
+ALL_SMALL_CASES = ["case_skew_regular", "case_skew_canonical", "case_k63_canonical", "case_small_k", "case_m_equals_k"]

@@ -252,3 +252,40 @@ def test_batch_larger_than_one_launch_piece(case_se_regular):
     sample = np.concatenate([np.arange(0, n, 997), np.arange((1 << 27) - 3000, (1 << 27) + 3000)])
     assert (got[sample] == case.oracle.lookup_ids(q[sample])).all()
     assert int((got == np.uint64(0xFFFFFFFFFFFFFFFD)).sum()) == 0  # nothing left unwritten
+
+
+def test_mphf_path_without_directory(tmp_path):
+    """SSHASH_AMD_DIRECTORY=0 (also what a dictionary with codewords wider than 40 bits gets): the
+    single-kernel MPHF path must give the same ids / membership as the oracle."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    from conftest import ROOT
+
+    script = tmp_path / "nodir.py"
+    script.write_text(textwrap.dedent(
+        """
+        import os, sys, tempfile
+        import numpy as np
+        sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+        import conftest as c
+        import sshash_amd
+        with tempfile.TemporaryDirectory() as tmp:
+            for canonical, seed in ((False, 3), (True, 5)):
+                case = c.Case("nodir%d" % seed, c.skewed_sequences(31, 11, seed=seed), 31, 11, canonical, tmp)
+                d = case.dict.to_device(0)
+                assert d.device_stats()["directory_sectors"] == 0
+                q = case.queries(4000, 4000, seed=1)
+                want = case.oracle.lookup_ids(q)
+                assert (d.lookup(q).kmer_id == want).all()
+                assert (d.is_member(q) == (want != np.uint64(0xFFFFFFFFFFFFFFFF))).all()
+                n = case.gt.num_kmers
+                allq = case.gt.kmers(np.arange(n))
+                assert (d.lookup(allq).kmer_id == np.arange(n, dtype=np.uint64)).all()
+        print("NODIR OK")
+        """))
+    p = subprocess.run([sys.executable, str(script), ROOT], env=dict(os.environ, SSHASH_AMD_DIRECTORY="0"), capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and "NODIR OK" in p.stdout, p.stdout + p.stderr
