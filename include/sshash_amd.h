@@ -110,8 +110,9 @@ sshash_status sshash_get_info(const sshash_dict* d, sshash_info* info);
 int sshash_device_count(void);
 sshash_status sshash_to_device(sshash_dict* d, int device);
 sshash_status sshash_device_bytes(const sshash_dict* d, int device, uint64_t* bytes);
-/* out = {bytes in HBM, minimizer-directory sectors (0 = disabled), sectors flagged overflow, keys in the directory} */
-sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out[4]);
+/* out = {bytes in HBM, minimizer-directory sectors (0 = disabled), sectors flagged overflow, keys in the directory,
+ *        super-k-mer table slots (0 = disabled), its keys, keys held inline, keys left to the complete path} */
+sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out[8]);
 
 /* ---- dictionary::lookup(Kmer, bool) / lookup(char const*, bool): include/dictionary.hpp:41-42,
  *      src/dictionary.cpp:58-78. Batched. ------------------------------------------------------

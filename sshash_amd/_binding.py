@@ -136,7 +136,7 @@ def _load() -> C.CDLL:
         "sshash_device_count": (C.c_int, []),
         "sshash_to_device": (C.c_int, [P, C.c_int]),
         "sshash_device_bytes": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64)]),
-        "sshash_device_stats": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64 * 4)]),
+        "sshash_device_stats": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64 * 8)]),
         "sshash_lookup_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
         "sshash_lookup_ascii_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
         "sshash_lookup_packed": (C.c_int, [P, P, C.c_uint64, C.c_int, C.POINTER(_Results)]),
@@ -313,10 +313,11 @@ class Dictionary:
         return int(out.value)
 
     def device_stats(self, device: int = 0) -> dict:
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         _check(_load().sshash_device_stats(self._h, int(device), C.byref(out)))
         return {"bytes": int(out[0]), "directory_sectors": int(out[1]), "directory_overflow_sectors": int(out[2]),
-                "directory_keys": int(out[3])}
+                "directory_keys": int(out[3]), "sk_slots": int(out[4]), "sk_keys": int(out[5]), "sk_inline_keys": int(out[6]),
+                "sk_deferred_keys": int(out[7])}
 
     # ---- lookups ---------------------------------------------------------------------------
     def _as_batch(self, kmers: KmerBatch):

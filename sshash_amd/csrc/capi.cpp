@@ -172,7 +172,7 @@ sshash_status sshash_device_bytes(const sshash_dict* d, int device, uint64_t* by
     return guarded([&] { *bytes = d->eng->device_bytes(device); });
 }
 
-sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out[4]) {
+sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out[8]) {
     if (!d || !out) return fail(SSHASH_ERR_ARGUMENT, "null argument");
     return guarded([&] { d->eng->device_stats(device, out); });
 }

@@ -51,6 +51,32 @@
 //      minimizer the reference's `minimizer_found` flag depends on which (arbitrary) bucket the
 //      MPHF lands on. Built on the GPU at upload; SSHASH_AMD_DIRECTORY=0 disables it.
 //
+//  (5) k <= 31: a *super-k-mer table*, built on the GPU at upload from the strings alone. Structures
+//      (1)-(4) answer a positive lookup with two dependent random reads per probe (minimizer ->
+//      position, then the strings) and a regular index probes both strands (src/dictionary.cpp:70-75);
+//      what bounds the batch is the number of such reads. The table answers most lookups with ONE:
+//        key    the strand-symmetric minimizer of a k-mer: the smaller-valued of the minimizers of x and
+//               of its reverse complement (equal values = tie, left to the structures above) -- one key
+//               for both strands, whatever the dictionary's own minimizer flavour;
+//        slot   32 bytes, 32-byte aligned; a key lives in one of three hashed slots (first free one
+//               wins, 2.5 slots per key):
+//                 d0  bit0 valid | bit1 list | bit2 strand | bit3 go-on-to-2nd | bit4 go-on-to-3rd |
+//                     bit5 unplaced-key-here | bits 8-13 left | bits 14-19 right
+//                 d1  string id (inline) or number of occurrences (list; 0 = too long, defer)
+//                 d2,d3  position of the minimizer occurrence / list begin (40 bits) | fingerprint << 40
+//                 d4-d7  inline: the 64 bases starting k-m bases before the occurrence, i.e. every k-mer
+//                        of the super-k-mer; list of <= 2: the occurrences themselves
+//               A key with exactly one occurrence in the strings (~90 % of the k-mers) is *inline*: the
+//               slot holds the super-k-mer, how far it may extend inside its string (left/right), and the
+//               string id, so the lookup ends at the slot. Other keys carry a list of occurrences
+//               ((position << 1) | strand, in `occ`), scanned through the atoms of (1).
+//        flags  bit3/bit4 say "a key hashed here lives further along its slot sequence"; a probe that
+//               finds neither its k-mer nor such a flag is a final miss -- negative queries end after
+//               ~1.1 reads. bit5 (a key that found no slot), over-long lists and ties send the query
+//               to the complete path through (3)/(4).
+//      Ids are positions in the strings, so results are identical to the reference's; the table only
+//      changes how many reads it takes to find the position. SSHASH_AMD_SKTABLE=0 disables it.
+//
 // The remaining packed vectors (bucket offset lists, pilots, skew positions) keep their bit-packed
 // form: one 8-byte read, sometimes two adjacent ones.
 #pragma once
@@ -111,6 +137,40 @@ SSH_HD uint32_t directory_bucket(uint64_t h, uint32_t num_buckets) { return mulh
 SSH_HD uint32_t directory_fingerprint(uint64_t h) { return uint32_t(h) & 0xFFFFu; }
 SSH_HD uint64_t directory_entry(uint64_t code, uint32_t fp) { return code | (uint64_t(fp) << 40) | (uint64_t(1) << 56); }
 
+/* ---- super-k-mer table (5) ---- */
+constexpr uint32_t SK_VALID = 1u, SK_LIST = 2u, SK_STRAND = 4u, SK_GO2 = 8u, SK_GO3 = 16u, SK_UNPLACED = 32u;
+constexpr uint32_t SK_LEFT_SHIFT = 8, SK_RIGHT_SHIFT = 14;
+constexpr uint32_t SK_LIST_MAX = 64;          // longer occurrence lists are left to the complete path
+constexpr double SK_SLOTS_PER_KEY = 2.5;
+constexpr uint32_t SK_CHOICES = 3;
+
+struct sk_view {
+    void const* slots;    // num_slots x 32 bytes
+    uint64_t const* occ;  // occurrences of the list keys: (position << 1) | strand
+    uint32_t num_slots;
+    uint32_t enabled;
+};
+
+struct sk_hash_t {
+    uint32_t slot[SK_CHOICES];
+    uint32_t fingerprint;  // 24 bits
+};
+
+SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_slots) {
+    uint64_t a = key * 0xFF51AFD7ED558CCDULL;
+    a ^= a >> 32;
+    a *= 0xC4CEB9FE1A85EC53ULL;
+    a ^= a >> 29;
+    uint64_t b = (a ^ key) * 0x9E3779B97F4A7C15ULL;
+    b ^= b >> 31;
+    sk_hash_t h;
+    h.slot[0] = mulhi32(uint32_t(a >> 32), num_slots);
+    h.slot[1] = mulhi32(uint32_t(a), num_slots);
+    h.slot[2] = mulhi32(uint32_t(b >> 32), num_slots);
+    h.fingerprint = uint32_t(b) & 0xFFFFFFu;
+    return h;
+}
+
 struct dict_view {
     uint32_t k, m;
     uint32_t canonical;
@@ -130,6 +190,7 @@ struct dict_view {
     uint64_t const* heavy_load;
     uint64_t heavy_size;
     directory_view directory;
+    sk_view sk;
 
     mphf_view skew_f[8];
     uint64_t const* skew_pos[8];

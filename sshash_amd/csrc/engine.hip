@@ -11,6 +11,7 @@
 
 #include "engine.hpp"
 #include "replica.hpp"
+#include "sktable.hpp"
 
 namespace sshash_amd {
 
@@ -161,12 +162,16 @@ std::vector<int> engine::devices() const {
 
 uint64_t engine::device_bytes(int device) const { return replica(device)->bytes; }
 
-void engine::device_stats(int device, uint64_t out[4]) const {
+void engine::device_stats(int device, uint64_t out[8]) const {
     device_replica const* r = replica(device);
     out[0] = r->bytes;
     out[1] = r->view.directory.enabled ? r->view.directory.num_buckets : 0;
     out[2] = r->directory_overflowed;
     out[3] = r->directory_entries;
+    out[4] = r->view.sk.enabled ? r->view.sk.num_slots : 0;
+    out[5] = r->sk_keys;
+    out[6] = r->sk_inline_keys;
+    out[7] = r->sk_long_lists + r->sk_unplaced;
 }
 
 device_replica const* engine::replica(int device) const {
@@ -292,6 +297,7 @@ void engine::to_device(int device) {
         }
     }
     rep->d_skew = rep->put(skew);
+    build_sk_table(*rep, idx);
     m_replicas.push_back(std::move(rep));
 }
 
@@ -338,8 +344,9 @@ __device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries
 }
 
 /* Phase 1 of the two-phase lookup (lookup_device.hpp): one query per lane, common case only. Queries it
-   cannot settle are appended to `queue` (their index in the batch). MODE: ids or member. */
-template <int W, bool CANON, int MODE, bool ASCII>
+   cannot settle are appended to `queue` (their index in the batch). SK: through the super-k-mer table
+   (device_layout.hpp (5)) instead of directory + atoms. */
+template <int W, bool CANON, int MODE, bool ASCII, bool SK>
 __global__ void __launch_bounds__(256)
 fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const uint64_t n, const bool check_rc,
                    const result_view out, uint8_t* __restrict__ member, uint32_t* __restrict__ queue,
@@ -383,7 +390,9 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
         if (i >= n) return;
         x = load_query<W, false>(queries, i, d.k);
     }
-    const fast_t r = fast_lookup_one<W, CANON>(d, x, check_rc);
+    fast_t r;
+    if constexpr (SK) r = sk_lookup_one(d, x, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1));
+    else r = fast_lookup_one<W, CANON>(d, x, check_rc);
     /* every lane stores first (a deferred lane's value is a placeholder that phase 2 overwrites), the
        queue push comes last: no lane leaves the wave between the probe and its store */
     if constexpr (MODE == int(out_mode::member)) {
@@ -450,7 +459,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
        for an absent minimizer the reference's flag depends on which (arbitrary) bucket the MPHF lands
        on, so only the MPHF path can reproduce it (device_layout.hpp (4)). */
     {
-        if (d.directory.enabled && !(MODE == int(out_mode::full) && out.minimizer_found)) {
+        if ((d.directory.enabled || d.sk.enabled) && !(MODE == int(out_mode::full) && out.minimizer_found)) {
             /* two-phase: at most 2^27 queries per launch pair (queue indices are 32-bit; the scratch
                queue stays at 0.5 GiB) */
             const uint64_t piece = uint64_t(1) << 27;
@@ -465,8 +474,17 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 const void* qa = static_cast<const char*>(q) + at * (ASCII ? kbytes : qbytes);
                 const result_view ids = advance(out, at);
                 uint8_t* mem = member ? member + at : nullptr;
-                hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII>), dim3(nblocks), dim3(block), 0, stream, d, qa, m,
-                                   check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
+                bool through_table = false;
+                if constexpr (W == 1) {
+                    if (d.sk.enabled) {
+                        through_table = true;
+                        hipLaunchKernelGGL((fast_lookup_kernel<1, CANON, MODE, ASCII, true>), dim3(nblocks), dim3(block), 0, stream, d, qa,
+                                           m, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
+                    }
+                }
+                if (!through_table)
+                    hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII, false>), dim3(nblocks), dim3(block), 0, stream, d, qa,
+                                       m, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
                 hipLaunchKernelGGL((deferred_lookup_kernel<W, CANON, MODE, ASCII>), dim3(DEFER_SHARDS * DEFER_BLOCKS_PER_SHARD), dim3(block), 0, stream, d,
                                    skew, qa, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
                 HIP_CHECK(hipGetLastError());

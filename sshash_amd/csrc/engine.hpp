@@ -35,8 +35,9 @@ public:
     bool on_device(int device) const;
     std::vector<int> devices() const;
     uint64_t device_bytes(int device) const;
-    /* {bytes in HBM, directory sectors, directory sectors flagged overflow, keys held by the directory} */
-    void device_stats(int device, uint64_t out[4]) const;
+    /* {bytes in HBM, directory sectors, directory sectors flagged overflow, keys held by the directory,
+        super-k-mer table slots (0 = disabled), its keys, its inline keys, its keys left to the complete path} */
+    void device_stats(int device, uint64_t out[8]) const;
 
     /* Device-pointer entry points: queries and outputs already live in the HBM of `device`;
        the launch is asynchronous on `stream` (a hipStream_t, may be null = default stream).

@@ -426,6 +426,84 @@ __device__ __forceinline__ fast_t fast_lookup_one(dict_view const& d, kmer_w<W> 
     }
 }
 
+/* ---- lookup through the super-k-mer table (device_layout.hpp (5)), k <= 31 ----------------------
+   Same contract as fast_lookup_one: HIT / final MISS / DEFER to the complete path. `allow_rc` false
+   (regular dictionary, check_reverse_complement off: src/dictionary.cpp:70-71) turns a hit on the other
+   strand into a miss. `miss_orientation`: what a miss reports (-1 after a regular dictionary's
+   reverse-complement probe, src/dictionary.cpp:74-75). */
+__device__ __forceinline__ fast_t sk_lookup_one(dict_view const& d, kmer_w<1> const& x, bool allow_rc, int8_t miss_orientation) {
+    const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
+    const minimizer_t mf = compute_minimizer<1>(x, d.k, d.m, d.hash_magic);
+    const minimizer_t mr = compute_minimizer<1>(x_rc, d.k, d.m, d.hash_magic);
+    if (mf.value == mr.value) return fast_unsettled(true);  // tie: no strand-symmetric key
+    const bool s = mr.value < mf.value;                     // the key was read on the reverse complement of x
+    const uint64_t key = s ? mr.value : mf.value;
+    const uint32_t j = s ? mr.pos : mf.pos;                 // where the key starts in y
+    const uint64_t y = s ? x_rc.w[0] : x.w[0], y_rc = s ? x.w[0] : x_rc.w[0];
+    const uint32_t km = d.k - d.m;
+    const uint64_t kmask = low_mask(2 * d.k);
+    const sk_hash_t h = sk_hash(key, d.sk.num_slots);
+    fast_t r = fast_unsettled(false);
+    r.orientation = miss_orientation;
+#pragma unroll 1
+    for (uint32_t c = 0; c < SK_CHOICES; ++c) {
+        const uint4* S = reinterpret_cast<const uint4*>(d.sk.slots) + 2 * uint64_t(h.slot[c]);
+        const uint4 q0 = S[0], q1 = S[1];
+        uint32_t meta = q0.x;
+        asm volatile("" : "+v"(meta));  // keep the flags in their own register across the list scan
+        if (meta & SK_VALID) {
+            const uint64_t at = uint64_t(q0.z) | (uint64_t(q0.w & 0xFFu) << 32);
+            if (!(meta & SK_LIST)) {
+                /* inline super-k-mer: the strings read the key forward (strand 0: y aligns, key at km - a)
+                   or reverse-complemented (strand 1: rc(y) aligns, its copy of the key sits at km - j) */
+                const bool o = (meta & SK_STRAND) != 0;
+                const uint32_t a = o ? j : km - j;
+                const uint64_t lo = uint64_t(q1.x) | (uint64_t(q1.y) << 32), hi = uint64_t(q1.z) | (uint64_t(q1.w) << 32);
+                const uint64_t cand = funnel_shr(lo, hi, 2 * a) & kmask;
+                const uint32_t left = (meta >> SK_LEFT_SHIFT) & 63u, right = (meta >> SK_RIGHT_SHIFT) & 63u;
+                if (cand == (o ? y_rc : y) && a + left >= km && a <= right) {
+                    r.kmer_offset = at + a - km;
+                    r.string_id = q0.y;
+                    r.orientation = (o != s) ? -1 : 1;
+                    r.outcome = FAST_HIT;
+                    break;
+                }
+            } else if ((q0.w >> 8) == h.fingerprint) {
+                const uint32_t size = q0.y;
+                if (size == 0) return fast_unsettled(true);  // list longer than SK_LIST_MAX
+                bool hit = false;
+                for (uint32_t t = 0; t < size; ++t) {
+                    uint64_t v;
+                    if (size <= 2) v = t == 0 ? (uint64_t(q1.x) | (uint64_t(q1.y) << 32)) : (uint64_t(q1.z) | (uint64_t(q1.w) << 32));
+                    else v = d.sk.occ[at + t];
+                    const bool o = (v & 1) != 0;
+                    const uint64_t p = v >> 1;
+                    const uint32_t a = o ? j : km - j;
+                    if (p + a < km) continue;
+                    const window_t<1> w = read_window<1>(d.granules, p + a - km, d.k);
+                    if (w.kmer.w[0] == (o ? y_rc : y) && !w.crosses) {
+                        r.kmer_offset = p + a - km;
+                        r.string_id = w.string_id;
+                        r.orientation = (o != s) ? -1 : 1;
+                        r.outcome = FAST_HIT;
+                        hit = true;
+                        break;
+                    }
+                }
+                if (hit) break;
+            }
+        }
+        const uint32_t go = c == 0 ? SK_GO2 : (c == 1 ? SK_GO3 : SK_UNPLACED);
+        if (!(meta & go)) break;                       // nobody who hashed here lives elsewhere: final miss
+        if (c + 1 == SK_CHOICES) return fast_unsettled(true);  // a key that found no slot: complete path
+    }
+    if (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc) {
+        r = fast_unsettled(false);
+        r.orientation = miss_orientation;
+    }
+    return r;
+}
+
 /* hit -> lookup_result fields (include/offsets.hpp:138-154, spss.hpp:226-228) */
 template <bool FULL>
 __device__ __forceinline__ void store_result(dict_view const& d, result_view const& out, uint64_t i, hit_t const& h) {

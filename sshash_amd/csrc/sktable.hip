@@ -1,0 +1,293 @@
+// sktable.hip -- construction of the super-k-mer table (device_layout.hpp (5)) on the GPU, at upload.
+//
+// Input: the atoms of (1) and the endpoints, already resident. Nothing of the host index's own
+// minimizer structures is used: the table is keyed by strand-symmetric minimizers recomputed from
+// the strings, so it serves regular and canonical dictionaries alike.
+//
+//   1. scan     one lane per k-mer start: the k-mer's key occurrence (key, position, strand); a lane
+//               whose occurrence differs from its left neighbour's starts a super-k-mer and emits one
+//               tuple. Two passes (count, exclusive scan, emit) keep the tuples in string order.
+//   2. sort     stable radix sort of the tuples by key (hipCUB), run-length encode -> one run per key.
+//   3. place    three rounds, one per hashed slot choice: a key claims its slot with a CAS on the slot's
+//               flag word; a key that loses sets the slot's "go on" flag and waits for the next round.
+//   4. fill     the winner writes its slot: the 64 bases around a single occurrence, how far the
+//               super-k-mer may extend inside its string, the string id -- or the occurrence list.
+#include <hip/hip_runtime.h>
+
+#include <hipcub/hipcub.hpp>
+
+#include <cstdlib>
+
+#include "replica.hpp"
+#include "sktable.hpp"
+
+namespace sshash_amd {
+
+namespace {
+
+constexpr uint32_t WAVE = 64;
+constexpr uint32_t NEW_PER_WAVE = WAVE - 1;  // lane 0 only supplies its right neighbour's "previous"
+
+template <bool EMIT>
+__global__ void __launch_bounds__(256)
+sk_scan_kernel(const dict_view d, const uint64_t num_waves, uint32_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
+               uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+    const uint64_t gtid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t wave = gtid / WAVE;
+    const uint32_t lane = uint32_t(gtid % WAVE);
+    if (wave >= num_waves) return;  // whole waves only: the grid is sized in waves
+    const int64_t i = int64_t(wave * NEW_PER_WAVE + lane) - 1;
+    uint64_t key = INVALID_U64, val = INVALID_U64;
+    if (i >= 0 && uint64_t(i) + d.k <= d.num_bases) {
+        const window_t<1> w = read_window<1>(d.granules, uint64_t(i), d.k);
+        if (!w.crosses) {
+            const kmer_w<1> x = w.kmer;
+            const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
+            const minimizer_t mf = compute_minimizer<1>(x, d.k, d.m, d.hash_magic);
+            const minimizer_t mr = compute_minimizer<1>(x_rc, d.k, d.m, d.hash_magic);
+            if (mf.value != mr.value) {
+                const bool s = mr.value < mf.value;
+                key = s ? mr.value : mf.value;
+                const uint64_t p = uint64_t(i) + (s ? (d.k - d.m) - mr.pos : mf.pos);
+                val = (p << 1) | (s ? 1u : 0u);
+            }
+        }
+    }
+    const uint64_t prev_key = __shfl_up(key, 1), prev_val = __shfl_up(val, 1);
+    const bool start = lane > 0 && key != INVALID_U64 && (key != prev_key || val != prev_val);
+    const uint64_t ballot = __ballot(start);
+    if constexpr (!EMIT) {
+        if (lane == 0) counts[wave] = uint32_t(__popcll(ballot));
+    } else {
+        if (start) {
+            const uint64_t at = offsets[wave] + uint64_t(__popcll(ballot & ((uint64_t(1) << lane) - 1)));
+            keys[at] = key;
+            vals[at] = val;
+        }
+    }
+}
+
+/* 64 bases starting at base `pos` (pos may be negative: the missing bases read as zero) */
+__device__ __forceinline__ void read_bases64(void const* __restrict__ atoms, int64_t pos, uint64_t& lo, uint64_t& hi) {
+    const uint64_t from = pos < 0 ? 0 : uint64_t(pos);
+    const uint4* A = reinterpret_cast<const uint4*>(atoms) + 2 * (from >> 5);
+    const uint32_t r = uint32_t(from) & 31u;
+    const uint4 a0 = A[0], a1 = A[2];  // bases of atom `from/32` and of the next atom
+    const uint64_t b0 = uint64_t(a0.x) | (uint64_t(a0.y) << 32), b1 = uint64_t(a0.z) | (uint64_t(a0.w) << 32);
+    const uint64_t b2 = uint64_t(a1.z) | (uint64_t(a1.w) << 32);
+    lo = funnel_shr(b0, b1, 2 * r);
+    hi = funnel_shr(b1, b2, 2 * r);
+    if (pos < 0) {
+        const uint32_t sh = 2 * uint32_t(-pos);  // 2..60
+        hi = (hi << sh) | (lo >> (64 - sh));
+        lo <<= sh;
+    }
+}
+
+/* One lane per key (run of the sorted tuples), one launch per slot choice. */
+__global__ void __launch_bounds__(256)
+sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_keys, const uint64_t* __restrict__ keys,
+                const uint32_t* __restrict__ run_sizes, const uint32_t* __restrict__ run_begins, const uint64_t* __restrict__ occ,
+                uint32_t* __restrict__ slots, const uint32_t num_slots, uint8_t* __restrict__ placed,
+                unsigned long long* __restrict__ stats) {
+    const uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r >= num_keys || placed[r]) return;
+    const uint64_t key = keys[r];
+    const sk_hash_t h = sk_hash(key, num_slots);
+    uint32_t* S = slots + 8 * uint64_t(h.slot[choice]);
+    /* claim: set the valid bit unless somebody holds it (other lanes may be OR-ing flags into the same word) */
+    uint32_t cur = __hip_atomic_load(S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool mine = false;
+    while (!(cur & SK_VALID)) {
+        const uint32_t seen = atomicCAS(S, cur, cur | SK_VALID);
+        if (seen == cur) {
+            mine = true;
+            break;
+        }
+        cur = seen;
+    }
+    if (!mine) {
+        atomicOr(S, choice == 0 ? SK_GO2 : (choice == 1 ? SK_GO3 : SK_UNPLACED));
+        if (choice + 1 == SK_CHOICES) atomicAdd(stats + 2, 1ull);  // unplaced keys
+        return;
+    }
+    placed[r] = 1;
+    const uint32_t size = run_sizes[r];
+    const uint64_t begin = run_begins[r];
+    uint32_t meta = 0;
+    uint32_t d1;
+    uint64_t w1, w2, w3;
+    if (size == 1) {
+        const uint64_t v = occ[begin];
+        const uint64_t p = v >> 1;
+        const uint32_t km = d.k - d.m;
+        const uint32_t sid = read_window<1>(d.granules, p, 1).string_id;
+        const uint64_t s_begin = d.endpoints[sid], s_end = d.endpoints[sid + 1];
+        const uint64_t left = p - s_begin < km ? p - s_begin : km;
+        const uint64_t right = s_end - (p + d.m) < km ? s_end - (p + d.m) : km;
+        meta = (uint32_t(v & 1) ? SK_STRAND : 0u) | (uint32_t(left) << SK_LEFT_SHIFT) | (uint32_t(right) << SK_RIGHT_SHIFT);
+        d1 = sid;
+        w1 = p;
+        read_bases64(d.granules, int64_t(p) - int64_t(km), w2, w3);
+        atomicAdd(stats + 0, 1ull);  // inline keys
+    } else {
+        meta = SK_LIST;
+        d1 = size <= SK_LIST_MAX ? size : 0u;
+        w1 = begin | (uint64_t(h.fingerprint) << 40);
+        w2 = size <= 2 ? occ[begin] : 0;
+        w3 = size == 2 ? occ[begin + 1] : 0;
+        if (size > SK_LIST_MAX) atomicAdd(stats + 1, 1ull);  // keys whose list is left to the complete path
+    }
+    S[1] = d1;
+    reinterpret_cast<uint64_t*>(S)[1] = w1;
+    reinterpret_cast<uint64_t*>(S)[2] = w2;
+    reinterpret_cast<uint64_t*>(S)[3] = w3;
+    if (meta) atomicOr(S, meta);
+}
+
+struct temp_buffers {  // freed on every exit path
+    std::vector<void*> owned;
+    template <typename T>
+    T* alloc(uint64_t n) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, std::max<uint64_t>(n, 1) * sizeof(T)));
+        owned.push_back(p);
+        return static_cast<T*>(p);
+    }
+    void release(void* p) {
+        for (auto& q : owned)
+            if (q == p) {
+                (void)hipFree(q);
+                q = nullptr;
+            }
+    }
+    /* hand a buffer over to the replica */
+    void keep(void* p) {
+        for (auto& q : owned)
+            if (q == p) q = nullptr;
+    }
+    ~temp_buffers() {
+        for (void* p : owned)
+            if (p) (void)hipFree(p);
+    }
+};
+
+}  // namespace
+
+void build_sk_table(device_replica& rep, host_index const& idx) {
+    dict_view& v = rep.view;
+    v.sk.slots = nullptr;
+    v.sk.occ = nullptr;
+    v.sk.num_slots = 0;
+    v.sk.enabled = 0;
+    const char* env = std::getenv("SSHASH_AMD_SKTABLE");
+    if (env && env[0] == '0') return;
+    if (idx.k > 31 || idx.num_shards > 1 || idx.num_kmers == 0) return;  // a shard holds only its own minimizers' buckets: keep its path
+    if (idx.num_bases >= (uint64_t(1) << 39)) return;                       // positions are stored in 40 bits with a strand bit
+
+    const uint64_t positions = idx.num_bases - idx.k + 1;
+    const uint64_t num_waves = (positions + 1 + NEW_PER_WAVE - 1) / NEW_PER_WAVE;
+    const uint64_t threads = num_waves * WAVE;
+    const dim3 block(256), grid(uint32_t((threads + 255) / 256));
+    if ((threads + 255) / 256 >= (uint64_t(1) << 31)) return;
+
+    temp_buffers tmp;
+    uint32_t* counts = tmp.alloc<uint32_t>(num_waves);
+    uint64_t* offsets = tmp.alloc<uint64_t>(num_waves + 1);
+    hipLaunchKernelGGL(sk_scan_kernel<false>, grid, block, 0, 0, v, num_waves, counts, nullptr, nullptr, nullptr);
+    HIP_CHECK(hipGetLastError());
+    {
+        /* exclusive scan of the per-wave counts into 64-bit offsets */
+        size_t bytes = 0;
+        auto in = hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, uint32_t*>(counts, hipcub::CastOp<uint64_t>());
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, offsets, int(num_waves)));
+        void* scratch = tmp.alloc<uint8_t>(bytes);
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scratch, bytes, in, offsets, int(num_waves)));
+        tmp.release(scratch);
+    }
+    uint64_t last_offset = 0;
+    uint32_t last_count = 0;
+    HIP_CHECK(hipMemcpy(&last_offset, offsets + (num_waves - 1), 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&last_count, counts + (num_waves - 1), 4, hipMemcpyDeviceToHost));
+    const uint64_t T = last_offset + last_count;  // super-k-mers
+    if (T == 0 || T >= (uint64_t(1) << 31)) return;
+
+    uint64_t* keys = tmp.alloc<uint64_t>(T);
+    uint64_t* vals = tmp.alloc<uint64_t>(T);
+    hipLaunchKernelGGL(sk_scan_kernel<true>, grid, block, 0, 0, v, num_waves, counts, offsets, keys, vals);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+    tmp.release(counts);
+    tmp.release(offsets);
+
+    uint64_t* keys_sorted = tmp.alloc<uint64_t>(T);
+    uint64_t* occ = tmp.alloc<uint64_t>(T);
+    {
+        size_t bytes = 0;
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys_sorted, vals, occ, int(T), 0, int(2 * idx.m)));
+        void* scratch = tmp.alloc<uint8_t>(bytes);
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(scratch, bytes, keys, keys_sorted, vals, occ, int(T), 0, int(2 * idx.m)));
+        HIP_CHECK(hipDeviceSynchronize());
+        tmp.release(scratch);
+    }
+    tmp.release(vals);
+    /* runs of equal keys; `keys` is reused for the distinct keys */
+    uint32_t* run_sizes = tmp.alloc<uint32_t>(T);
+    uint64_t* d_num_runs = tmp.alloc<uint64_t>(1);
+    {
+        size_t bytes = 0;
+        HIP_CHECK(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes, keys_sorted, keys, run_sizes, d_num_runs, int(T)));
+        void* scratch = tmp.alloc<uint8_t>(bytes);
+        HIP_CHECK(hipcub::DeviceRunLengthEncode::Encode(scratch, bytes, keys_sorted, keys, run_sizes, d_num_runs, int(T)));
+        HIP_CHECK(hipDeviceSynchronize());
+        tmp.release(scratch);
+    }
+    tmp.release(keys_sorted);
+    uint64_t K = 0;
+    HIP_CHECK(hipMemcpy(&K, d_num_runs, 8, hipMemcpyDeviceToHost));
+    const uint64_t num_slots = uint64_t(double(K) * SK_SLOTS_PER_KEY) + 16;
+    if (K == 0 || num_slots >= (uint64_t(1) << 32)) return;
+    {
+        size_t free_bytes = 0, total_bytes = 0;
+        HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
+        if (num_slots * 32 + K * 8 > free_bytes / 2) return;  // leave HBM for the caller's batches
+    }
+    uint32_t* run_begins = tmp.alloc<uint32_t>(K);
+    {
+        size_t bytes = 0;
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, run_sizes, run_begins, int(K)));
+        void* scratch = tmp.alloc<uint8_t>(bytes);
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scratch, bytes, run_sizes, run_begins, int(K)));
+        tmp.release(scratch);
+    }
+    uint32_t* slots = tmp.alloc<uint32_t>(num_slots * 8);
+    uint8_t* placed = tmp.alloc<uint8_t>(K);
+    unsigned long long* stats = tmp.alloc<unsigned long long>(4);
+    HIP_CHECK(hipMemset(slots, 0, num_slots * 32));
+    HIP_CHECK(hipMemset(placed, 0, K));
+    HIP_CHECK(hipMemset(stats, 0, 32));
+    for (uint32_t choice = 0; choice < SK_CHOICES; ++choice) {
+        hipLaunchKernelGGL(sk_place_kernel, dim3(uint32_t((K + 255) / 256)), block, 0, 0, v, choice, K, keys, run_sizes, run_begins, occ,
+                           slots, uint32_t(num_slots), placed, stats);
+        HIP_CHECK(hipGetLastError());
+    }
+    unsigned long long h_stats[4];
+    HIP_CHECK(hipMemcpy(h_stats, stats, 32, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipDeviceSynchronize());
+
+    tmp.keep(slots);
+    tmp.keep(occ);
+    rep.allocations.push_back(slots);
+    rep.allocations.push_back(occ);
+    rep.bytes += num_slots * 32 + T * 8;
+    rep.sk_keys = K;
+    rep.sk_inline_keys = h_stats[0];
+    rep.sk_long_lists = h_stats[1];
+    rep.sk_unplaced = h_stats[2];
+    v.sk.slots = slots;
+    v.sk.occ = occ;
+    v.sk.num_slots = uint32_t(num_slots);
+    v.sk.enabled = 1;
+}
+
+}  // namespace sshash_amd

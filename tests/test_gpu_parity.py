@@ -254,9 +254,12 @@ def test_batch_larger_than_one_launch_piece(case_se_regular):
     assert int((got == np.uint64(0xFFFFFFFFFFFFFFFD)).sum()) == 0  # nothing left unwritten
 
 
-def test_mphf_path_without_directory(tmp_path):
-    """SSHASH_AMD_DIRECTORY=0 (also what a dictionary with codewords wider than 40 bits gets): the
-    single-kernel MPHF path must give the same ids / membership as the oracle."""
+@pytest.mark.parametrize("disabled", [("SSHASH_AMD_DIRECTORY", "SSHASH_AMD_SKTABLE"), ("SSHASH_AMD_SKTABLE",), ("SSHASH_AMD_DIRECTORY",)],
+                         ids=["mphf_only", "directory_only", "sktable_over_mphf"])
+def test_accelerators_disabled(tmp_path, disabled):
+    """The lookup structures are layered (device_layout.hpp (3)-(5)): with the super-k-mer table and/or
+    the minimizer directory switched off (also what an over-wide dictionary gets) the remaining path must
+    give the same ids / membership as the oracle."""
     import os
     import subprocess
     import sys
@@ -264,7 +267,7 @@ def test_mphf_path_without_directory(tmp_path):
 
     from conftest import ROOT
 
-    script = tmp_path / "nodir.py"
+    script = tmp_path / "layers.py"
     script.write_text(textwrap.dedent(
         """
         import os, sys, tempfile
@@ -274,9 +277,11 @@ def test_mphf_path_without_directory(tmp_path):
         import sshash_amd
         with tempfile.TemporaryDirectory() as tmp:
             for canonical, seed in ((False, 3), (True, 5)):
-                case = c.Case("nodir%d" % seed, c.skewed_sequences(31, 11, seed=seed), 31, 11, canonical, tmp)
+                case = c.Case("layers%d" % seed, c.skewed_sequences(31, 11, seed=seed), 31, 11, canonical, tmp)
                 d = case.dict.to_device(0)
-                assert d.device_stats()["directory_sectors"] == 0
+                stats = d.device_stats()
+                assert (stats["directory_sectors"] == 0) == (os.environ.get("SSHASH_AMD_DIRECTORY") == "0"), stats
+                assert (stats["sk_slots"] == 0) == (os.environ.get("SSHASH_AMD_SKTABLE") == "0"), stats
                 q = case.queries(4000, 4000, seed=1)
                 want = case.oracle.lookup_ids(q)
                 assert (d.lookup(q).kmer_id == want).all()
@@ -284,8 +289,10 @@ def test_mphf_path_without_directory(tmp_path):
                 n = case.gt.num_kmers
                 allq = case.gt.kmers(np.arange(n))
                 assert (d.lookup(allq).kmer_id == np.arange(n, dtype=np.uint64)).all()
-        print("NODIR OK")
+        print("LAYERS OK")
         """))
-    p = subprocess.run([sys.executable, str(script), ROOT], env=dict(os.environ, SSHASH_AMD_DIRECTORY="0"), capture_output=True,
-                       text=True, timeout=600)
-    assert p.returncode == 0 and "NODIR OK" in p.stdout, p.stdout + p.stderr
+    env = dict(os.environ)
+    for name in disabled:
+        env[name] = "0"
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "LAYERS OK" in p.stdout, p.stdout + p.stderr
