@@ -129,7 +129,7 @@ def main():
     t0 = time.time()
     d.to_device(local_rank)
     if rank == 0:
-        log(f"replica in HBM: {d.device_bytes(local_rank) / 1e6:.0f} MB (upload {time.time() - t0:.1f}s)")
+        log(f"replica in HBM: {d.device_bytes(local_rank) / 1e6:.0f} MB (upload {time.time() - t0:.1f}s); {d.device_stats(local_rank)}")
 
     n = args.queries
     W = d.words_per_kmer()
@@ -192,8 +192,9 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel": "fast_lookup_kernel<W=%d,canonical=%d,ids> + deferred_lookup_kernel (one pair per step; "
-                              "avg_kernel_ms = HIP-event time around the pair)" % (W, int(d.canonical())),
+                    "kernel": "fast_lookup_kernel<W=%d,canonical=%d,ids,%s> + deferred_lookup_kernel (one pair per step; "
+                              "avg_kernel_ms = HIP-event time around the pair)"
+                              % (W, int(d.canonical()), "super-k-mer table" if d.device_stats(local_rank)["sk_slots"] else "directory"),
                     "algorithmic_bytes_per_lookup": round(bytes_per_lookup, 2), "avg_kernel_ms": round(avg_kernel_ms, 3)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

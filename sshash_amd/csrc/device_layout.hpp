@@ -59,9 +59,9 @@
 //               of its reverse complement (equal values = tie, left to the structures above) -- one key
 //               for both strands, whatever the dictionary's own minimizer flavour;
 //        slot   32 bytes, 32-byte aligned; a key lives in one of three hashed slots (first free one
-//               wins, 2.5 slots per key):
-//                 d0  bit0 valid | bit1 list | bit2 strand | bit3 go-on-to-2nd | bit4 go-on-to-3rd |
-//                     bit5 unplaced-key-here | bits 8-13 left | bits 14-19 right
+//               wins, 3 slots per key), SK_CHOICES = 4:
+//                 d0  bit0 valid | bit1 list | bit2 strand | bits 3-6 go-on flags, one per choice |
+//                     bits 8-13 left | bits 14-19 right
 //                 d1  string id (inline) or number of occurrences (list; 0 = too long, defer)
 //                 d2,d3  position of the minimizer occurrence / list begin (40 bits) | fingerprint << 40
 //                 d4-d7  inline: the 64 bases starting k-m bases before the occurrence, i.e. every k-mer
@@ -70,10 +70,10 @@
 //               slot holds the super-k-mer, how far it may extend inside its string (left/right), and the
 //               string id, so the lookup ends at the slot. Other keys carry a list of occurrences
 //               ((position << 1) | strand, in `occ`), scanned through the atoms of (1).
-//        flags  bit3/bit4 say "a key hashed here lives further along its slot sequence"; a probe that
-//               finds neither its k-mer nor such a flag is a final miss -- negative queries end after
-//               ~1.1 reads. bit5 (a key that found no slot), over-long lists and ties send the query
-//               to the complete path through (3)/(4).
+//        flags  go-on flag c of a slot says "a key whose c-th choice is this slot lives further along its
+//               sequence"; a probe that finds neither its k-mer nor that flag is a final miss -- negative
+//               queries end after ~1.1 reads. The last choice's flag (a key that found no slot at all),
+//               over-long lists and ties send the query to the complete path through (3)/(4).
 //      Ids are positions in the strings, so results are identical to the reference's; the table only
 //      changes how many reads it takes to find the position. SSHASH_AMD_SKTABLE=0 disables it.
 //
@@ -138,11 +138,12 @@ SSH_HD uint32_t directory_fingerprint(uint64_t h) { return uint32_t(h) & 0xFFFFu
 SSH_HD uint64_t directory_entry(uint64_t code, uint32_t fp) { return code | (uint64_t(fp) << 40) | (uint64_t(1) << 56); }
 
 /* ---- super-k-mer table (5) ---- */
-constexpr uint32_t SK_VALID = 1u, SK_LIST = 2u, SK_STRAND = 4u, SK_GO2 = 8u, SK_GO3 = 16u, SK_UNPLACED = 32u;
+constexpr uint32_t SK_VALID = 1u, SK_LIST = 2u, SK_STRAND = 4u;
+constexpr uint32_t SK_GO_ON = 8u;             // << c: a key whose choice c is this slot lives at a later choice ...
+constexpr uint32_t SK_CHOICES = 4;            // ... or, for the last choice, in no slot at all
 constexpr uint32_t SK_LEFT_SHIFT = 8, SK_RIGHT_SHIFT = 14;
 constexpr uint32_t SK_LIST_MAX = 64;          // longer occurrence lists are left to the complete path
-constexpr double SK_SLOTS_PER_KEY = 2.5;
-constexpr uint32_t SK_CHOICES = 3;
+constexpr double SK_SLOTS_PER_KEY = 3.0;
 
 struct sk_view {
     void const* slots;    // num_slots x 32 bytes
@@ -167,7 +168,9 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_slots) {
     h.slot[0] = mulhi32(uint32_t(a >> 32), num_slots);
     h.slot[1] = mulhi32(uint32_t(a), num_slots);
     h.slot[2] = mulhi32(uint32_t(b >> 32), num_slots);
-    h.fingerprint = uint32_t(b) & 0xFFFFFFu;
+    h.slot[3] = mulhi32(uint32_t(b), num_slots);
+    const uint64_t c = (a + b) * 0xD6E8FEB86659FD93ULL;
+    h.fingerprint = uint32_t(c >> 40);
     return h;
 }
 

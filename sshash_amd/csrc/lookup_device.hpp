@@ -493,8 +493,7 @@ __device__ __forceinline__ fast_t sk_lookup_one(dict_view const& d, kmer_w<1> co
                 if (hit) break;
             }
         }
-        const uint32_t go = c == 0 ? SK_GO2 : (c == 1 ? SK_GO3 : SK_UNPLACED);
-        if (!(meta & go)) break;                       // nobody who hashed here lives elsewhere: final miss
+        if (!(meta & (SK_GO_ON << c))) break;          // nobody who hashed here lives elsewhere: final miss
         if (c + 1 == SK_CHOICES) return fast_unsettled(true);  // a key that found no slot: complete path
     }
     if (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc) {

@@ -8,7 +8,7 @@
 //               whose occurrence differs from its left neighbour's starts a super-k-mer and emits one
 //               tuple. Two passes (count, exclusive scan, emit) keep the tuples in string order.
 //   2. sort     stable radix sort of the tuples by key (hipCUB), run-length encode -> one run per key.
-//   3. place    three rounds, one per hashed slot choice: a key claims its slot with a CAS on the slot's
+//   3. place    SK_CHOICES rounds, one per hashed slot choice: a key claims its slot with a CAS on the slot's
 //               flag word; a key that loses sets the slot's "go on" flag and waits for the next round.
 //   4. fill     the winner writes its slot: the 64 bases around a single occurrence, how far the
 //               super-k-mer may extend inside its string, the string id -- or the occurrence list.
@@ -91,58 +91,66 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_key
                 uint32_t* __restrict__ slots, const uint32_t num_slots, uint8_t* __restrict__ placed,
                 unsigned long long* __restrict__ stats) {
     const uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (r >= num_keys || placed[r]) return;
-    const uint64_t key = keys[r];
-    const sk_hash_t h = sk_hash(key, num_slots);
-    uint32_t* S = slots + 8 * uint64_t(h.slot[choice]);
-    /* claim: set the valid bit unless somebody holds it (other lanes may be OR-ing flags into the same word) */
-    uint32_t cur = __hip_atomic_load(S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bool mine = false;
-    while (!(cur & SK_VALID)) {
-        const uint32_t seen = atomicCAS(S, cur, cur | SK_VALID);
-        if (seen == cur) {
-            mine = true;
-            break;
+    bool is_inline = false, too_long = false, unplaced = false;
+    if (r < num_keys && !placed[r]) {
+        const uint64_t key = keys[r];
+        const sk_hash_t h = sk_hash(key, num_slots);
+        uint32_t* S = slots + 8 * uint64_t(h.slot[choice]);
+        /* claim: set the valid bit unless somebody holds it (other lanes may be OR-ing flags into the same word) */
+        uint32_t cur = __hip_atomic_load(S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool mine = false;
+        while (!(cur & SK_VALID)) {
+            const uint32_t seen = atomicCAS(S, cur, cur | SK_VALID);
+            if (seen == cur) {
+                mine = true;
+                break;
+            }
+            cur = seen;
         }
-        cur = seen;
+        if (!mine) {
+            atomicOr(S, SK_GO_ON << choice);
+            unplaced = choice + 1 == SK_CHOICES;
+        } else {
+            placed[r] = 1;
+            const uint32_t size = run_sizes[r];
+            const uint64_t begin = run_begins[r];
+            uint32_t meta, d1;
+            uint64_t w1, w2, w3;
+            if (size == 1) {
+                const uint64_t v = occ[begin];
+                const uint64_t p = v >> 1;
+                const uint32_t km = d.k - d.m;
+                const uint32_t sid = read_window<1>(d.granules, p, 1).string_id;
+                const uint64_t s_begin = d.endpoints[sid], s_end = d.endpoints[sid + 1];
+                const uint64_t left = p - s_begin < km ? p - s_begin : km;
+                const uint64_t right = s_end - (p + d.m) < km ? s_end - (p + d.m) : km;
+                meta = (uint32_t(v & 1) ? SK_STRAND : 0u) | (uint32_t(left) << SK_LEFT_SHIFT) | (uint32_t(right) << SK_RIGHT_SHIFT);
+                d1 = sid;
+                w1 = p;
+                read_bases64(d.granules, int64_t(p) - int64_t(km), w2, w3);
+                is_inline = true;
+            } else {
+                meta = SK_LIST;
+                too_long = size > SK_LIST_MAX;
+                d1 = too_long ? 0u : size;
+                w1 = begin | (uint64_t(h.fingerprint) << 40);
+                w2 = size <= 2 ? occ[begin] : 0;
+                w3 = size == 2 ? occ[begin + 1] : 0;
+            }
+            S[1] = d1;
+            reinterpret_cast<uint64_t*>(S)[1] = w1;
+            reinterpret_cast<uint64_t*>(S)[2] = w2;
+            reinterpret_cast<uint64_t*>(S)[3] = w3;
+            if (meta) atomicOr(S, meta);
+        }
     }
-    if (!mine) {
-        atomicOr(S, choice == 0 ? SK_GO2 : (choice == 1 ? SK_GO3 : SK_UNPLACED));
-        if (choice + 1 == SK_CHOICES) atomicAdd(stats + 2, 1ull);  // unplaced keys
-        return;
+    /* statistics: one atomic per wave and counter, not per key */
+    const uint64_t b0 = __ballot(is_inline), b1 = __ballot(too_long), b2 = __ballot(unplaced);
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        if (b0) atomicAdd(stats + 0, (unsigned long long)__popcll(b0));
+        if (b1) atomicAdd(stats + 1, (unsigned long long)__popcll(b1));
+        if (b2) atomicAdd(stats + 2, (unsigned long long)__popcll(b2));
     }
-    placed[r] = 1;
-    const uint32_t size = run_sizes[r];
-    const uint64_t begin = run_begins[r];
-    uint32_t meta = 0;
-    uint32_t d1;
-    uint64_t w1, w2, w3;
-    if (size == 1) {
-        const uint64_t v = occ[begin];
-        const uint64_t p = v >> 1;
-        const uint32_t km = d.k - d.m;
-        const uint32_t sid = read_window<1>(d.granules, p, 1).string_id;
-        const uint64_t s_begin = d.endpoints[sid], s_end = d.endpoints[sid + 1];
-        const uint64_t left = p - s_begin < km ? p - s_begin : km;
-        const uint64_t right = s_end - (p + d.m) < km ? s_end - (p + d.m) : km;
-        meta = (uint32_t(v & 1) ? SK_STRAND : 0u) | (uint32_t(left) << SK_LEFT_SHIFT) | (uint32_t(right) << SK_RIGHT_SHIFT);
-        d1 = sid;
-        w1 = p;
-        read_bases64(d.granules, int64_t(p) - int64_t(km), w2, w3);
-        atomicAdd(stats + 0, 1ull);  // inline keys
-    } else {
-        meta = SK_LIST;
-        d1 = size <= SK_LIST_MAX ? size : 0u;
-        w1 = begin | (uint64_t(h.fingerprint) << 40);
-        w2 = size <= 2 ? occ[begin] : 0;
-        w3 = size == 2 ? occ[begin + 1] : 0;
-        if (size > SK_LIST_MAX) atomicAdd(stats + 1, 1ull);  // keys whose list is left to the complete path
-    }
-    S[1] = d1;
-    reinterpret_cast<uint64_t*>(S)[1] = w1;
-    reinterpret_cast<uint64_t*>(S)[2] = w2;
-    reinterpret_cast<uint64_t*>(S)[3] = w3;
-    if (meta) atomicOr(S, meta);
 }
 
 struct temp_buffers {  // freed on every exit path
@@ -245,7 +253,12 @@ void build_sk_table(device_replica& rep, host_index const& idx) {
     tmp.release(keys_sorted);
     uint64_t K = 0;
     HIP_CHECK(hipMemcpy(&K, d_num_runs, 8, hipMemcpyDeviceToHost));
-    const uint64_t num_slots = uint64_t(double(K) * SK_SLOTS_PER_KEY) + 16;
+    double slots_per_key = SK_SLOTS_PER_KEY;
+    if (const char* e = std::getenv("SSHASH_AMD_SK_SLOTS_PER_KEY")) {  // measurement knob
+        const double want = std::atof(e);
+        if (want >= 1.5 && want <= 16.0) slots_per_key = want;
+    }
+    const uint64_t num_slots = uint64_t(double(K) * slots_per_key) + 16;
     if (K == 0 || num_slots >= (uint64_t(1) << 32)) return;
     {
         size_t free_bytes = 0, total_bytes = 0;
