@@ -55,9 +55,10 @@
 //      (1)-(4) answer a positive lookup with two dependent random reads per probe (minimizer ->
 //      position, then the strings) and a regular index probes both strands (src/dictionary.cpp:70-75);
 //      what bounds the batch is the number of such reads. The table answers most lookups with ONE:
-//        key    the strand-symmetric minimizer of a k-mer: the smaller-valued of the minimizers of x and
-//               of its reverse complement (equal values = tie, left to the structures above) -- one key
-//               for both strands, whatever the dictionary's own minimizer flavour;
+//        key    a strand-symmetric minimizer of the k-mer (sk_key below): the m-mer with the smallest hash
+//               over both strands (equal minima = tie, left to the structures above) -- one key for both
+//               strands, whatever the dictionary's own minimizer flavour. Built and probed with the same
+//               function, the table need not follow the reference's minimizer hash: it uses a 32-bit one;
 //        slot   32 bytes, 32-byte aligned; a key lives in one of three hashed slots (first free one
 //               wins, 3 slots per key), SK_CHOICES = 4:
 //                 d0  bit0 valid | bit1 list | bit2 strand | bits 3-6 go-on flags, one per choice |
@@ -172,6 +173,48 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_slots) {
     const uint64_t c = (a + b) * 0xD6E8FEB86659FD93ULL;
     h.fingerprint = uint32_t(c >> 40);
     return h;
+}
+
+/* Key of a k-mer (k <= 31) for the super-k-mer table: an m-mer occurrence chosen so that a k-mer and its
+   reverse complement choose the same one. The table is free to use any such function (it is built and
+   probed with the same one), so this is NOT the reference's minimizer: 32-bit arithmetic, no 64-bit
+   multiply. Per strand the leftmost m-mer with the smallest hash wins; the strand with the smaller of
+   the two winning hashes supplies the key; equal hashes = tie (no key: the caller takes the complete path). */
+struct sk_key_t {
+    uint64_t key;  // the m-mer, as read on the winning strand
+    uint32_t pos;  // where it starts on that strand
+    bool rc;       // the winning strand is the reverse complement of x
+    bool tie;
+};
+
+SSH_HD uint32_t sk_mmer_hash(uint64_t mmer) {
+    return uint32_t(mmer) * 0x9E3779B1u + (uint32_t(mmer >> 32) * 0x85EBCA77u + 0x27D4EB2Fu);
+}
+
+SSH_HD sk_key_t sk_key(uint64_t x, uint64_t x_rc, uint32_t k, uint32_t m) {
+    const uint64_t mask = low_mask(2 * m);
+    uint32_t best_f = 0xFFFFFFFFu, best_r = 0xFFFFFFFFu, pos_f = 0, pos_r = 0;
+    uint64_t f = x, r = x_rc;
+    const uint32_t n = k - m + 1;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t hf = sk_mmer_hash(f & mask), hr = sk_mmer_hash(r & mask);
+        if (hf < best_f) {
+            best_f = hf;
+            pos_f = i;
+        }
+        if (hr < best_r) {
+            best_r = hr;
+            pos_r = i;
+        }
+        f >>= 2;
+        r >>= 2;
+    }
+    sk_key_t out;
+    out.rc = best_r < best_f;
+    out.tie = best_r == best_f;
+    out.pos = out.rc ? pos_r : pos_f;
+    out.key = ((out.rc ? x_rc : x) >> (2 * out.pos)) & mask;
+    return out;
 }
 
 struct dict_view {

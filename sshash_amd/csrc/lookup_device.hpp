@@ -433,12 +433,11 @@ __device__ __forceinline__ fast_t fast_lookup_one(dict_view const& d, kmer_w<W> 
    reverse-complement probe, src/dictionary.cpp:74-75). */
 __device__ __forceinline__ fast_t sk_lookup_one(dict_view const& d, kmer_w<1> const& x, bool allow_rc, int8_t miss_orientation) {
     const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
-    const minimizer_t mf = compute_minimizer<1>(x, d.k, d.m, d.hash_magic);
-    const minimizer_t mr = compute_minimizer<1>(x_rc, d.k, d.m, d.hash_magic);
-    if (mf.value == mr.value) return fast_unsettled(true);  // tie: no strand-symmetric key
-    const bool s = mr.value < mf.value;                     // the key was read on the reverse complement of x
-    const uint64_t key = s ? mr.value : mf.value;
-    const uint32_t j = s ? mr.pos : mf.pos;                 // where the key starts in y
+    const sk_key_t kk = sk_key(x.w[0], x_rc.w[0], d.k, d.m);
+    if (kk.tie) return fast_unsettled(true);  // no strand-symmetric key
+    const bool s = kk.rc;                     // the key was read on the reverse complement of x
+    const uint64_t key = kk.key;
+    const uint32_t j = kk.pos;                // where the key starts in y
     const uint64_t y = s ? x_rc.w[0] : x.w[0], y_rc = s ? x.w[0] : x_rc.w[0];
     const uint32_t km = d.k - d.m;
     const uint64_t kmask = low_mask(2 * d.k);

@@ -1,7 +1,7 @@
 // sktable.hip -- construction of the super-k-mer table (device_layout.hpp (5)) on the GPU, at upload.
 //
 // Input: the atoms of (1) and the endpoints, already resident. Nothing of the host index's own
-// minimizer structures is used: the table is keyed by strand-symmetric minimizers recomputed from
+// minimizer structures is used: the table is keyed by strand-symmetric minimizers (sk_key) recomputed from
 // the strings, so it serves regular and canonical dictionaries alike.
 //
 //   1. scan     one lane per k-mer start: the k-mer's key occurrence (key, position, strand); a lane
@@ -43,13 +43,11 @@ sk_scan_kernel(const dict_view d, const uint64_t num_waves, uint32_t* __restrict
         if (!w.crosses) {
             const kmer_w<1> x = w.kmer;
             const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
-            const minimizer_t mf = compute_minimizer<1>(x, d.k, d.m, d.hash_magic);
-            const minimizer_t mr = compute_minimizer<1>(x_rc, d.k, d.m, d.hash_magic);
-            if (mf.value != mr.value) {
-                const bool s = mr.value < mf.value;
-                key = s ? mr.value : mf.value;
-                const uint64_t p = uint64_t(i) + (s ? (d.k - d.m) - mr.pos : mf.pos);
-                val = (p << 1) | (s ? 1u : 0u);
+            const sk_key_t kk = sk_key(x.w[0], x_rc.w[0], d.k, d.m);
+            if (!kk.tie) {
+                key = kk.key;
+                const uint64_t p = uint64_t(i) + (kk.rc ? (d.k - d.m) - kk.pos : kk.pos);
+                val = (p << 1) | (kk.rc ? 1u : 0u);
             }
         }
     }

@@ -102,6 +102,20 @@ def mmer_hash(mmer_str, seed=1):
     return ((x * 0x517CC1B727220A95) & ((1 << 64) - 1)) ^ O.xxh64_u64(seed, 0)
 
 
+def table_key_hash(mmer_str):
+    """sk_mmer_hash of csrc/device_layout.hpp (the super-k-mer table's own 32-bit m-mer hash), taken over
+    both strands: an m-mer with a small value wins the table's key election of any window it appears in."""
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+    def h(t):
+        x = 0
+        for i, c in enumerate(t):
+            x |= ((ord(c) >> 1) & 3) << (2 * i)
+        return ((x & 0xFFFFFFFF) * 0x9E3779B1 + ((x >> 32) * 0x85EBCA77 + 0x27D4EB2F)) & 0xFFFFFFFF
+
+    return min(h(mmer_str), h("".join(comp[c] for c in reversed(mmer_str))))
+
+
 def skewed_sequences(k, m, seed=3, n_heavy=150, n_mid=7, n_plain=60, canonical=False):
     """Synthetic strings with planted low-hash m-mers so that MIDLOAD and HEAVYLOAD buckets exist.
     Every planted copy sits between fresh random flanks, so k-mers stay unique."""
@@ -120,6 +134,30 @@ def skewed_sequences(k, m, seed=3, n_heavy=150, n_mid=7, n_plain=60, canonical=F
     for i in range(n_plain):
         seqs.append(random_dna(rng, int(rng.integers(k, 6 * k))))
     seqs.append(random_dna(rng, k))  # a string holding exactly one k-mer
+    # the same for the device's super-k-mer table, which elects keys with its own hash: one key with more
+    # occurrences than the table lists (left to the complete path), one with a list in `occ`, one with two
+    table_motifs = [c for c in sorted(cands, key=table_key_hash) if c not in motifs][:3]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+    def canonical_kmers(t):
+        out = set()
+        for i in range(len(t) - k + 1):
+            x = t[i:i + k]
+            out.add(min(x, "".join(comp[c] for c in reversed(x))))
+        return out
+
+    seen = set()
+    for t in seqs:
+        seen |= canonical_kmers(t)
+    for motif, copies in zip(table_motifs, (100, 9, 2)):
+        for i in range(copies):
+            while True:  # short k: keep every k-mer of the collection distinct
+                t = random_dna(rng, k + int(rng.integers(3, 30))) + motif + random_dna(rng, k + int(rng.integers(3, 30)))
+                mine = canonical_kmers(t)
+                if len(mine) == len(t) - k + 1 and not (mine & seen):
+                    break
+            seen |= mine
+            seqs.append(t)
     return seqs
 
 

@@ -37,7 +37,11 @@ def test_shards_partition_the_dictionary(case_name, S, request, tmp_path):
     full = case.oracle.lookup_ids(q)
     per_shard = np.stack([o.lookup_ids(q) for _, o in shards])
     found = per_shard != np.uint64(0xFFFFFFFFFFFFFFFF)
-    assert (found.sum(axis=0) <= 1).all()  # a k-mer is answered by exactly one owner (or by none)
+    # a k-mer is answered by its owner; another shard may answer too (its MPHF sends the foreign minimizer to
+    # an arbitrary bucket, which in a canonical dictionary can be the reverse-complement minimizer's bucket
+    # over the same position) -- never with a different id
+    assert (per_shard[found] == np.broadcast_to(full, per_shard.shape)[found]).all()
+    assert (found.sum(axis=0) >= (full != np.uint64(0xFFFFFFFFFFFFFFFF))).all()
     combined = np.where(found.any(axis=0), per_shard.min(axis=0), np.uint64(0xFFFFFFFFFFFFFFFF))
     assert (combined == full).all()
 
