@@ -144,6 +144,15 @@ sshash_status sshash_access_packed(const sshash_dict* d, const uint64_t* kmer_id
 sshash_status sshash_access_packed_device(const sshash_dict* d, int device, const uint64_t* kmer_ids, uint64_t n,
                                           uint64_t* out_words, void* hip_stream);
 
+/* ---- dictionary::kmer_neighbours(Kmer, bool): include/dictionary.hpp:59-61, src/dictionary.cpp:111-126,176-187.
+ *      Batched: every array of `out` holds 8*n entries; entry 8*i + c (c = 0..3) is the lookup of the forward
+ *      neighbour suffix(kmer i) + "ACGT"[c], entry 8*i + 4 + c the backward neighbour "ACGT"[c] + prefix(kmer i)
+ *      (neighbourhood::forward / ::backward, include/util.hpp:78-81). Same pointer rules as the lookups. */
+sshash_status sshash_neighbours_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                              int check_reverse_complement, const sshash_results* out, void* hip_stream);
+sshash_status sshash_neighbours_packed(const sshash_dict* d, const uint64_t* kmers, uint64_t n,
+                                       int check_reverse_complement, const sshash_results* out);
+
 /* ---- dictionary::streaming_query_from_file (include/dictionary.hpp:81-82, src/query.cpp:118-175)
  *      and streaming_query<Dict,canonical> over reads in memory (include/streaming_query.hpp) -- */
 sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char* filename, int multiline,

@@ -135,6 +135,17 @@ public:
         return ids;
     }
 
+    /* Navigational query -- include/dictionary.hpp:59-61 (kmer_neighbours): ids of the forward neighbours
+       suffix + A,C,G,T at [8*i .. 8*i+3] and of the backward neighbours A,C,G,T + prefix at [8*i+4 .. 8*i+7]
+       of packed k-mer i; INVALID for a neighbour that is not in the dictionary. */
+    std::vector<uint64_t> neighbours_ids(uint64_t const* kmers, uint64_t n, bool check_reverse_complement = true) const {
+        std::vector<uint64_t> ids(8 * n);
+        sshash_results out{};
+        out.kmer_id = ids.data();
+        check(sshash_neighbours_packed(m_h, kmers, n, check_reverse_complement, &out));
+        return ids;
+    }
+
     /* Membership queries -- include/dictionary.hpp:74-76 */
     bool is_member(char const* string_kmer, bool check_reverse_complement = true) const {
         uint8_t out = 0;

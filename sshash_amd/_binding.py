@@ -141,6 +141,8 @@ def _load() -> C.CDLL:
         "sshash_lookup_ascii_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
         "sshash_lookup_packed": (C.c_int, [P, P, C.c_uint64, C.c_int, C.POINTER(_Results)]),
         "sshash_lookup_ascii": (C.c_int, [P, P, C.c_uint64, C.c_int, C.POINTER(_Results)]),
+        "sshash_neighbours_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
+        "sshash_neighbours_packed": (C.c_int, [P, P, C.c_uint64, C.c_int, C.POINTER(_Results)]),
         "sshash_is_member_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, P, P]),
         "sshash_is_member_packed": (C.c_int, [P, P, C.c_uint64, C.c_int, P]),
         "sshash_is_member_ascii": (C.c_int, [P, P, C.c_uint64, C.c_int, P]),
@@ -164,6 +166,7 @@ C_ABI_SYMBOLS = (
     "sshash_last_error sshash_build_config_default sshash_build_from_fasta sshash_build_from_packed sshash_save "
     "sshash_load sshash_free sshash_get_info sshash_device_count sshash_to_device sshash_device_bytes sshash_device_stats "
     "sshash_lookup_packed_device sshash_lookup_ascii_device sshash_lookup_packed sshash_lookup_ascii "
+    "sshash_neighbours_packed_device sshash_neighbours_packed "
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
     "sshash_access_packed_device "
     "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device "
@@ -375,6 +378,37 @@ class Dictionary:
         fn = _load().sshash_lookup_ascii_device if ascii_input else _load().sshash_lookup_packed_device
         _check(fn(self._h, int(device), C.c_void_p(d_kmers), int(n), 1 if check_reverse_complement else 0, C.byref(r),
                   C.c_void_p(stream)))
+
+    def neighbours(self, kmers: np.ndarray, check_reverse_complement: bool = True, full: bool = False) -> LookupResult:
+        """Batched dictionary::kmer_neighbours (reference src/dictionary.cpp:111-126,176-187) over packed k-mers:
+        every array of the result has 8 entries per query -- forward neighbours with A,C,G,T appended, then
+        backward neighbours with A,C,G,T prepended."""
+        a = np.ascontiguousarray(kmers, dtype=np.uint64)
+        n = a.size // self.words_per_kmer()
+        res = LookupResult(kmer_id=np.empty(8 * n, dtype=np.uint64))
+        r = _Results()
+        r.kmer_id = res.kmer_id.ctypes.data
+        if full:
+            for name in ("kmer_id_in_string", "kmer_offset", "string_id", "string_begin", "string_end"):
+                arr = np.empty(8 * n, dtype=np.uint64)
+                setattr(res, name, arr)
+                setattr(r, name, arr.ctypes.data)
+            res.kmer_orientation = np.empty(8 * n, dtype=np.int8)
+            res.minimizer_found = np.empty(8 * n, dtype=np.uint8)
+            r.kmer_orientation = res.kmer_orientation.ctypes.data
+            r.minimizer_found = res.minimizer_found.ctypes.data
+        _check(_load().sshash_neighbours_packed(self._h, a.ctypes.data, n, 1 if check_reverse_complement else 0, C.byref(r)))
+        return res
+
+    def neighbours_device(self, device: int, d_kmers: int, n: int, d_kmer_id: int, check_reverse_complement: bool = True,
+                          stream: int = 0, **optional_outputs: int) -> None:
+        """Device-pointer form: d_kmer_id (and every optional output) has room for 8*n entries."""
+        r = _Results()
+        r.kmer_id = d_kmer_id
+        for name, ptr in optional_outputs.items():
+            setattr(r, name, ptr)
+        _check(_load().sshash_neighbours_packed_device(self._h, int(device), C.c_void_p(d_kmers), int(n),
+                                                       1 if check_reverse_complement else 0, C.byref(r), C.c_void_p(stream)))
 
     def is_member_device(self, device: int, d_kmers: int, n: int, d_out: int, check_reverse_complement: bool = True,
                          stream: int = 0) -> None:

@@ -213,6 +213,23 @@ sshash_status sshash_lookup_ascii(const sshash_dict* d, const char* kmers, uint6
     });
 }
 
+sshash_status sshash_neighbours_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                              int check_rc, const sshash_results* out, void* hip_stream) {
+    if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        d->eng->neighbours_packed_device(device, kmers, n, check_rc != 0, wants_full(out) ? out_mode::full : out_mode::ids,
+                                         to_view(out), hip_stream);
+    });
+}
+
+sshash_status sshash_neighbours_packed(const sshash_dict* d, const uint64_t* kmers, uint64_t n, int check_rc,
+                                       const sshash_results* out) {
+    if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        d->eng->neighbours_packed_host(kmers, n, check_rc != 0, wants_full(out) ? out_mode::full : out_mode::ids, to_view(out));
+    });
+}
+
 sshash_status sshash_is_member_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
                                              int check_rc, uint8_t* out, void* hip_stream) {
     if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");

@@ -546,6 +546,59 @@ void engine::lookup_ascii_device(int device, char const* d_kmers, uint64_t n, bo
     launch_any<true>(mode, rep, d_kmers, n, check_rc, d_out, d_member, hipStream_t(stream));
 }
 
+/* ---- kmer_neighbours: expand every query into its 8 neighbours, then the ordinary batched lookup -------- */
+
+template <int W>
+__global__ void __launch_bounds__(256)
+expand_neighbours_kernel(const uint64_t* __restrict__ kmers, const uint64_t n, const uint32_t k, uint64_t* __restrict__ out) {
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // one lane per neighbour: coalesced stores
+    if (t >= 8 * n) return;
+    const kmer_w<W> x = load_query<W, false>(kmers, t >> 3, k);
+    const kmer_w<W> y = kmer_neighbour<W>(x, uint32_t(t & 7), k);
+    for (int j = 0; j < W; ++j) out[t * W + j] = y.w[j];
+}
+
+void engine::neighbours_packed_device(int device, uint64_t const* d_kmers, uint64_t n, bool check_rc, out_mode mode,
+                                      result_view const& d_out, void* stream) const {
+    device_replica const* rep = replica(device);
+    check_outputs(mode, d_out, nullptr);
+    if (n == 0) return;
+    device_guard guard(device);
+    hipStream_t s = hipStream_t(stream);
+    const uint32_t W = rep->view.k <= 31 ? 1 : 2;
+    uint64_t* expanded = nullptr;
+    HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&expanded), 8 * n * W * sizeof(uint64_t), s));
+    const dim3 grid(uint32_t((8 * n + 255) / 256)), block(256);
+    if (W == 1) hipLaunchKernelGGL(expand_neighbours_kernel<1>, grid, block, 0, s, d_kmers, n, rep->view.k, expanded);
+    else hipLaunchKernelGGL(expand_neighbours_kernel<2>, grid, block, 0, s, d_kmers, n, rep->view.k, expanded);
+    HIP_CHECK(hipGetLastError());
+    launch_any<false>(mode, rep, expanded, 8 * n, check_rc, d_out, nullptr, s);
+    HIP_CHECK(hipFreeAsync(expanded, s));
+}
+
+void engine::neighbours_packed_host(uint64_t const* h_kmers, uint64_t n, bool check_rc, out_mode mode,
+                                    result_view const& h_out) const {
+    const uint32_t k = m_idx->k, W = m_idx->words_per_kmer();
+    std::vector<uint64_t> expanded(8 * n * W);
+    for (uint64_t i = 0; i < n; ++i) {
+        for (uint32_t which = 0; which < 8; ++which) {
+            if (W == 1) {
+                kmer_w<1> x;
+                x.w[0] = h_kmers[i];
+                expanded[8 * i + which] = kmer_neighbour<1>(kmer_take_chars<1>(x, k), which, k).w[0];
+            } else {
+                kmer_w<2> x;
+                x.w[0] = h_kmers[2 * i];
+                x.w[1] = h_kmers[2 * i + 1];
+                const kmer_w<2> y = kmer_neighbour<2>(kmer_take_chars<2>(x, k), which, k);
+                expanded[2 * (8 * i + which)] = y.w[0];
+                expanded[2 * (8 * i + which) + 1] = y.w[1];
+            }
+        }
+    }
+    lookup_packed_host(expanded.data(), 8 * n, check_rc, mode, h_out, nullptr);
+}
+
 /* ---- routing of queries to the owners of their minimizers (minimizer-sharded index) ------------ */
 
 template <int W>

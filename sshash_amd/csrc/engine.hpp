@@ -47,6 +47,13 @@ public:
     void lookup_ascii_device(int device, char const* d_kmers, uint64_t n, bool check_rc, out_mode mode,
                              result_view const& d_out, uint8_t* d_member, void* stream) const;
 
+    /* kmer_neighbours (src/dictionary.cpp:111-187) for a batch: the 8 lookups per query, results at 8*i + which
+       (which = 0..3 forward with A,C,G,T; 4..7 backward with A,C,G,T). Device buffers / host buffers. */
+    void neighbours_packed_device(int device, uint64_t const* d_kmers, uint64_t n, bool check_rc, out_mode mode,
+                                  result_view const& d_out, void* stream) const;
+    void neighbours_packed_host(uint64_t const* h_kmers, uint64_t n, bool check_rc, out_mode mode,
+                                result_view const& h_out) const;
+
     /* access(kmer_id) for a batch of ids, device buffers: out gets n*W packed words
        (all-ones for an id >= num_kmers). */
     void access_packed_device(int device, uint64_t const* d_ids, uint64_t n, uint64_t* d_out, void* stream) const;

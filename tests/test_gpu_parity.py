@@ -296,3 +296,46 @@ def test_accelerators_disabled(tmp_path, disabled):
         env[name] = "0"
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "LAYERS OK" in p.stdout, p.stdout + p.stderr
+
+
+def _expand_neighbours(q, k, W):
+    """Independent expansion of kmer_neighbours' 8 queries (src/dictionary.cpp:111-126) with Python integers."""
+    out = np.empty(q.size * 8, dtype=np.uint64)
+    mask = (1 << (2 * k)) - 1
+    codes = [0, 1, 3, 2]  # A C G T
+    for i in range(q.size // W):
+        x = int(q[i * W]) | (int(q[i * W + 1]) << 64 if W == 2 else 0)
+        for c in range(4):
+            f = (x >> 2) | (codes[c] << (2 * (k - 1)))
+            b = ((x << 2) & mask) | codes[c]
+            for which, y in ((c, f), (4 + c, b)):
+                for j in range(W):
+                    out[(8 * i + which) * W + j] = (y >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+@pytest.mark.parametrize("case_name", ["case_skew_regular", "case_skew_canonical", "case_k63_canonical", "case_se_regular"])
+def test_neighbours_match_eight_oracle_lookups(case_name, request):
+    case = request.getfixturevalue(case_name)
+    d = case.dict.to_device(0)
+    q = case.queries(1500, 300, seed=77)
+    expanded = _expand_neighbours(q, case.k, case.W)
+    want = case.oracle.lookup_packed(expanded)
+    got = d.neighbours(q, full=True)
+    for f in U64_FIELDS:
+        assert (getattr(got, f) == want[f]).all(), f
+    assert (got.kmer_orientation.astype(np.int64) == want["kmer_orientation"]).all()
+    assert (got.minimizer_found.astype(np.int64) == want["minimizer_found"]).all()
+    assert (d.neighbours(q, check_reverse_complement=False).kmer_id == case.oracle.lookup_packed(expanded, False)["kmer_id"]).all()
+    # positives drawn from inside a string have at least one forward or backward neighbour in the dictionary
+    ids = got.kmer_id.reshape(-1, 8)
+    assert (ids != np.uint64(0xFFFFFFFFFFFFFFFF)).any()
+    # device-pointer form
+    import torch
+
+    n = q.size // case.W
+    dq = torch.from_numpy(q.view(np.int64)).cuda()
+    out = torch.empty(8 * n, dtype=torch.int64, device="cuda")
+    d.neighbours_device(0, dq.data_ptr(), n, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (out.cpu().numpy().view(np.uint64) == want["kmer_id"]).all()
