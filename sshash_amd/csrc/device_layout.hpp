@@ -64,7 +64,7 @@
 //                 d0  bit0 valid | bit1 list | bit2 strand | bits 3-6 go-on flags, one per choice |
 //                     bits 8-13 left | bits 14-19 right
 //                 d1  string id (inline) or number of occurrences (list; 0 = too long, defer)
-//                 d2,d3  position of the minimizer occurrence / list begin (40 bits) | fingerprint << 40
+//                 d2,d3  position of the key occurrence / list begin (40 bits) | fingerprint of the key << 40
 //                 d4-d7  inline: the 64 bases starting k-m bases before the occurrence, i.e. every k-mer
 //                        of the super-k-mer; list of <= 2: the occurrences themselves
 //               A key with exactly one occurrence in the strings (~90 % of the k-mers) is *inline*: the

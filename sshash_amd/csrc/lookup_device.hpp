@@ -427,34 +427,35 @@ __device__ __forceinline__ fast_t fast_lookup_one(dict_view const& d, kmer_w<W> 
 }
 
 /* ---- lookup through the super-k-mer table (device_layout.hpp (5)), k <= 31 ----------------------
-   Same contract as fast_lookup_one: HIT / final MISS / DEFER to the complete path. `allow_rc` false
-   (regular dictionary, check_reverse_complement off: src/dictionary.cpp:70-71) turns a hit on the other
-   strand into a miss. `miss_orientation`: what a miss reports (-1 after a regular dictionary's
-   reverse-complement probe, src/dictionary.cpp:74-75). */
-__device__ __forceinline__ fast_t sk_lookup_one(dict_view const& d, kmer_w<1> const& x, bool allow_rc, int8_t miss_orientation) {
-    const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
-    const sk_key_t kk = sk_key(x.w[0], x_rc.w[0], d.k, d.m);
-    if (kk.tie) return fast_unsettled(true);  // no strand-symmetric key
-    const bool s = kk.rc;                     // the key was read on the reverse complement of x
-    const uint64_t key = kk.key;
-    const uint32_t j = kk.pos;                // where the key starts in y
-    const uint64_t y = s ? x_rc.w[0] : x.w[0], y_rc = s ? x.w[0] : x_rc.w[0];
+   sk_probe: follow the key's slot sequence. HIT / final MISS / DEFER to the complete path. `key_seen`:
+   some slot on the way carried the key's fingerprint; a MISS without it proves that no k-mer with this
+   key is in the dictionary (the streaming query's negative short-cut uses that). */
+__device__ __forceinline__ fast_t sk_probe(dict_view const& d, uint64_t x, uint64_t x_rc, sk_key_t const& kk, bool& key_seen) {
+    const bool s = kk.rc;       // the key was read on the reverse complement of x
+    const uint32_t j = kk.pos;  // where the key starts in y
+    const uint64_t y = s ? x_rc : x, y_rc = s ? x : x_rc;
     const uint32_t km = d.k - d.m;
     const uint64_t kmask = low_mask(2 * d.k);
-    const sk_hash_t h = sk_hash(key, d.sk.num_slots);
+    const sk_hash_t h = sk_hash(kk.key, d.sk.num_slots);
     fast_t r = fast_unsettled(false);
-    r.orientation = miss_orientation;
+    key_seen = false;
 #pragma unroll 1
     for (uint32_t c = 0; c < SK_CHOICES; ++c) {
         const uint4* S = reinterpret_cast<const uint4*>(d.sk.slots) + 2 * uint64_t(h.slot[c]);
         const uint4 q0 = S[0], q1 = S[1];
-        uint32_t meta = q0.x;
-        asm volatile("" : "+v"(meta));  // keep the flags in their own register across the list scan
+        const uint32_t meta = q0.x;
+        /* decided now, in its own register: hipcc 7.2 has been seen recycling a slot word that is only
+           consumed after the list scan */
+        uint32_t go_on = meta & (SK_GO_ON << c);
+        asm volatile("" : "+v"(go_on));
         if (meta & SK_VALID) {
             const uint64_t at = uint64_t(q0.z) | (uint64_t(q0.w & 0xFFu) << 32);
+            const bool same_fingerprint = (q0.w >> 8) == h.fingerprint;
+            key_seen = key_seen || same_fingerprint;
             if (!(meta & SK_LIST)) {
                 /* inline super-k-mer: the strings read the key forward (strand 0: y aligns, key at km - a)
-                   or reverse-complemented (strand 1: rc(y) aligns, its copy of the key sits at km - j) */
+                   or reverse-complemented (strand 1: rc(y) aligns, its copy of the key sits at km - j).
+                   No fingerprint test: the k-mer comparison is the test. */
                 const bool o = (meta & SK_STRAND) != 0;
                 const uint32_t a = o ? j : km - j;
                 const uint64_t lo = uint64_t(q1.x) | (uint64_t(q1.y) << 32), hi = uint64_t(q1.z) | (uint64_t(q1.w) << 32);
@@ -465,12 +466,10 @@ __device__ __forceinline__ fast_t sk_lookup_one(dict_view const& d, kmer_w<1> co
                     r.string_id = q0.y;
                     r.orientation = (o != s) ? -1 : 1;
                     r.outcome = FAST_HIT;
-                    break;
                 }
-            } else if ((q0.w >> 8) == h.fingerprint) {
+            } else if (same_fingerprint) {
                 const uint32_t size = q0.y;
-                if (size == 0) return fast_unsettled(true);  // list longer than SK_LIST_MAX
-                bool hit = false;
+                if (size == 0) r.outcome = FAST_DEFER;  // list longer than SK_LIST_MAX
                 for (uint32_t t = 0; t < size; ++t) {
                     uint64_t v;
                     if (size <= 2) v = t == 0 ? (uint64_t(q1.x) | (uint64_t(q1.y) << 32)) : (uint64_t(q1.z) | (uint64_t(q1.w) << 32));
@@ -485,17 +484,27 @@ __device__ __forceinline__ fast_t sk_lookup_one(dict_view const& d, kmer_w<1> co
                         r.string_id = w.string_id;
                         r.orientation = (o != s) ? -1 : 1;
                         r.outcome = FAST_HIT;
-                        hit = true;
                         break;
                     }
                 }
-                if (hit) break;
             }
         }
-        if (!(meta & (SK_GO_ON << c))) break;          // nobody who hashed here lives elsewhere: final miss
-        if (c + 1 == SK_CHOICES) return fast_unsettled(true);  // a key that found no slot: complete path
+        if (r.outcome != FAST_MISS || go_on == 0) break;  // settled, or nobody who hashed here lives elsewhere
+        if (c + 1 == SK_CHOICES) r.outcome = FAST_DEFER;  // a key that found no slot: complete path
     }
-    if (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc) {
+    return r;
+}
+
+/* Same contract as fast_lookup_one. `allow_rc` false (regular dictionary, check_reverse_complement off:
+   src/dictionary.cpp:70-71) turns a hit on the other strand into a miss. `miss_orientation`: what a miss
+   reports (-1 after a regular dictionary's reverse-complement probe, src/dictionary.cpp:74-75). */
+__device__ __forceinline__ fast_t sk_lookup_one(dict_view const& d, kmer_w<1> const& x, bool allow_rc, int8_t miss_orientation) {
+    const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
+    const sk_key_t kk = sk_key(x.w[0], x_rc.w[0], d.k, d.m);
+    if (kk.tie) return fast_unsettled(true);  // no strand-symmetric key
+    bool key_seen;
+    fast_t r = sk_probe(d, x.w[0], x_rc.w[0], kk, key_seen);
+    if (r.outcome == FAST_MISS || (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc)) {
         r = fast_unsettled(false);
         r.orientation = miss_orientation;
     }

@@ -124,7 +124,7 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_key
                 const uint64_t right = s_end - (p + d.m) < km ? s_end - (p + d.m) : km;
                 meta = (uint32_t(v & 1) ? SK_STRAND : 0u) | (uint32_t(left) << SK_LEFT_SHIFT) | (uint32_t(right) << SK_RIGHT_SHIFT);
                 d1 = sid;
-                w1 = p;
+                w1 = p | (uint64_t(h.fingerprint) << 40);
                 read_bases64(d.granules, int64_t(p) - int64_t(km), w2, w3);
                 is_inline = true;
             } else {

@@ -11,6 +11,10 @@
 //   * otherwise seed(): the negative short-cut (:150-157), then the point lookups (:159-180).
 //     Minimizers are only needed inside seed(), so they are computed there, statelessly
 //     (the rolling iterators of include/minimizer_iterator.hpp return the same values: :56-57).
+//     For k <= 31 seed() goes through the super-k-mer table (device_layout.hpp (5)): one slot read per
+//     seed instead of directory + window per strand. The negative short-cut becomes "same table key as
+//     the previous k-mer, and that key is provably not in the table" -- the same k-mers are negative
+//     either way, so the counters are unchanged; queries the table defers take the path above.
 // Output: the six counters of streaming_query_report (include/util.hpp:21-36).
 #include <hip/hip_runtime.h>
 
@@ -51,7 +55,7 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
     return v;
 }
 
-template <int W, bool CANON>
+template <int W, bool CANON, bool SK>
 __global__ void __launch_bounds__(256)
 streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const char* __restrict__ bases,
                  const uint64_t* __restrict__ offsets, const uint64_t n_reads, uint64_t* __restrict__ report) {
@@ -66,7 +70,7 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
         uint32_t valid_len = 0;
         bool in_run = false;        // previous k-mer was found (remaining bases tracked via `off`)
         bool neg_unknown_mini = false;  // previous k-mer: seed() said "negative, minimizer not in index"
-        uint64_t prev_f = 0, prev_r = 0;
+        uint64_t prev_f = 0, prev_r = 0;  // SK: prev_f holds the previous table key
         uint64_t off = 0;
         int ori = 1;
         const char* p = bases + begin;
@@ -93,6 +97,36 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
                 }
             }
             /* seed() */
+            if constexpr (SK) {
+                const sk_key_t kk = sk_key(x.w[0], x_rc.w[0], k, d.m);
+                if (!kk.tie) {
+                    if (neg_unknown_mini && kk.key == prev_f) {
+                        ++c_negative;
+                        in_run = false;
+                        continue;
+                    }
+                    bool key_seen;
+                    const fast_t r = sk_probe(d, x.w[0], x_rc.w[0], kk, key_seen);
+                    if (r.outcome != FAST_DEFER) {
+                        if (r.outcome == FAST_HIT) {
+                            ++c_searches;
+                            in_run = true;
+                            off = r.kmer_offset;
+                            ori = r.orientation;
+                            neg_unknown_mini = false;
+                        } else {
+                            ++c_negative;
+                            in_run = false;
+                            neg_unknown_mini = !key_seen;
+                            prev_f = kk.key;
+                        }
+                        continue;
+                    }
+                }
+                /* tie / unplaced key / over-long list: the complete seed() below (its own short-cut state is
+                   not carried across table seeds) */
+                neg_unknown_mini = false;
+            }
             const minimizer_t mf = compute_minimizer<W>(x, k, d.m, d.hash_magic);
             const minimizer_t mr = compute_minimizer<W>(x_rc, k, d.m, d.hash_magic);
             if (neg_unknown_mini && mf.value == prev_f && mr.value == prev_r) {  // :150-157
@@ -112,7 +146,7 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
             } else {
                 ++c_negative;
                 in_run = false;
-                neg_unknown_mini = !h.minimizer_found;
+                neg_unknown_mini = SK ? false : !h.minimizer_found;
             }
         }
     }
@@ -137,8 +171,17 @@ void launch_streaming(dict_view const& d, skew_part_dev const* skew, char const*
     const uint32_t block = 256;
     uint64_t blocks = (n_reads + block - 1) / block;
     if (blocks > (uint64_t(1) << 20)) blocks = uint64_t(1) << 20;
-    hipLaunchKernelGGL((streaming_kernel<W, CANON>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases, offsets,
-                       n_reads, report);
+    bool through_table = false;
+    if constexpr (W == 1) {
+        if (d.sk.enabled) {
+            through_table = true;
+            hipLaunchKernelGGL((streaming_kernel<1, CANON, true>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
+                               offsets, n_reads, report);
+        }
+    }
+    if (!through_table)
+        hipLaunchKernelGGL((streaming_kernel<W, CANON, false>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
+                           offsets, n_reads, report);
     HIP_CHECK(hipGetLastError());
 }
 

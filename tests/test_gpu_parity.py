@@ -79,6 +79,13 @@ def test_every_kmer_of_the_input_in_file_order(case_name, request):
     res = d.lookup(kmers, full=True)
     assert (res.kmer_id == np.arange(count, dtype=np.uint64)).all(), "wrong id assigned"
     assert (res.kmer_orientation == np.array(orient, dtype=np.int8)).all()
+    # every output mode is its own kernel instance: all of them over every k-mer of the input
+    assert (d.lookup(kmers).kmer_id == res.kmer_id).all(), "ids-only kernel"
+    assert d.is_member(kmers).all(), "membership kernel"
+    packed = case.gt.kmers(np.arange(count))
+    assert d.is_member(packed).all() and (d.lookup(packed).kmer_id == res.kmer_id).all(), "packed entry points"
+    partial = d.lookup(packed, full=True)  # (host path asks for every field: the complete kernel)
+    assert (partial.kmer_offset == res.kmer_offset).all()
     sizes = res.string_end - res.string_begin - np.uint64(k - 1)
     assert (res.kmer_id_in_string < sizes).all()
     # access round trip: access(lookup(x).kmer_id) is x or its reverse complement (:146-155)
@@ -216,18 +223,21 @@ def test_full_result_without_minimizer_found_uses_the_same_values(case_name, req
     case = request.getfixturevalue(case_name)
     d = case.dict.to_device(0)
     n = 20000 if case.gt.num_kmers > 100000 else 3000
-    q = case.queries(n, n, seed=21)
-    want = case.oracle.lookup_packed(q)
-    dq = torch.from_numpy(q.view(np.int64)).cuda()
-    bufs = {f: torch.empty(2 * n, dtype=torch.int64, device="cuda") for f in U64_FIELDS}
-    ori = torch.empty(2 * n, dtype=torch.int8, device="cuda")
-    extra = {f: t.data_ptr() for f, t in bufs.items() if f != "kmer_id"}
-    d.lookup_device(0, dq.data_ptr(), 2 * n, bufs["kmer_id"].data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
-                    kmer_orientation=ori.data_ptr(), **extra)
-    torch.cuda.synchronize()
-    for f in U64_FIELDS:
-        assert (bufs[f].cpu().numpy().view(np.uint64) == want[f]).all(), f
-    assert (ori.cpu().numpy().astype(np.int64) == want["kmer_orientation"]).all()
+    # a random mix, then every k-mer of the dictionary (each super-k-mer, list and deferred key at least once)
+    every = case.gt.kmers(np.arange(min(case.gt.num_kmers, 1_000_000)))
+    for q in (case.queries(n, n, seed=21), every):
+        total = q.size // case.W
+        want = case.oracle.lookup_packed(q)
+        dq = torch.from_numpy(q.view(np.int64)).cuda()
+        bufs = {f: torch.empty(total, dtype=torch.int64, device="cuda") for f in U64_FIELDS}
+        ori = torch.empty(total, dtype=torch.int8, device="cuda")
+        extra = {f: t.data_ptr() for f, t in bufs.items() if f != "kmer_id"}
+        d.lookup_device(0, dq.data_ptr(), total, bufs["kmer_id"].data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
+                        kmer_orientation=ori.data_ptr(), **extra)
+        torch.cuda.synchronize()
+        for f in U64_FIELDS:
+            assert (bufs[f].cpu().numpy().view(np.uint64) == want[f]).all(), f
+        assert (ori.cpu().numpy().astype(np.int64) == want["kmer_orientation"]).all()
 
 
 def test_batch_larger_than_one_launch_piece(case_se_regular):
