@@ -51,7 +51,8 @@
 //      minimizer the reference's `minimizer_found` flag depends on which (arbitrary) bucket the
 //      MPHF lands on. Built on the GPU at upload; SSHASH_AMD_DIRECTORY=0 disables it.
 //
-//  (5) k <= 31: a *super-k-mer table*, built on the GPU at upload from the strings alone. Structures
+//  (5) a *super-k-mer table*, built on the GPU at upload from the strings alone (described for k <= 31;
+//      for k <= 63 the slot is 64 bytes -- the same 16-byte head, then 128 bases -- and 48 of them are read). Structures
 //      (1)-(4) answer a positive lookup with two dependent random reads per probe (minimizer ->
 //      position, then the strings) and a regular index probes both strands (src/dictionary.cpp:70-75);
 //      what bounds the batch is the number of such reads. The table answers most lookups with ONE:
@@ -147,7 +148,7 @@ constexpr uint32_t SK_LIST_MAX = 64;          // longer occurrence lists are lef
 constexpr double SK_SLOTS_PER_KEY = 3.0;
 
 struct sk_view {
-    void const* slots;    // num_slots x 32 bytes
+    void const* slots;    // num_slots x 32 bytes (k <= 31) or x 64 bytes (k <= 63)
     uint64_t const* occ;  // occurrences of the list keys: (position << 1) | strand
     uint32_t num_slots;
     uint32_t enabled;
@@ -191,13 +192,14 @@ SSH_HD uint32_t sk_mmer_hash(uint64_t mmer) {
     return uint32_t(mmer) * 0x9E3779B1u + (uint32_t(mmer >> 32) * 0x85EBCA77u + 0x27D4EB2Fu);
 }
 
-SSH_HD sk_key_t sk_key(uint64_t x, uint64_t x_rc, uint32_t k, uint32_t m) {
+template <int W>
+SSH_HD sk_key_t sk_key(kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m) {
     const uint64_t mask = low_mask(2 * m);
     uint32_t best_f = 0xFFFFFFFFu, best_r = 0xFFFFFFFFu, pos_f = 0, pos_r = 0;
-    uint64_t f = x, r = x_rc;
+    kmer_w<W> f = x, r = x_rc;
     const uint32_t n = k - m + 1;
     for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t hf = sk_mmer_hash(f & mask), hr = sk_mmer_hash(r & mask);
+        const uint32_t hf = sk_mmer_hash(f.w[0] & mask), hr = sk_mmer_hash(r.w[0] & mask);
         if (hf < best_f) {
             best_f = hf;
             pos_f = i;
@@ -206,14 +208,21 @@ SSH_HD sk_key_t sk_key(uint64_t x, uint64_t x_rc, uint32_t k, uint32_t m) {
             best_r = hr;
             pos_r = i;
         }
-        f >>= 2;
-        r >>= 2;
+        if constexpr (W == 1) {
+            f.w[0] >>= 2;
+            r.w[0] >>= 2;
+        } else {
+            f.w[0] = (f.w[0] >> 2) | (f.w[1] << 62);
+            f.w[1] >>= 2;
+            r.w[0] = (r.w[0] >> 2) | (r.w[1] << 62);
+            r.w[1] >>= 2;
+        }
     }
     sk_key_t out;
     out.rc = best_r < best_f;
     out.tie = best_r == best_f;
     out.pos = out.rc ? pos_r : pos_f;
-    out.key = ((out.rc ? x_rc : x) >> (2 * out.pos)) & mask;
+    out.key = kmer_shr_chars<W>(out.rc ? x_rc : x, out.pos).w[0] & mask;
     return out;
 }
 

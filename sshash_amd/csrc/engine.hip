@@ -391,7 +391,7 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
         x = load_query<W, false>(queries, i, d.k);
     }
     fast_t r;
-    if constexpr (SK) r = sk_lookup_one(d, x, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1));
+    if constexpr (SK) r = sk_lookup_one<W>(d, x, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1));
     else r = fast_lookup_one<W, CANON>(d, x, check_rc);
     /* every lane stores first (a deferred lane's value is a placeholder that phase 2 overwrites), the
        queue push comes last: no lane leaves the wave between the probe and its store */
@@ -474,15 +474,10 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 const void* qa = static_cast<const char*>(q) + at * (ASCII ? kbytes : qbytes);
                 const result_view ids = advance(out, at);
                 uint8_t* mem = member ? member + at : nullptr;
-                bool through_table = false;
-                if constexpr (W == 1) {
-                    if (d.sk.enabled) {
-                        through_table = true;
-                        hipLaunchKernelGGL((fast_lookup_kernel<1, CANON, MODE, ASCII, true>), dim3(nblocks), dim3(block), 0, stream, d, qa,
-                                           m, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
-                    }
-                }
-                if (!through_table)
+                if (d.sk.enabled)
+                    hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII, true>), dim3(nblocks), dim3(block), 0, stream, d, qa,
+                                       m, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
+                else
                     hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII, false>), dim3(nblocks), dim3(block), 0, stream, d, qa,
                                        m, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
                 hipLaunchKernelGGL((deferred_lookup_kernel<W, CANON, MODE, ASCII>), dim3(DEFER_SHARDS * DEFER_BLOCKS_PER_SHARD), dim3(block), 0, stream, d,

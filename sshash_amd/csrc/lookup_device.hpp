@@ -426,23 +426,26 @@ __device__ __forceinline__ fast_t fast_lookup_one(dict_view const& d, kmer_w<W> 
     }
 }
 
-/* ---- lookup through the super-k-mer table (device_layout.hpp (5)), k <= 31 ----------------------
+/* ---- lookup through the super-k-mer table (device_layout.hpp (5)) -------------------------------
    sk_probe: follow the key's slot sequence. HIT / final MISS / DEFER to the complete path. `key_seen`:
    some slot on the way carried the key's fingerprint; a MISS without it proves that no k-mer with this
    key is in the dictionary (the streaming query's negative short-cut uses that). */
-__device__ __forceinline__ fast_t sk_probe(dict_view const& d, uint64_t x, uint64_t x_rc, sk_key_t const& kk, bool& key_seen) {
+template <int W>
+__device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
+                                           bool& key_seen) {
     const bool s = kk.rc;       // the key was read on the reverse complement of x
     const uint32_t j = kk.pos;  // where the key starts in y
-    const uint64_t y = s ? x_rc : x, y_rc = s ? x : x_rc;
+    const kmer_w<W> y = s ? x_rc : x, y_rc = s ? x : x_rc;
     const uint32_t km = d.k - d.m;
-    const uint64_t kmask = low_mask(2 * d.k);
     const sk_hash_t h = sk_hash(kk.key, d.sk.num_slots);
     fast_t r = fast_unsettled(false);
     key_seen = false;
 #pragma unroll 1
     for (uint32_t c = 0; c < SK_CHOICES; ++c) {
-        const uint4* S = reinterpret_cast<const uint4*>(d.sk.slots) + 2 * uint64_t(h.slot[c]);
+        const uint4* S = reinterpret_cast<const uint4*>(d.sk.slots) + (2 * W) * uint64_t(h.slot[c]);
         const uint4 q0 = S[0], q1 = S[1];
+        uint4 q2 = q1;
+        if constexpr (W == 2) q2 = S[2];
         const uint32_t meta = q0.x;
         /* decided now, in its own register: hipcc 7.2 has been seen recycling a slot word that is only
            consumed after the list scan */
@@ -458,10 +461,21 @@ __device__ __forceinline__ fast_t sk_probe(dict_view const& d, uint64_t x, uint6
                    No fingerprint test: the k-mer comparison is the test. */
                 const bool o = (meta & SK_STRAND) != 0;
                 const uint32_t a = o ? j : km - j;
-                const uint64_t lo = uint64_t(q1.x) | (uint64_t(q1.y) << 32), hi = uint64_t(q1.z) | (uint64_t(q1.w) << 32);
-                const uint64_t cand = funnel_shr(lo, hi, 2 * a) & kmask;
+                const uint64_t w0 = uint64_t(q1.x) | (uint64_t(q1.y) << 32), w1 = uint64_t(q1.z) | (uint64_t(q1.w) << 32);
+                kmer_w<W> cand;
+                if constexpr (W == 1) {
+                    cand.w[0] = funnel_shr(w0, w1, 2 * a);
+                } else {
+                    const uint64_t w2 = uint64_t(q2.x) | (uint64_t(q2.y) << 32), w3 = uint64_t(q2.z) | (uint64_t(q2.w) << 32);
+                    const bool up = 2 * a >= 64;  // a <= 62: the k-mer starts in word 0 or 1
+                    const uint32_t sh = (2 * a) & 63u;
+                    const uint64_t e0 = up ? w1 : w0, e1 = up ? w2 : w1, e2 = up ? w3 : w2;
+                    cand.w[0] = funnel_shr(e0, e1, sh);
+                    cand.w[1] = funnel_shr(e1, e2, sh);
+                }
+                cand = kmer_take_chars<W>(cand, d.k);
                 const uint32_t left = (meta >> SK_LEFT_SHIFT) & 63u, right = (meta >> SK_RIGHT_SHIFT) & 63u;
-                if (cand == (o ? y_rc : y) && a + left >= km && a <= right) {
+                if (kmer_eq<W>(cand, o ? y_rc : y) && a + left >= km && a <= right) {
                     r.kmer_offset = at + a - km;
                     r.string_id = q0.y;
                     r.orientation = (o != s) ? -1 : 1;
@@ -478,8 +492,8 @@ __device__ __forceinline__ fast_t sk_probe(dict_view const& d, uint64_t x, uint6
                     const uint64_t p = v >> 1;
                     const uint32_t a = o ? j : km - j;
                     if (p + a < km) continue;
-                    const window_t<1> w = read_window<1>(d.granules, p + a - km, d.k);
-                    if (w.kmer.w[0] == (o ? y_rc : y) && !w.crosses) {
+                    const window_t<W> w = read_window<W>(d.granules, p + a - km, d.k);
+                    if (kmer_eq<W>(w.kmer, o ? y_rc : y) && !w.crosses) {
                         r.kmer_offset = p + a - km;
                         r.string_id = w.string_id;
                         r.orientation = (o != s) ? -1 : 1;
@@ -498,12 +512,13 @@ __device__ __forceinline__ fast_t sk_probe(dict_view const& d, uint64_t x, uint6
 /* Same contract as fast_lookup_one. `allow_rc` false (regular dictionary, check_reverse_complement off:
    src/dictionary.cpp:70-71) turns a hit on the other strand into a miss. `miss_orientation`: what a miss
    reports (-1 after a regular dictionary's reverse-complement probe, src/dictionary.cpp:74-75). */
-__device__ __forceinline__ fast_t sk_lookup_one(dict_view const& d, kmer_w<1> const& x, bool allow_rc, int8_t miss_orientation) {
-    const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
-    const sk_key_t kk = sk_key(x.w[0], x_rc.w[0], d.k, d.m);
+template <int W>
+__device__ __forceinline__ fast_t sk_lookup_one(dict_view const& d, kmer_w<W> const& x, bool allow_rc, int8_t miss_orientation) {
+    const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
+    const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
     if (kk.tie) return fast_unsettled(true);  // no strand-symmetric key
     bool key_seen;
-    fast_t r = sk_probe(d, x.w[0], x_rc.w[0], kk, key_seen);
+    fast_t r = sk_probe<W>(d, x, x_rc, kk, key_seen);
     if (r.outcome == FAST_MISS || (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc)) {
         r = fast_unsettled(false);
         r.orientation = miss_orientation;

@@ -28,7 +28,7 @@ namespace {
 constexpr uint32_t WAVE = 64;
 constexpr uint32_t NEW_PER_WAVE = WAVE - 1;  // lane 0 only supplies its right neighbour's "previous"
 
-template <bool EMIT>
+template <int W, bool EMIT>
 __global__ void __launch_bounds__(256)
 sk_scan_kernel(const dict_view d, const uint64_t num_waves, uint32_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
                uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
@@ -39,11 +39,11 @@ sk_scan_kernel(const dict_view d, const uint64_t num_waves, uint32_t* __restrict
     const int64_t i = int64_t(wave * NEW_PER_WAVE + lane) - 1;
     uint64_t key = INVALID_U64, val = INVALID_U64;
     if (i >= 0 && uint64_t(i) + d.k <= d.num_bases) {
-        const window_t<1> w = read_window<1>(d.granules, uint64_t(i), d.k);
+        const window_t<W> w = read_window<W>(d.granules, uint64_t(i), d.k);
         if (!w.crosses) {
-            const kmer_w<1> x = w.kmer;
-            const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
-            const sk_key_t kk = sk_key(x.w[0], x_rc.w[0], d.k, d.m);
+            const kmer_w<W> x = w.kmer;
+            const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
+            const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
             if (!kk.tie) {
                 key = kk.key;
                 const uint64_t p = uint64_t(i) + (kk.rc ? (d.k - d.m) - kk.pos : kk.pos);
@@ -65,24 +65,41 @@ sk_scan_kernel(const dict_view d, const uint64_t num_waves, uint32_t* __restrict
     }
 }
 
-/* 64 bases starting at base `pos` (pos may be negative: the missing bases read as zero) */
-__device__ __forceinline__ void read_bases64(void const* __restrict__ atoms, int64_t pos, uint64_t& lo, uint64_t& hi) {
+/* 64*W bases starting at base `pos` (pos may be negative: the missing bases read as zero) */
+template <int W>
+__device__ __forceinline__ void read_bases(void const* __restrict__ blocks, int64_t pos, uint64_t (&out)[2 * W]) {
     const uint64_t from = pos < 0 ? 0 : uint64_t(pos);
-    const uint4* A = reinterpret_cast<const uint4*>(atoms) + 2 * (from >> 5);
     const uint32_t r = uint32_t(from) & 31u;
-    const uint4 a0 = A[0], a1 = A[2];  // bases of atom `from/32` and of the next atom
-    const uint64_t b0 = uint64_t(a0.x) | (uint64_t(a0.y) << 32), b1 = uint64_t(a0.z) | (uint64_t(a0.w) << 32);
-    const uint64_t b2 = uint64_t(a1.z) | (uint64_t(a1.w) << 32);
-    lo = funnel_shr(b0, b1, 2 * r);
-    hi = funnel_shr(b1, b2, 2 * r);
-    if (pos < 0) {
-        const uint32_t sh = 2 * uint32_t(-pos);  // 2..60
-        hi = (hi << sh) | (lo >> (64 - sh));
-        lo <<= sh;
+    uint64_t b[2 * W + 1];  // 32 bases each
+    if constexpr (W == 1) {
+        const uint4* A = reinterpret_cast<const uint4*>(blocks) + 2 * (from >> 5);
+        const uint4 a0 = A[0], a1 = A[2];  // bases of atom `from/32` and of the next atom
+        b[0] = uint64_t(a0.x) | (uint64_t(a0.y) << 32);
+        b[1] = uint64_t(a0.z) | (uint64_t(a0.w) << 32);
+        b[2] = uint64_t(a1.z) | (uint64_t(a1.w) << 32);
+    } else {
+        const uint4* G = reinterpret_cast<const uint4*>(blocks) + (from >> 5);
+        for (int i = 0; i < 2 * W + 1; ++i) {
+            const uint4 g = G[i];
+            b[i] = uint64_t(g.z) | (uint64_t(g.w) << 32);
+        }
+    }
+    for (int i = 0; i < 2 * W; ++i) out[i] = funnel_shr(b[i], b[i + 1], 2 * r);
+    if (pos < 0) {  // shift the whole window up by -pos bases (1 .. k-m <= 62)
+        const uint32_t bits = 2 * uint32_t(-pos);
+        const int ws = int(bits >> 6);
+        const uint32_t bs = bits & 63u;
+        uint64_t t[2 * W];
+        for (int i = 0; i < 2 * W; ++i) {
+            const uint64_t lo = i - ws - 1 >= 0 ? out[i - ws - 1] : 0, hi = i - ws >= 0 ? out[i - ws] : 0;
+            t[i] = (hi << bs) | (bs ? lo >> (64 - bs) : 0);
+        }
+        for (int i = 0; i < 2 * W; ++i) out[i] = t[i];
     }
 }
 
 /* One lane per key (run of the sorted tuples), one launch per slot choice. */
+template <int W>
 __global__ void __launch_bounds__(256)
 sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_keys, const uint64_t* __restrict__ keys,
                 const uint32_t* __restrict__ run_sizes, const uint32_t* __restrict__ run_begins, const uint64_t* __restrict__ occ,
@@ -93,7 +110,7 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_key
     if (r < num_keys && !placed[r]) {
         const uint64_t key = keys[r];
         const sk_hash_t h = sk_hash(key, num_slots);
-        uint32_t* S = slots + 8 * uint64_t(h.slot[choice]);
+        uint32_t* S = slots + (8 * W) * uint64_t(h.slot[choice]);
         /* claim: set the valid bit unless somebody holds it (other lanes may be OR-ing flags into the same word) */
         uint32_t cur = __hip_atomic_load(S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool mine = false;
@@ -113,32 +130,33 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_key
             const uint32_t size = run_sizes[r];
             const uint64_t begin = run_begins[r];
             uint32_t meta, d1;
-            uint64_t w1, w2, w3;
+            uint64_t w1;
+            uint64_t body[2 * W];
+            for (int i = 0; i < 2 * W; ++i) body[i] = 0;
             if (size == 1) {
                 const uint64_t v = occ[begin];
                 const uint64_t p = v >> 1;
                 const uint32_t km = d.k - d.m;
-                const uint32_t sid = read_window<1>(d.granules, p, 1).string_id;
+                const uint32_t sid = read_window<W>(d.granules, p, 1).string_id;
                 const uint64_t s_begin = d.endpoints[sid], s_end = d.endpoints[sid + 1];
                 const uint64_t left = p - s_begin < km ? p - s_begin : km;
                 const uint64_t right = s_end - (p + d.m) < km ? s_end - (p + d.m) : km;
                 meta = (uint32_t(v & 1) ? SK_STRAND : 0u) | (uint32_t(left) << SK_LEFT_SHIFT) | (uint32_t(right) << SK_RIGHT_SHIFT);
                 d1 = sid;
                 w1 = p | (uint64_t(h.fingerprint) << 40);
-                read_bases64(d.granules, int64_t(p) - int64_t(km), w2, w3);
+                read_bases<W>(d.granules, int64_t(p) - int64_t(km), body);
                 is_inline = true;
             } else {
                 meta = SK_LIST;
                 too_long = size > SK_LIST_MAX;
                 d1 = too_long ? 0u : size;
                 w1 = begin | (uint64_t(h.fingerprint) << 40);
-                w2 = size <= 2 ? occ[begin] : 0;
-                w3 = size == 2 ? occ[begin + 1] : 0;
+                body[0] = size <= 2 ? occ[begin] : 0;
+                body[1] = size == 2 ? occ[begin + 1] : 0;
             }
             S[1] = d1;
             reinterpret_cast<uint64_t*>(S)[1] = w1;
-            reinterpret_cast<uint64_t*>(S)[2] = w2;
-            reinterpret_cast<uint64_t*>(S)[3] = w3;
+            for (int i = 0; i < 2 * W; ++i) reinterpret_cast<uint64_t*>(S)[2 + i] = body[i];
             if (meta) atomicOr(S, meta);
         }
     }
@@ -188,7 +206,7 @@ void build_sk_table(device_replica& rep, host_index const& idx) {
     v.sk.enabled = 0;
     const char* env = std::getenv("SSHASH_AMD_SKTABLE");
     if (env && env[0] == '0') return;
-    if (idx.k > 31 || idx.num_shards > 1 || idx.num_kmers == 0) return;  // a shard holds only its own minimizers' buckets: keep its path
+    if (idx.num_shards > 1 || idx.num_kmers == 0) return;  // a shard holds only its own minimizers' buckets: keep its path
     if (idx.num_bases >= (uint64_t(1) << 39)) return;                       // positions are stored in 40 bits with a strand bit
 
     const uint64_t positions = idx.num_bases - idx.k + 1;
@@ -200,7 +218,9 @@ void build_sk_table(device_replica& rep, host_index const& idx) {
     temp_buffers tmp;
     uint32_t* counts = tmp.alloc<uint32_t>(num_waves);
     uint64_t* offsets = tmp.alloc<uint64_t>(num_waves + 1);
-    hipLaunchKernelGGL(sk_scan_kernel<false>, grid, block, 0, 0, v, num_waves, counts, nullptr, nullptr, nullptr);
+    const bool wide = idx.k > 31;
+    if (wide) hipLaunchKernelGGL((sk_scan_kernel<2, false>), grid, block, 0, 0, v, num_waves, counts, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((sk_scan_kernel<1, false>), grid, block, 0, 0, v, num_waves, counts, nullptr, nullptr, nullptr);
     HIP_CHECK(hipGetLastError());
     {
         /* exclusive scan of the per-wave counts into 64-bit offsets */
@@ -220,7 +240,8 @@ void build_sk_table(device_replica& rep, host_index const& idx) {
 
     uint64_t* keys = tmp.alloc<uint64_t>(T);
     uint64_t* vals = tmp.alloc<uint64_t>(T);
-    hipLaunchKernelGGL(sk_scan_kernel<true>, grid, block, 0, 0, v, num_waves, counts, offsets, keys, vals);
+    if (wide) hipLaunchKernelGGL((sk_scan_kernel<2, true>), grid, block, 0, 0, v, num_waves, counts, offsets, keys, vals);
+    else hipLaunchKernelGGL((sk_scan_kernel<1, true>), grid, block, 0, 0, v, num_waves, counts, offsets, keys, vals);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipDeviceSynchronize());
     tmp.release(counts);
@@ -257,11 +278,12 @@ void build_sk_table(device_replica& rep, host_index const& idx) {
         if (want >= 1.5 && want <= 16.0) slots_per_key = want;
     }
     const uint64_t num_slots = uint64_t(double(K) * slots_per_key) + 16;
+    const uint64_t slot_bytes = wide ? 64 : 32;
     if (K == 0 || num_slots >= (uint64_t(1) << 32)) return;
     {
         size_t free_bytes = 0, total_bytes = 0;
         HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
-        if (num_slots * 32 + K * 8 > free_bytes / 2) return;  // leave HBM for the caller's batches
+        if (num_slots * slot_bytes + K * 8 > free_bytes / 2) return;  // leave HBM for the caller's batches
     }
     uint32_t* run_begins = tmp.alloc<uint32_t>(K);
     {
@@ -271,15 +293,19 @@ void build_sk_table(device_replica& rep, host_index const& idx) {
         HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scratch, bytes, run_sizes, run_begins, int(K)));
         tmp.release(scratch);
     }
-    uint32_t* slots = tmp.alloc<uint32_t>(num_slots * 8);
+    uint32_t* slots = tmp.alloc<uint32_t>(num_slots * slot_bytes / 4);
     uint8_t* placed = tmp.alloc<uint8_t>(K);
     unsigned long long* stats = tmp.alloc<unsigned long long>(4);
-    HIP_CHECK(hipMemset(slots, 0, num_slots * 32));
+    HIP_CHECK(hipMemset(slots, 0, num_slots * slot_bytes));
     HIP_CHECK(hipMemset(placed, 0, K));
     HIP_CHECK(hipMemset(stats, 0, 32));
     for (uint32_t choice = 0; choice < SK_CHOICES; ++choice) {
-        hipLaunchKernelGGL(sk_place_kernel, dim3(uint32_t((K + 255) / 256)), block, 0, 0, v, choice, K, keys, run_sizes, run_begins, occ,
-                           slots, uint32_t(num_slots), placed, stats);
+        if (wide)
+            hipLaunchKernelGGL(sk_place_kernel<2>, dim3(uint32_t((K + 255) / 256)), block, 0, 0, v, choice, K, keys, run_sizes,
+                               run_begins, occ, slots, uint32_t(num_slots), placed, stats);
+        else
+            hipLaunchKernelGGL(sk_place_kernel<1>, dim3(uint32_t((K + 255) / 256)), block, 0, 0, v, choice, K, keys, run_sizes,
+                               run_begins, occ, slots, uint32_t(num_slots), placed, stats);
         HIP_CHECK(hipGetLastError());
     }
     unsigned long long h_stats[4];
@@ -290,7 +316,7 @@ void build_sk_table(device_replica& rep, host_index const& idx) {
     tmp.keep(occ);
     rep.allocations.push_back(slots);
     rep.allocations.push_back(occ);
-    rep.bytes += num_slots * 32 + T * 8;
+    rep.bytes += num_slots * slot_bytes + T * 8;
     rep.sk_keys = K;
     rep.sk_inline_keys = h_stats[0];
     rep.sk_long_lists = h_stats[1];

@@ -8,7 +8,7 @@ namespace sshash_amd {
 
 struct device_replica;
 
-/* Leaves rep.view.sk disabled when the table does not apply (k > 31, a minimizer shard, SSHASH_AMD_SKTABLE=0,
+/* Leaves rep.view.sk disabled when the table does not apply (a minimizer shard, SSHASH_AMD_SKTABLE=0,
    not enough free HBM). Runs on the current device. */
 void build_sk_table(device_replica& rep, host_index const& idx);
 

@@ -11,7 +11,7 @@
 //   * otherwise seed(): the negative short-cut (:150-157), then the point lookups (:159-180).
 //     Minimizers are only needed inside seed(), so they are computed there, statelessly
 //     (the rolling iterators of include/minimizer_iterator.hpp return the same values: :56-57).
-//     For k <= 31 seed() goes through the super-k-mer table (device_layout.hpp (5)): one slot read per
+//     When the replica has a super-k-mer table seed() goes through it (device_layout.hpp (5)): one slot read per
 //     seed instead of directory + window per strand. The negative short-cut becomes "same table key as
 //     the previous k-mer, and that key is provably not in the table" -- the same k-mers are negative
 //     either way, so the counters are unchanged; queries the table defers take the path above.
@@ -98,7 +98,7 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
             }
             /* seed() */
             if constexpr (SK) {
-                const sk_key_t kk = sk_key(x.w[0], x_rc.w[0], k, d.m);
+                const sk_key_t kk = sk_key<W>(x, x_rc, k, d.m);
                 if (!kk.tie) {
                     if (neg_unknown_mini && kk.key == prev_f) {
                         ++c_negative;
@@ -106,7 +106,7 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
                         continue;
                     }
                     bool key_seen;
-                    const fast_t r = sk_probe(d, x.w[0], x_rc.w[0], kk, key_seen);
+                    const fast_t r = sk_probe<W>(d, x, x_rc, kk, key_seen);
                     if (r.outcome != FAST_DEFER) {
                         if (r.outcome == FAST_HIT) {
                             ++c_searches;
@@ -171,15 +171,10 @@ void launch_streaming(dict_view const& d, skew_part_dev const* skew, char const*
     const uint32_t block = 256;
     uint64_t blocks = (n_reads + block - 1) / block;
     if (blocks > (uint64_t(1) << 20)) blocks = uint64_t(1) << 20;
-    bool through_table = false;
-    if constexpr (W == 1) {
-        if (d.sk.enabled) {
-            through_table = true;
-            hipLaunchKernelGGL((streaming_kernel<1, CANON, true>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
-                               offsets, n_reads, report);
-        }
-    }
-    if (!through_table)
+    if (d.sk.enabled)
+        hipLaunchKernelGGL((streaming_kernel<W, CANON, true>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
+                           offsets, n_reads, report);
+    else
         hipLaunchKernelGGL((streaming_kernel<W, CANON, false>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
                            offsets, n_reads, report);
     HIP_CHECK(hipGetLastError());

@@ -17,6 +17,7 @@ U64_FIELDS = ["kmer_id", "kmer_id_in_string", "kmer_offset", "string_id", "strin
 
 def _check_full(case, queries, check_rc=True):
     d = case.dict.to_device(0)
+    assert d.device_stats()["sk_slots"] > 0  # every k and flavour gets the super-k-mer table
     got = d.lookup(queries, check_reverse_complement=check_rc, full=True)
     want = case.oracle.lookup_packed(queries, check_rc)
     for f in U64_FIELDS:
