@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -658,33 +659,91 @@ void engine::access_packed_device(int device, uint64_t const* d_ids, uint64_t n,
     HIP_CHECK(hipGetLastError());
 }
 
-/* ---- host-buffer path: shard over replicas, chunk through device staging buffers ---------- */
+/* ---- host-buffer path -----------------------------------------------------------------------
+   The caller's arrays are pageable host memory. Per replica the batch is cut into chunks that several
+   *lanes* pull from a shared counter; a lane owns a HIP stream, a pinned staging block and a device block
+   and runs copy-in -> H2D -> kernels -> D2H -> copy-out for one chunk at a time. Lanes overlap one another,
+   so host copies, both PCIe directions and the kernels proceed concurrently without any lane having to be
+   asynchronous inside. Lanes (streams, pinned and device memory) are pooled in the replica across calls. */
 
 namespace {
 
-struct staging {  // per-device scratch for one chunk
-    void* d_in = nullptr;
-    result_view d_out{};
-    uint8_t* d_member = nullptr;
-    std::vector<void*> owned;
-    template <typename T>
-    T* alloc(uint64_t n) {
-        void* p = nullptr;
-        HIP_CHECK(hipMalloc(&p, std::max<uint64_t>(n, 1) * sizeof(T)));
-        owned.push_back(p);
-        return static_cast<T*>(p);
-    }
-    ~staging() {
-        for (void* p : owned) (void)hipFree(p);
-    }
+constexpr uint64_t HOST_CHUNK = uint64_t(1) << 21;  // queries per lane round
+constexpr uint32_t HOST_LANES_MAX = 8;
+
+uint64_t env_u64(char const* name, uint64_t fallback, uint64_t lo, uint64_t hi) {  // measurement knobs
+    char const* e = std::getenv(name);
+    if (!e) return fallback;
+    const uint64_t v = std::strtoull(e, nullptr, 10);
+    return v >= lo && v <= hi ? v : fallback;
+}
+
+uint64_t align256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
+
+struct field_plan {  // where each output of a chunk lives inside the staging block
+    uint64_t in_bytes = 0, out_bytes = 0;
+    uint64_t at[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // sshash_results order; member shares slot 0
+    bool wanted[8] = {false, false, false, false, false, false, false, false};
 };
 
-template <typename T>
-void copy_back(T* h, T const* d, uint64_t off, uint64_t n, hipStream_t s) {
-    if (h) HIP_CHECK(hipMemcpyAsync(h + off, d, n * sizeof(T), hipMemcpyDeviceToHost, s));
+field_plan plan_fields(out_mode mode, result_view const& h_out, uint64_t chunk, uint64_t bytes_per_query) {
+    field_plan p;
+    p.in_bytes = align256(chunk * bytes_per_query);
+    uint64_t at = 0;
+    auto add = [&](int f, bool wanted, uint64_t width) {
+        p.wanted[f] = wanted;
+        if (!wanted) return;
+        p.at[f] = at;
+        at += align256(chunk * width);
+    };
+    if (mode == out_mode::member) {
+        add(0, true, 1);
+    } else {
+        add(0, true, 8);
+        const bool full = mode == out_mode::full;
+        add(1, full && h_out.kmer_id_in_string, 8);
+        add(2, full && h_out.kmer_offset, 8);
+        add(3, full && h_out.string_id, 8);
+        add(4, full && h_out.string_begin, 8);
+        add(5, full && h_out.string_end, 8);
+        add(6, full && h_out.kmer_orientation, 1);
+        add(7, full && h_out.minimizer_found, 1);
+    }
+    p.out_bytes = at;
+    return p;
 }
 
 }  // namespace
+
+host_lane* device_replica::acquire_lane(size_t bytes) const {
+    host_lane* lane = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(lanes_mutex);
+        if (!idle_lanes.empty()) {
+            lane = idle_lanes.back();
+            idle_lanes.pop_back();
+        }
+    }
+    if (!lane) {
+        lane = new host_lane();
+        HIP_CHECK(hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking));
+    }
+    if (lane->capacity < bytes) {
+        if (lane->pinned) HIP_CHECK(hipHostFree(lane->pinned));
+        if (lane->device) HIP_CHECK(hipFree(lane->device));
+        lane->pinned = lane->device = nullptr;
+        lane->capacity = 0;
+        HIP_CHECK(hipHostMalloc(&lane->pinned, bytes, hipHostMallocDefault));
+        HIP_CHECK(hipMalloc(&lane->device, bytes));
+        lane->capacity = bytes;
+    }
+    return lane;
+}
+
+void device_replica::release_lane(host_lane* lane) const {
+    std::lock_guard<std::mutex> lock(lanes_mutex);
+    idle_lanes.push_back(lane);
+}
 
 template <bool ASCII>
 static void host_lookup(engine const& eng, std::vector<int> const& devs, void const* h_in, uint64_t bytes_per_query,
@@ -693,66 +752,91 @@ static void host_lookup(engine const& eng, std::vector<int> const& devs, void co
     if (n == 0) return;
     if (devs.empty()) throw error(error_kind::no_device, "dictionary is not resident on any device (call sshash_to_device first)");
     const uint64_t G = devs.size();
-    const uint64_t chunk = uint64_t(1) << 24;  // queries per device round
-    std::vector<std::exception_ptr> errors(G);
-    std::vector<std::thread> workers;
+    const uint64_t chunk = std::min<uint64_t>(env_u64("SSHASH_AMD_HOST_CHUNK", HOST_CHUNK, 1024, uint64_t(1) << 26), n);
+    const uint64_t max_lanes = env_u64("SSHASH_AMD_HOST_LANES", HOST_LANES_MAX, 1, 64);
+    const field_plan plan = plan_fields(mode, h_out, chunk, bytes_per_query);
+    const uint64_t hw = std::max(1u, std::thread::hardware_concurrency());
+
+    struct share {  // one per device: its slice of the batch, handed out chunk by chunk
+        uint64_t lo = 0, hi = 0;
+        std::atomic<uint64_t> next{0};
+    };
+    std::vector<share> shares(G);
+    std::vector<std::pair<uint64_t, uint32_t>> lanes;  // (device index, lane index)
     for (uint64_t g = 0; g < G; ++g) {
-        workers.emplace_back([&, g] {
-            try {
-                const uint64_t lo = n * g / G, hi = n * (g + 1) / G;
-                if (lo == hi) return;
-                HIP_CHECK(hipSetDevice(devs[g]));
-                hipStream_t s;
-                HIP_CHECK(hipStreamCreate(&s));
-                {
-                    staging st;
-                    const uint64_t c = std::min(chunk, hi - lo);
-                    st.d_in = st.alloc<uint8_t>(c * bytes_per_query);
-                    if (mode == out_mode::member) st.d_member = st.alloc<uint8_t>(c);
-                    else {
-                        st.d_out.kmer_id = st.alloc<uint64_t>(c);
-                        if (mode == out_mode::full) {
-                            if (h_out.kmer_id_in_string) st.d_out.kmer_id_in_string = st.alloc<uint64_t>(c);
-                            if (h_out.kmer_offset) st.d_out.kmer_offset = st.alloc<uint64_t>(c);
-                            if (h_out.string_id) st.d_out.string_id = st.alloc<uint64_t>(c);
-                            if (h_out.string_begin) st.d_out.string_begin = st.alloc<uint64_t>(c);
-                            if (h_out.string_end) st.d_out.string_end = st.alloc<uint64_t>(c);
-                            if (h_out.kmer_orientation) st.d_out.kmer_orientation = st.alloc<int8_t>(c);
-                            if (h_out.minimizer_found) st.d_out.minimizer_found = st.alloc<uint8_t>(c);
-                        }
-                    }
-                    for (uint64_t at = lo; at < hi; at += c) {
-                        const uint64_t m = std::min(c, hi - at);
-                        HIP_CHECK(hipMemcpyAsync(st.d_in, static_cast<uint8_t const*>(h_in) + at * bytes_per_query,
-                                                 m * bytes_per_query, hipMemcpyHostToDevice, s));
-                        if (ASCII)
-                            eng.lookup_ascii_device(devs[g], static_cast<char const*>(st.d_in), m, check_rc, mode, st.d_out,
-                                                    st.d_member, s);
-                        else
-                            eng.lookup_packed_device(devs[g], static_cast<uint64_t const*>(st.d_in), m, check_rc, mode,
-                                                     st.d_out, st.d_member, s);
-                        if (mode == out_mode::member) copy_back(h_member, st.d_member, at, m, s);
-                        else {
-                            copy_back(h_out.kmer_id, st.d_out.kmer_id, at, m, s);
-                            if (mode == out_mode::full) {
-                                copy_back(h_out.kmer_id_in_string, st.d_out.kmer_id_in_string, at, m, s);
-                                copy_back(h_out.kmer_offset, st.d_out.kmer_offset, at, m, s);
-                                copy_back(h_out.string_id, st.d_out.string_id, at, m, s);
-                                copy_back(h_out.string_begin, st.d_out.string_begin, at, m, s);
-                                copy_back(h_out.string_end, st.d_out.string_end, at, m, s);
-                                copy_back(h_out.kmer_orientation, st.d_out.kmer_orientation, at, m, s);
-                                copy_back(h_out.minimizer_found, st.d_out.minimizer_found, at, m, s);
-                            }
-                        }
-                        HIP_CHECK(hipStreamSynchronize(s));
-                    }
-                }
-                eng.release_stream(devs[g], s);
-                HIP_CHECK(hipStreamDestroy(s));
-            } catch (...) { errors[g] = std::current_exception(); }
-        });
+        shares[g].lo = n * g / G;
+        shares[g].hi = n * (g + 1) / G;
+        shares[g].next = shares[g].lo;
+        const uint64_t chunks = (shares[g].hi - shares[g].lo + chunk - 1) / chunk;
+        const uint64_t want = std::min<uint64_t>({chunks, max_lanes, std::max<uint64_t>(1, hw / G)});
+        for (uint32_t l = 0; l < want; ++l) lanes.emplace_back(g, l);
     }
-    for (auto& w : workers) w.join();
+    std::vector<std::exception_ptr> errors(lanes.size());
+
+    auto run_lane = [&](size_t li) {
+        try {
+            const uint64_t g = lanes[li].first;
+            device_replica const* rep = eng.replica_of(devs[g]);
+            HIP_CHECK(hipSetDevice(devs[g]));
+            host_lane* lane = rep->acquire_lane(plan.in_bytes + plan.out_bytes);
+            struct give_back {
+                device_replica const* rep;
+                host_lane* lane;
+                ~give_back() { rep->release_lane(lane); }
+            } guard{rep, lane};
+            hipStream_t s = lane->stream;
+            char* hp = static_cast<char*>(lane->pinned);
+            char* dp = static_cast<char*>(lane->device);
+            char* h_out_block = hp + plan.in_bytes;
+            char* d_out_block = dp + plan.in_bytes;
+            result_view d_out{};
+            uint8_t* d_member = nullptr;
+            if (mode == out_mode::member) d_member = reinterpret_cast<uint8_t*>(d_out_block + plan.at[0]);
+            else {
+                d_out.kmer_id = reinterpret_cast<uint64_t*>(d_out_block + plan.at[0]);
+                if (plan.wanted[1]) d_out.kmer_id_in_string = reinterpret_cast<uint64_t*>(d_out_block + plan.at[1]);
+                if (plan.wanted[2]) d_out.kmer_offset = reinterpret_cast<uint64_t*>(d_out_block + plan.at[2]);
+                if (plan.wanted[3]) d_out.string_id = reinterpret_cast<uint64_t*>(d_out_block + plan.at[3]);
+                if (plan.wanted[4]) d_out.string_begin = reinterpret_cast<uint64_t*>(d_out_block + plan.at[4]);
+                if (plan.wanted[5]) d_out.string_end = reinterpret_cast<uint64_t*>(d_out_block + plan.at[5]);
+                if (plan.wanted[6]) d_out.kmer_orientation = reinterpret_cast<int8_t*>(d_out_block + plan.at[6]);
+                if (plan.wanted[7]) d_out.minimizer_found = reinterpret_cast<uint8_t*>(d_out_block + plan.at[7]);
+            }
+            for (;;) {
+                const uint64_t at = shares[g].next.fetch_add(chunk);
+                if (at >= shares[g].hi) break;
+                const uint64_t m = std::min(chunk, shares[g].hi - at);
+                std::memcpy(hp, static_cast<char const*>(h_in) + at * bytes_per_query, m * bytes_per_query);
+                HIP_CHECK(hipMemcpyAsync(dp, hp, m * bytes_per_query, hipMemcpyHostToDevice, s));
+                if (ASCII) eng.lookup_ascii_device(devs[g], dp, m, check_rc, mode, d_out, d_member, s);
+                else eng.lookup_packed_device(devs[g], reinterpret_cast<uint64_t const*>(dp), m, check_rc, mode, d_out, d_member, s);
+                HIP_CHECK(hipMemcpyAsync(h_out_block, d_out_block, plan.out_bytes, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                if (mode == out_mode::member) std::memcpy(h_member + at, h_out_block + plan.at[0], m);
+                else {
+                    std::memcpy(h_out.kmer_id + at, h_out_block + plan.at[0], m * 8);
+                    if (plan.wanted[1]) std::memcpy(h_out.kmer_id_in_string + at, h_out_block + plan.at[1], m * 8);
+                    if (plan.wanted[2]) std::memcpy(h_out.kmer_offset + at, h_out_block + plan.at[2], m * 8);
+                    if (plan.wanted[3]) std::memcpy(h_out.string_id + at, h_out_block + plan.at[3], m * 8);
+                    if (plan.wanted[4]) std::memcpy(h_out.string_begin + at, h_out_block + plan.at[4], m * 8);
+                    if (plan.wanted[5]) std::memcpy(h_out.string_end + at, h_out_block + plan.at[5], m * 8);
+                    if (plan.wanted[6]) std::memcpy(h_out.kmer_orientation + at, h_out_block + plan.at[6], m);
+                    if (plan.wanted[7]) std::memcpy(h_out.minimizer_found + at, h_out_block + plan.at[7], m);
+                }
+            }
+        } catch (...) { errors[li] = std::current_exception(); }
+    };
+
+    int prev = 0;
+    HIP_CHECK(hipGetDevice(&prev));
+    if (lanes.size() == 1) {
+        run_lane(0);  // small batch on one device: no thread at all
+    } else {
+        std::vector<std::thread> workers;
+        for (size_t li = 0; li < lanes.size(); ++li) workers.emplace_back(run_lane, li);
+        for (auto& w : workers) w.join();
+    }
+    (void)hipSetDevice(prev);
     for (auto const& e : errors)
         if (e) std::rethrow_exception(e);
 }

@@ -79,6 +79,7 @@ public:
 private:
     device_replica const* replica(int device) const;
 public:
+    device_replica const* replica_of(int device) const { return replica(device); }
     /* drop the per-stream scratch of a stream the caller is about to destroy */
     void release_stream(int device, void* stream) const;
 

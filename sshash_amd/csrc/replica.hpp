@@ -31,6 +31,14 @@ struct device_guard {
     }
 };
 
+/* one pipeline of the host-buffer entry points: stream + pinned staging block + device block (engine.hip) */
+struct host_lane {
+    hipStream_t stream = nullptr;
+    void* pinned = nullptr;
+    void* device = nullptr;
+    size_t capacity = 0;
+};
+
 struct device_replica {
     int device = -1;
     uint64_t bytes = 0;
@@ -69,6 +77,12 @@ struct device_replica {
         scratch.erase(it);
     }
 
+    /* pooled lanes of the host-buffer path */
+    mutable std::mutex lanes_mutex;
+    mutable std::vector<host_lane*> idle_lanes;
+    host_lane* acquire_lane(size_t bytes) const;
+    void release_lane(host_lane* lane) const;
+
     template <typename T>
     T* put(std::vector<T> const& v) {
         T* d = nullptr;
@@ -97,6 +111,12 @@ struct device_replica {
         for (void* p : allocations) (void)hipFree(p);
         for (auto& kv : scratch)
             if (kv.second.first) (void)hipFree(kv.second.first);
+        for (host_lane* lane : idle_lanes) {
+            if (lane->pinned) (void)hipHostFree(lane->pinned);
+            if (lane->device) (void)hipFree(lane->device);
+            if (lane->stream) (void)hipStreamDestroy(lane->stream);
+            delete lane;
+        }
         (void)hipSetDevice(prev);
     }
 };

@@ -93,11 +93,18 @@ def main():
         assert torch.equal(out, out2), "ASCII and packed entry points disagree"
         del da, ascii_q, codes
     # host buffers (pageable), PCIe inclusive
-    m = min(n, 20_000_000)
+    m = n
     t0 = time.perf_counter()
     ids = d.lookup(q[: m * W]).kmer_id
     t = time.perf_counter() - t0
-    report("host_buffers_packed_mix50_pcie_inclusive", t * 1e3, units=m)
+    report("host_buffers_packed_mix50_pcie_inclusive_first_call", t * 1e3, units=m)  # creates the pinned lanes
+    assert (ids == out[:m].cpu().numpy().view(np.uint64)).all()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ids = d.lookup(q[: m * W]).kmer_id
+        best = min(best, time.perf_counter() - t0)
+    report("host_buffers_packed_mix50_pcie_inclusive", best * 1e3, units=m)
     assert (ids == out[:m].cpu().numpy().view(np.uint64)).all()
 
     if not args.skip_streaming:
