@@ -247,9 +247,6 @@ struct dict_view {
     directory_view directory;
     sk_view sk;
 
-    mphf_view skew_f[8];
-    uint64_t const* skew_pos[8];
-    uint32_t skew_pos_width[8];
 };
 
 /* Struct-of-arrays lookup output; any pointer except kmer_id may be null.

@@ -776,7 +776,7 @@ static void host_lookup(engine const& eng, std::vector<int> const& devs, void co
     auto run_lane = [&](size_t li) {
         try {
             const uint64_t g = lanes[li].first;
-            device_replica const* rep = eng.replica_of(devs[g]);
+            device_replica const* rep = eng.replica(devs[g]);
             HIP_CHECK(hipSetDevice(devs[g]));
             host_lane* lane = rep->acquire_lane(plan.in_bytes + plan.out_bytes);
             struct give_back {
@@ -840,8 +840,6 @@ static void host_lookup(engine const& eng, std::vector<int> const& devs, void co
     for (auto const& e : errors)
         if (e) std::rethrow_exception(e);
 }
-
-void engine::release_stream(int device, void* stream) const { replica(device)->scratch_release(stream); }
 
 void engine::lookup_packed_host(uint64_t const* h_kmers, uint64_t n, bool check_rc, out_mode mode,
                                 result_view const& h_out, uint8_t* h_member) const {

@@ -19,10 +19,6 @@ struct streaming_report {  // streaming_query_report, include/util.hpp:21-36
              num_searches = 0, num_extensions = 0;
 };
 
-struct launch_timing {  // filled when the caller asks for device-side timing
-    float kernel_ms = 0.f;
-};
-
 class engine {
 public:
     explicit engine(std::shared_ptr<host_index> idx);
@@ -76,12 +72,8 @@ public:
     void streaming_query_device(int device, char const* d_bases, uint64_t const* d_read_offsets, uint64_t n_reads,
                                 uint64_t total_bases, uint64_t* d_report, void* stream) const;
 
-private:
+    /* the replica resident on `device` (throws when there is none); internal to the .hip files */
     device_replica const* replica(int device) const;
-public:
-    device_replica const* replica_of(int device) const { return replica(device); }
-    /* drop the per-stream scratch of a stream the caller is about to destroy */
-    void release_stream(int device, void* stream) const;
 
 private:
     std::shared_ptr<host_index> m_idx;

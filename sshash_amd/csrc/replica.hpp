@@ -51,7 +51,8 @@ struct device_replica {
 
     /* Per-stream scratch for the deferred-query queue of the two-phase lookup. Work on one stream is
        ordered, so a buffer keyed by the stream can be reused without synchronisation; it only grows
-       (hipFree of the old block synchronises implicitly). */
+       (hipFree of the old block synchronises implicitly) and lives as long as the replica: the caller's
+       streams are few and the host path's lanes keep theirs. */
     mutable std::mutex scratch_mutex;
     mutable std::unordered_map<void*, std::pair<void*, size_t>> scratch;
     void* scratch_for(void* stream, size_t bytes) const {
@@ -66,15 +67,6 @@ struct device_replica {
             slot.second = want;
         }
         return slot.first;
-    }
-
-    /* a stream that is about to be destroyed gives its scratch back (the caller has synchronised it) */
-    void scratch_release(void* stream) const {
-        std::lock_guard<std::mutex> lock(scratch_mutex);
-        auto it = scratch.find(stream);
-        if (it == scratch.end()) return;
-        if (it->second.first) (void)hipFree(it->second.first);
-        scratch.erase(it);
     }
 
     /* pooled lanes of the host-buffer path */
