@@ -47,7 +47,8 @@ typedef struct sshash_build_config {
     uint32_t num_threads; /* default 1; 0 = hardware concurrency */
     double lambda;        /* default 5.0 */
     uint32_t verbose;
-    uint32_t reserved;
+    uint32_t weighted;    /* build_configuration::weighted: FASTA headers carry '>[id] LN:i:[len] ab:Z:[weights]'
+                             (src/builder/encode_strings.cpp:83-135); sshash_build_from_fasta only */
     /* minimizer-sharded build for dictionaries larger than one GPU's HBM: keep only the buckets of the
      * minimizers owned by shard `shard_id` of `num_shards` (strings stay complete). 0/1 = whole index. */
     uint32_t num_shards;
@@ -63,7 +64,7 @@ typedef struct sshash_info {
     uint64_t num_kmers, num_strings, num_bases, num_minimizers;
     uint64_t num_bits;      /* dictionary::num_bits(), host representation */
     uint32_t skew_partitions;
-    uint32_t reserved;
+    uint32_t weighted;   /* dictionary::weighted() */
     uint32_t num_shards; /* 1 unless built as one shard of a minimizer-partitioned index */
     uint32_t shard_id;
 } sshash_info;
@@ -143,6 +144,14 @@ sshash_status sshash_access_packed(const sshash_dict* d, const uint64_t* kmer_id
 /* the same on the GPU: device pointers, asynchronous; an id >= num_kmers yields all-ones words */
 sshash_status sshash_access_packed_device(const sshash_dict* d, int device, const uint64_t* kmer_ids, uint64_t n,
                                           uint64_t* out_words, void* hip_stream);
+
+/* ---- dictionary::weight(kmer_id): include/dictionary.hpp (weight), src/dictionary.cpp:96-100,
+ *      include/weights.hpp:147-152. Batched; SSHASH_ERR_ARGUMENT when the dictionary stores no weights
+ *      (the reference's checker refuses it the same way, test/check_from_file.hpp:234-237) or an id is
+ *      >= num_kmers (host variant; the device variant writes UINT64_MAX for such an id). */
+sshash_status sshash_weight(const sshash_dict* d, const uint64_t* kmer_ids, uint64_t n, uint64_t* out_weights);
+sshash_status sshash_weight_device(const sshash_dict* d, int device, const uint64_t* kmer_ids, uint64_t n,
+                                   uint64_t* out_weights, void* hip_stream);
 
 /* ---- dictionary::kmer_neighbours(Kmer, bool): include/dictionary.hpp:59-61, src/dictionary.cpp:111-126,176-187.
  *      Batched: every array of `out` holds 8*n entries; entry 8*i + c (c = 0..3) is the lookup of the forward

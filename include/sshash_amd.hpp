@@ -146,6 +146,14 @@ public:
         return ids;
     }
 
+    /* Return the weight of the kmer given its id -- include/dictionary.hpp (weight), src/dictionary.cpp:96-100 */
+    bool weighted() const { return m_info.weighted != 0; }
+    uint64_t weight(uint64_t kmer_id) const {
+        uint64_t w = 0;
+        check(sshash_weight(m_h, &kmer_id, 1, &w));
+        return w;
+    }
+
     /* Membership queries -- include/dictionary.hpp:74-76 */
     bool is_member(char const* string_kmer, bool check_reverse_complement = true) const {
         uint8_t out = 0;

@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         L.oracle_count_bytes.restype = C.c_uint64
         L.oracle_count_bytes.argtypes = [P, P, C.c_uint64, C.c_int]
         L.oracle_access.argtypes = [P, C.c_uint64, P]
+        L.oracle_weights.argtypes = [P, P, C.c_uint64, P]
+        L.oracle_weights.restype = C.c_int
         L.oracle_streaming_query.argtypes = [P, P, P, C.c_uint64, P]
         L.oracle_streaming_read.argtypes = [P, P, C.c_uint64, P]
         L.oracle_encode_kmer.argtypes = [C.c_char_p, C.c_uint32, P]
@@ -129,6 +131,14 @@ class OracleIndex:
     def count_bytes(self, kmers: np.ndarray, check_rc: bool = True) -> int:
         a = np.ascontiguousarray(kmers, dtype=np.uint64)
         return int(lib().oracle_count_bytes(self._h, a.ctypes.data, a.size // self.W, int(check_rc)))
+
+    def weights(self, kmer_ids) -> np.ndarray:
+        """weights::weight for each id (reference include/weights.hpp:147-152)."""
+        ids = np.ascontiguousarray(kmer_ids, dtype=np.uint64)
+        out = np.empty(ids.size, dtype=np.uint64)
+        if not lib().oracle_weights(self._h, ids.ctypes.data, ids.size, out.ctypes.data):
+            raise ValueError("the dictionary does not store weights (or id out of range)")
+        return out
 
     def access(self, kmer_id: int) -> str:
         buf = C.create_string_buffer(self.k)

@@ -59,6 +59,10 @@ struct oracle_index {
     mphf skew_f[8];
     cvec skew_pos[8];
     cvec heavy_load;
+    /* weights (include/weights.hpp): interval i = ids [weight_starts[i], weight_starts[i+1]) -> weight_values[i] */
+    uint64_t* weight_starts;
+    uint64_t* weight_values;
+    uint64_t num_weight_intervals;
 };
 
 /* optional per-query instrumentation: distinct 64-bit words touched */
@@ -521,6 +525,31 @@ uint64_t oracle_count_bytes(const oracle_index* d, const uint64_t* kmers, uint64
 }
 
 /* spss::access, include/spectrum_preserving_string_set.hpp:114-118 with id_to_offset (include/offsets.hpp:41-65) */
+/* dictionary::weight (src/dictionary.cpp:96-100) -> weights::weight (include/weights.hpp:147-152):
+   prev_leq(kmer_id) over the cumulative interval lengths, then the interval's value. Returns 0 and sets
+   *ok = 0 when the dictionary stores no weights (test/check_from_file.hpp:234-237) or the id is out of range. */
+uint64_t oracle_weight(const oracle_index* d, uint64_t kmer_id, int* ok) {
+    *ok = 0;
+    if (d->num_weight_intervals == 0 || kmer_id >= d->num_kmers) return 0;
+    uint64_t lo = 0, hi = d->num_weight_intervals - 1; /* largest i with weight_starts[i] <= kmer_id */
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (d->weight_starts[mid] <= kmer_id) lo = mid;
+        else hi = mid - 1;
+    }
+    *ok = 1;
+    return d->weight_values[lo];
+}
+
+int oracle_weights(const oracle_index* d, const uint64_t* kmer_ids, uint64_t n, uint64_t* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        int ok;
+        out[i] = oracle_weight(d, kmer_ids[i], &ok);
+        if (!ok) return 0;
+    }
+    return 1;
+}
+
 void oracle_access(const oracle_index* d, uint64_t kmer_id, char* out) {
     uint64_t lo = 0, hi = d->num_strings - 1;
     while (lo < hi) {
@@ -767,7 +796,7 @@ int oracle_load(const char* filename, oracle_index** out, char* err, int err_len
     uint8_t hdr[4];
     uint32_t kms[3];
     rd_raw(&r, magic, 8);
-    if (!r.ok || memcmp(magic, "SSHAMD\x02\x00", 8) != 0) {
+    if (!r.ok || memcmp(magic, "SSHAMD\x03\x00", 8) != 0) {
         snprintf(err, (size_t)err_len, "not an sshash_amd index file");
         fclose(f);
         free(d);
@@ -809,6 +838,8 @@ int oracle_load(const char* filename, oracle_index** out, char* err, int err_len
         rd_cvec(&r, &d->skew_pos[p]);
     }
     rd_cvec(&r, &d->heavy_load);
+    d->weight_starts = (uint64_t*)rd_vec(&r, 8, &d->num_weight_intervals);
+    d->weight_values = (uint64_t*)rd_vec(&r, 8, &cnt);
     fclose(f);
     if (!r.ok) {
         snprintf(err, (size_t)err_len, "index file truncated or corrupt");
@@ -838,6 +869,8 @@ void oracle_free(oracle_index* d) {
         free(d->skew_pos[p].words);
     }
     free(d->heavy_load.words);
+    free(d->weight_starts);
+    free(d->weight_values);
     free(d);
 }
 

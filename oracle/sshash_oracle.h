@@ -61,6 +61,9 @@ void oracle_lookup_ids(const oracle_index* idx, const uint64_t* kmers, uint64_t 
  * endpoint `locate` is charged 24 B. */
 uint64_t oracle_count_bytes(const oracle_index* idx, const uint64_t* kmers, uint64_t n, int check_rc);
 void oracle_access(const oracle_index* idx, uint64_t kmer_id, char* out_k_chars);
+/* weights::weight, include/weights.hpp:147-152; *ok = 0 when there are no weights / the id is out of range */
+uint64_t oracle_weight(const oracle_index* idx, uint64_t kmer_id, int* ok);
+int oracle_weights(const oracle_index* idx, const uint64_t* kmer_ids, uint64_t n, uint64_t* out); /* 1 = all ok */
 
 /* ---- streaming query: report = {num_kmers, positive, negative, invalid, searches, extensions} ---- */
 void oracle_streaming_query(const oracle_index* idx, const char* bases, const uint64_t* read_offsets, uint64_t num_reads,

@@ -36,7 +36,7 @@ class _BuildConfig(C.Structure):
         ("num_threads", C.c_uint32),
         ("lambda_", C.c_double),
         ("verbose", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("weighted", C.c_uint32),
         ("num_shards", C.c_uint32),
         ("shard_id", C.c_uint32),
     ]
@@ -55,7 +55,7 @@ class _Info(C.Structure):
         ("num_minimizers", C.c_uint64),
         ("num_bits", C.c_uint64),
         ("skew_partitions", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("weighted", C.c_uint32),
         ("num_shards", C.c_uint32),
         ("shard_id", C.c_uint32),
     ]
@@ -146,6 +146,8 @@ def _load() -> C.CDLL:
         "sshash_is_member_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, P, P]),
         "sshash_is_member_packed": (C.c_int, [P, P, C.c_uint64, C.c_int, P]),
         "sshash_is_member_ascii": (C.c_int, [P, P, C.c_uint64, C.c_int, P]),
+        "sshash_weight": (C.c_int, [P, P, C.c_uint64, P]),
+        "sshash_weight_device": (C.c_int, [P, C.c_int, P, C.c_uint64, P, P]),
         "sshash_access": (C.c_int, [P, C.c_uint64, P]),
         "sshash_access_packed": (C.c_int, [P, P, C.c_uint64, P]),
         "sshash_access_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, P, P]),
@@ -168,7 +170,7 @@ C_ABI_SYMBOLS = (
     "sshash_lookup_packed_device sshash_lookup_ascii_device sshash_lookup_packed sshash_lookup_ascii "
     "sshash_neighbours_packed_device sshash_neighbours_packed "
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
-    "sshash_access_packed_device "
+    "sshash_access_packed_device sshash_weight sshash_weight_device "
     "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device "
     "sshash_route_packed_device"
 ).split()
@@ -248,10 +250,12 @@ class Dictionary:
     @classmethod
     def build(cls, input_filename: str, k: int = 31, m: int = 20, seed: int = 1, canonical: bool = False,
               num_threads: int = 0, lambda_: float = 5.0, verbose: bool = False, num_shards: int = 1,
-              shard_id: int = 0) -> "Dictionary":
+              shard_id: int = 0, weighted: bool = False) -> "Dictionary":
         """dictionary::build(input_filename, build_configuration) -- reference include/dictionary.hpp:28.
-        num_shards > 1: build only the part of the sparse-and-skew index owned by `shard_id`."""
+        num_shards > 1: build only the part of the sparse-and-skew index owned by `shard_id`.
+        weighted: the FASTA headers carry the k-mer abundances (build_configuration::weighted)."""
         cfg = cls._config(k, m, seed, canonical, num_threads, lambda_, verbose, num_shards, shard_id)
+        cfg.weighted = 1 if weighted else 0
         h = C.c_void_p()
         _check(_load().sshash_build_from_fasta(os.fsencode(input_filename), C.byref(cfg), C.byref(h)))
         return cls(h.value)
@@ -304,6 +308,7 @@ class Dictionary:
     def vnum(self): return tuple(self._info.version)
     def num_shards(self) -> int: return int(self._info.num_shards)
     def shard_id(self) -> int: return int(self._info.shard_id)
+    def weighted(self) -> bool: return bool(self._info.weighted)
 
     # ---- device residency -----------------------------------------------------------------
     def to_device(self, device: int = 0) -> "Dictionary":
@@ -427,6 +432,18 @@ class Dictionary:
         out = np.empty(ids.size * self.words_per_kmer(), dtype=np.uint64)
         _check(_load().sshash_access_packed(self._h, ids.ctypes.data, ids.size, out.ctypes.data))
         return out
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def weight(self, kmer_ids: Iterable[int]) -> np.ndarray:
+        """Batched dictionary::weight (reference src/dictionary.cpp:96-100, include/weights.hpp:147-152), host side."""
+        ids = np.ascontiguousarray(np.asarray(kmer_ids, dtype=np.uint64))
+        out = np.empty(ids.size, dtype=np.uint64)
+        _check(_load().sshash_weight(self._h, ids.ctypes.data, ids.size, out.ctypes.data))
+        return out
+
+    def weight_device(self, device: int, d_kmer_ids: int, n: int, d_out: int, stream: int = 0) -> None:
+        _check(_load().sshash_weight_device(self._h, int(device), C.c_void_p(d_kmer_ids), int(n), C.c_void_p(d_out),
+                                            C.c_void_p(stream)))
 
     def route_device(self, device: int, d_kmers: int, n: int, num_shards: int, d_owner_fwd: int, d_owner_rc: int,
                      stream: int = 0) -> None:

@@ -50,6 +50,7 @@ build_options to_options(sshash_build_config const* cfg) {
         o.num_threads = cfg->num_threads ? cfg->num_threads : std::max(1u, std::thread::hardware_concurrency());
         if (cfg->lambda > 0) o.lambda = cfg->lambda;
         o.verbose = cfg->verbose != 0;
+        o.weighted = cfg->weighted != 0;
         o.num_shards = cfg->num_shards ? cfg->num_shards : 1;
         o.shard_id = cfg->shard_id;
     }
@@ -155,6 +156,7 @@ sshash_status sshash_get_info(const sshash_dict* d, sshash_info* info) {
     info->num_minimizers = x.num_minimizers();
     info->num_bits = x.num_bits();
     info->skew_partitions = x.skew_num_partitions;
+    info->weighted = x.weighted() ? 1 : 0;
     info->num_shards = x.num_shards;
     info->shard_id = x.shard_id;
     return SSHASH_OK;
@@ -246,6 +248,19 @@ sshash_status sshash_is_member_packed(const sshash_dict* d, const uint64_t* kmer
 sshash_status sshash_is_member_ascii(const sshash_dict* d, const char* kmers, uint64_t n, int check_rc, uint8_t* out) {
     if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
     return guarded([&] { d->eng->lookup_ascii_host(kmers, n, check_rc != 0, out_mode::member, result_view{}, out); });
+}
+
+sshash_status sshash_weight(const sshash_dict* d, const uint64_t* kmer_ids, uint64_t n, uint64_t* out_weights) {
+    if (!d || (n && (!kmer_ids || !out_weights))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        for (uint64_t i = 0; i < n; ++i) out_weights[i] = weight_of(*d->idx, kmer_ids[i]);
+    });
+}
+
+sshash_status sshash_weight_device(const sshash_dict* d, int device, const uint64_t* kmer_ids, uint64_t n,
+                                   uint64_t* out_weights, void* hip_stream) {
+    if (!d || (n && (!kmer_ids || !out_weights))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->weight_device(device, kmer_ids, n, out_weights, hip_stream); });
 }
 
 sshash_status sshash_access(const sshash_dict* d, uint64_t kmer_id, char* out_k_chars) {

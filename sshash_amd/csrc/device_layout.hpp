@@ -246,6 +246,9 @@ struct dict_view {
     uint64_t heavy_size;
     directory_view directory;
     sk_view sk;
+    uint64_t const* weight_starts;  // run-length intervals of the weights over the k-mer ids (index.hpp), or null
+    uint64_t const* weight_values;
+    uint64_t num_weight_intervals;
 
 };
 

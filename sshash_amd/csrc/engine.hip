@@ -298,6 +298,12 @@ void engine::to_device(int device) {
         }
     }
     rep->d_skew = rep->put(skew);
+    v.weight_starts = v.weight_values = nullptr;
+    v.num_weight_intervals = idx.weight_values.size();
+    if (idx.weighted()) {
+        v.weight_starts = rep->put(idx.weight_starts);
+        v.weight_values = rep->put(idx.weight_values);
+    }
     build_sk_table(*rep, idx);
     m_replicas.push_back(std::move(rep));
 }
@@ -656,6 +662,35 @@ void engine::access_packed_device(int device, uint64_t const* d_ids, uint64_t n,
     const dim3 grid(uint32_t((n + 255) / 256)), block(256);
     if (rep->view.k <= 31) hipLaunchKernelGGL(access_kernel<1>, grid, block, 0, hipStream_t(stream), rep->view, d_ids, n, d_out);
     else hipLaunchKernelGGL(access_kernel<2>, grid, block, 0, hipStream_t(stream), rep->view, d_ids, n, d_out);
+    HIP_CHECK(hipGetLastError());
+}
+
+/* ---- weight(kmer_id) on the device: include/weights.hpp:147-152, prev_leq as a binary search ---- */
+
+__global__ void __launch_bounds__(256)
+weight_kernel(const dict_view d, const uint64_t* __restrict__ ids, const uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t id = ids[i];
+    if (id >= d.num_kmers) {
+        out[i] = INVALID_U64;
+        return;
+    }
+    uint64_t lo = 0, hi = d.num_weight_intervals - 1;  // largest interval start <= id
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (d.weight_starts[mid] <= id) lo = mid;
+        else hi = mid - 1;
+    }
+    out[i] = d.weight_values[lo];
+}
+
+void engine::weight_device(int device, uint64_t const* d_ids, uint64_t n, uint64_t* d_out, void* stream) const {
+    device_replica const* rep = replica(device);
+    if (!rep->view.num_weight_intervals) throw error(error_kind::argument, "the dictionary does not store weights");
+    if (n == 0) return;
+    device_guard guard(device);
+    hipLaunchKernelGGL(weight_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, hipStream_t(stream), rep->view, d_ids, n, d_out);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -54,6 +54,10 @@ public:
        (all-ones for an id >= num_kmers). */
     void access_packed_device(int device, uint64_t const* d_ids, uint64_t n, uint64_t* d_out, void* stream) const;
 
+    /* weight(kmer_id) for a batch of ids, device buffers (all-ones for an id >= num_kmers); throws when the
+       dictionary stores no weights */
+    void weight_device(int device, uint64_t const* d_ids, uint64_t n, uint64_t* d_out, void* stream) const;
+
     /* owner shards of every query's forward / reverse-complement minimizer (shard_of_minimizer) */
     void route_packed_device(int device, uint64_t const* d_kmers, uint64_t n, uint32_t num_shards, uint32_t* d_owner_fwd,
                              uint32_t* d_owner_rc, void* stream) const;

@@ -3,6 +3,8 @@
 
 #include <zlib.h>
 
+#include <algorithm>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -228,6 +230,7 @@ uint64_t host_index::num_bits() const {
                       heavy_load_buckets.num_bytes());
     b += minimizers_mphf.num_bits();
     for (uint32_t p = 0; p < skew_num_partitions; ++p) b += skew_mphfs[p].num_bits() + 8 * skew_positions[p].num_bytes();
+    b += 64 * (weight_starts.size() + weight_values.size());
     return b;
 }
 
@@ -494,8 +497,39 @@ void build_from_fasta(host_index& idx, std::string const& filename, build_option
     };
     std::string header, seq;
     bool eof = false;
+    /* run-length intervals of weights over the k-mers in file order (encode_strings.cpp:73-75,120-132,216-218) */
+    std::vector<uint64_t> weight_starts, weight_values;
+    uint64_t num_kmers = 0;
+    auto malformed = [&](char const* what) {
+        gzclose(f);
+        throw error(error_kind::build, std::string("file is malformed: ") + what);
+    };
     for (;;) {
-        if (!getline(header, eof) && eof) break;  // header line is skipped (encode_strings.cpp:136)
+        if (!getline(header, eof) && eof) break;  // unweighted: the header line is skipped (encode_strings.cpp:136)
+        uint64_t declared_len = 0;
+        if (opt.weighted) {
+            /* '>[id] LN:i:[seq_len] ab:Z:[weight_seq]' with seq_len - k + 1 space-separated counters */
+            if (header.empty()) break;
+            if (header[0] != '>') malformed("header does not start with '>'");
+            size_t i = header.find(' ');
+            if (i == std::string::npos || header.compare(i + 1, 5, "LN:i:") != 0) malformed("expected 'LN:i:'");
+            i += 6;
+            const size_t j = header.find(' ', i);
+            if (j == std::string::npos || header.compare(j + 1, 5, "ab:Z:") != 0) malformed("expected 'ab:Z:'");
+            declared_len = std::strtoull(header.c_str() + i, nullptr, 10);
+            if (declared_len < opt.k) malformed("sequence shorter than k");
+            i = j + 6;
+            for (uint64_t t = 0; t != declared_len - opt.k + 1; ++t) {
+                if (i >= header.size()) malformed("fewer weights than k-mers");
+                const uint64_t w = std::strtoull(header.c_str() + i, nullptr, 10);
+                const size_t sp = header.find(' ', i);
+                i = sp == std::string::npos ? header.size() : sp + 1;
+                if (weight_values.empty() || weight_values.back() != w) {
+                    weight_starts.push_back(num_kmers + t);
+                    weight_values.push_back(w);
+                }
+            }
+        }
         getline(seq, eof);
         if (eof) break;  // a last line without '\n' is dropped, as in encode_strings.cpp:139-140
         if (!seq.empty() && seq.back() == '\r') seq.pop_back();
@@ -503,12 +537,29 @@ void build_from_fasta(host_index& idx, std::string const& filename, build_option
             gzclose(f);
             throw error(error_kind::build, "input sequence shorter than k");
         }
+        if (opt.weighted && declared_len != seq.size()) malformed("sequence length differs from its LN:i: field");  // :151-155
         pack_append(words, num_bases, seq.data(), seq.size());
         endpoints.push_back(num_bases);
+        num_kmers += seq.size() - opt.k + 1;
     }
     gzclose(f);
     if (endpoints.size() < 2) throw error(error_kind::build, "no sequences in '" + filename + "'");
+    /* weights parsed from a header whose sequence line was dropped (EOF) do not belong to any k-mer */
+    while (!weight_starts.empty() && weight_starts.back() >= num_kmers) {
+        weight_starts.pop_back();
+        weight_values.pop_back();
+    }
     build_from_packed(idx, std::move(words), std::move(endpoints), opt);
+    idx.weight_starts = std::move(weight_starts);
+    idx.weight_values = std::move(weight_values);
+}
+
+uint64_t weight_of(host_index const& idx, uint64_t kmer_id) {
+    if (!idx.weighted()) throw error(error_kind::argument, "the dictionary does not store weights");
+    if (kmer_id >= idx.num_kmers) throw error(error_kind::argument, "kmer_id out of range");
+    /* prev_leq over the interval starts, include/weights.hpp:148 */
+    const auto it = std::upper_bound(idx.weight_starts.begin(), idx.weight_starts.end(), kmer_id);
+    return idx.weight_values[size_t(it - idx.weight_starts.begin()) - 1];
 }
 
 /* ---- access ---------------------------------------------------------------------------- */
@@ -547,12 +598,13 @@ void access_kmer(host_index const& idx, uint64_t kmer_id, char* out) {
 /* ---- (de)serialisation ----------------------------------------------------------------- */
 //
 // File layout (all little-endian, every section 8-byte aligned):
-//   "SSHAMD\x02\x00"  magic
+//   "SSHAMD\x03\x00"  magic
 //   u8 version[3], u8 canonical, u32 k, u32 m, u32 skew_num_partitions
 //   u64 num_kmers, num_strings, num_bases, hash_magic, build_seed, strings_num_bits, num_shards | shard_id << 32
 //   vec<u64> strings, vec<u64> endpoints
 //   mphf minimizers, packed control_codewords, vec<u32> begin_buckets_of_size, packed mid_load_buckets
 //   skew_num_partitions x { mphf, packed positions }, packed heavy_load_buckets
+//   vec<u64> weight_starts, vec<u64> weight_values   (both empty for an unweighted dictionary)
 // where vec<T> = u64 count + raw data padded to 8 bytes; packed = u64 size, u64 width, vec<u64>;
 // mphf = u64 seed, u64 num_keys, u64 pilot_width, vec<partition 48B>, vec<u64> pilots, vec<u32> free_slots.
 // The reference's own .sshash byte format is defined by essentials/bits/pthash, whose sources are
@@ -623,7 +675,7 @@ struct reader {
         vec(m.free_slots);
     }
 };
-const char FILE_MAGIC[8] = {'S', 'S', 'H', 'A', 'M', 'D', 2, 0};
+const char FILE_MAGIC[8] = {'S', 'S', 'H', 'A', 'M', 'D', 3, 0};
 }  // namespace
 
 void save_index(host_index const& idx, std::string const& filename) {
@@ -654,6 +706,8 @@ void save_index(host_index const& idx, std::string const& filename) {
             w.packed(idx.skew_positions[p]);
         }
         w.packed(idx.heavy_load_buckets);
+        w.vec(idx.weight_starts);
+        w.vec(idx.weight_values);
     } catch (...) {
         fclose(f);
         throw;
@@ -708,7 +762,10 @@ void load_index(host_index& idx, std::string const& filename) {
             r.packed(idx.skew_positions[p]);
         }
         r.packed(idx.heavy_load_buckets);
-        if (idx.endpoints.size() != idx.num_strings + 1 || idx.begin_buckets_of_size.size() != MAX_BUCKET_SMALL + 1)
+        r.vec(idx.weight_starts);
+        r.vec(idx.weight_values);
+        if (idx.endpoints.size() != idx.num_strings + 1 || idx.begin_buckets_of_size.size() != MAX_BUCKET_SMALL + 1 ||
+            idx.weight_starts.size() != idx.weight_values.size() || (!idx.weight_starts.empty() && idx.weight_starts[0] != 0))
             throw error(error_kind::format, "index file corrupt (sizes)");
         char extra;
         if (fread(&extra, 1, 1, f) != 0) throw error(error_kind::format, "index file has trailing bytes");

@@ -45,6 +45,9 @@ struct build_options {
        (shard_of_minimizer); strings and endpoints stay complete. num_shards = 1: the whole index. */
     uint32_t num_shards = 1;
     uint32_t shard_id = 0;
+    /* FASTA headers carry k-mer abundances, '>[id] LN:i:[len] ab:Z:[w w w ...]' (build_configuration::weighted,
+       src/builder/encode_strings.cpp:83-135); only build_from_fasta reads them */
+    bool weighted = false;
 };
 
 struct host_index {
@@ -74,6 +77,12 @@ struct host_index {
     packed_vec skew_positions[8];
     packed_vec heavy_load_buckets;
 
+    /* weights (include/weights.hpp): run-length encoded over the k-mer ids -- interval i covers the ids
+       [weight_starts[i], weight_starts[i+1]) and has weight weight_values[i]; empty when not weighted */
+    std::vector<uint64_t> weight_starts;
+    std::vector<uint64_t> weight_values;
+    bool weighted() const { return !weight_values.empty(); }
+
     uint64_t num_minimizers() const { return control_codewords.size; }
     uint64_t num_bits() const;
     uint32_t words_per_kmer() const { return k <= 31 ? 1 : 2; }
@@ -98,6 +107,9 @@ void load_index(host_index& idx, std::string const& filename);
 void access_kmer(host_index const& idx, uint64_t kmer_id, char* out);
 /* Packed form: out[0..W) words. */
 void access_kmer_packed(host_index const& idx, uint64_t kmer_id, uint64_t* out);
+
+/* weight(kmer_id): include/weights.hpp:147-152 (dictionary::weight, src/dictionary.cpp:96-100) */
+uint64_t weight_of(host_index const& idx, uint64_t kmer_id);
 
 std::string index_summary(host_index const& idx);
 

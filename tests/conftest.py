@@ -14,6 +14,7 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 SE_FASTA = os.path.join(GOLDEN, "salmonella_enterica_k31_ust.fa.gz")
 K63_FASTA = os.path.join(GOLDEN, "se.ust.k63.head.fa.gz")
+WEIGHTED_FASTA = os.path.join(GOLDEN, "salmonella_enterica.weighted.ust.k31.fa.gz")  # reference data/unitigs_stitched/with_weights
 FASTQ = os.path.join(GOLDEN, "SRR5833294.10K.fastq.gz")
 
 

@@ -11,7 +11,8 @@
                      absent from the reference checkout).
   Data files copied verbatim from the reference's data/ directory (inputs its own tools/tests use):
   salmonella_enterica_k31_ust.fa.gz, SRR5833294.10K.fastq.gz; se.ust.k63.head.fa.gz = the first 24
-  records of se.ust.k63.fa.gz.
+  records of se.ust.k63.fa.gz; salmonella_enterica.weighted.ust.k31.fa.gz =
+  data/unitigs_stitched/with_weights/salmonella_enterica.ust.k31.fa.gz (headers carry the abundances).
 """
 import gzip
 import json
@@ -42,6 +43,9 @@ def main():
         dst = os.path.join(HERE, os.path.basename(rel))
         if not os.path.exists(dst):
             shutil.copy(os.path.join(REF, rel), dst)
+    weighted = os.path.join(HERE, "salmonella_enterica.weighted.ust.k31.fa.gz")
+    if not os.path.exists(weighted):
+        shutil.copy(os.path.join(REF, "data/unitigs_stitched/with_weights/salmonella_enterica.ust.k31.fa.gz"), weighted)
     lines = gzip.open(os.path.join(REF, "data/unitigs_stitched/se.ust.k63.fa.gz"), "rb").read().split(b"\n")
     with gzip.open(os.path.join(HERE, "se.ust.k63.head.fa.gz"), "wb", compresslevel=9) as f:
         f.write(b"\n".join(lines[:48]) + b"\n")

@@ -350,3 +350,43 @@ def test_neighbours_match_eight_oracle_lookups(case_name, request):
     d.neighbours_device(0, dq.data_ptr(), n, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert (out.cpu().numpy().view(np.uint64) == want["kmer_id"]).all()
+
+
+def test_weights_on_the_device_equal_the_abundances_of_the_input_file(tmp_path):
+    """dictionary::weight (reference test/check_from_file.hpp:229-275): the id-th weight of the file, in file
+    order, for every k-mer; device kernel against the oracle restatement and the file itself."""
+    import gzip
+
+    import torch
+
+    from conftest import WEIGHTED_FASTA
+    from oracle import oracle as O
+
+    d = sshash_amd.Dictionary.build(WEIGHTED_FASTA, k=31, m=15, weighted=True, num_threads=8).to_device(0)
+    path = str(tmp_path / "w.sshash")
+    d.save(path)
+    want = []
+    with gzip.open(WEIGHTED_FASTA, "rt") as f:
+        for header in f:
+            next(f)
+            want.extend(int(x) for x in header.split("ab:Z:")[1].split())
+    want = np.array(want, dtype=np.uint64)
+    n = d.num_kmers()
+    assert n == want.size
+    ids = torch.arange(n + 3, dtype=torch.int64, device="cuda")  # three ids past the end
+    out = torch.empty(n + 3, dtype=torch.int64, device="cuda")
+    d.weight_device(0, ids.data_ptr(), n + 3, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    assert (got[:n] == want).all()
+    assert (got[n:] == sshash_amd.INVALID_U64).all()
+    assert (O.OracleIndex(path).weights(np.arange(n, dtype=np.uint64)) == want).all()
+    # weights ride along with lookups: lookup -> id -> weight for reverse-complemented queries
+    rng = np.random.default_rng(3)
+    pick = rng.integers(0, n, 5000)
+    packed = d.access_packed(pick)
+    assert (d.weight(d.lookup(packed).kmer_id) == want[pick]).all()
+    # a dictionary without weights refuses
+    plain = sshash_amd.Dictionary.build(WEIGHTED_FASTA, k=31, m=15, num_threads=8).to_device(0)
+    with pytest.raises(sshash_amd.SSHashError):
+        plain.weight_device(0, ids.data_ptr(), 4, out.data_ptr())

@@ -70,3 +70,73 @@ def test_algorithmic_bytes_rule(case_se_regular):
     q = case.queries(5000, 5000, seed=1)
     per = case.oracle.count_bytes(q) / 10000
     assert 70 < per < 130
+
+
+# ---- weights (reference test/check_from_file.hpp:229-275: weight(kmer_id) must equal the id-th abundance of the
+# ---- input file, read in file order) -----------------------------------------------------------------------
+
+def _file_weights(path, k):
+    import gzip
+
+    out = []
+    with gzip.open(path, "rt") as f:
+        for header in f:
+            seq = next(f).strip()
+            ln, ab = header.split(" ", 2)[1:]
+            assert ln.startswith("LN:i:") and int(ln[5:]) == len(seq) and ab.startswith("ab:Z:")
+            w = [int(x) for x in ab[5:].split()]
+            assert len(w) == len(seq) - k + 1
+            out.extend(w)
+    return np.array(out, dtype=np.uint64)
+
+
+@pytest.fixture(scope="module")
+def weighted_case(tmp_path_factory):
+    import sshash_amd
+    from conftest import WEIGHTED_FASTA
+    from oracle import oracle as O
+
+    d = sshash_amd.Dictionary.build(WEIGHTED_FASTA, k=31, m=15, weighted=True, num_threads=4)
+    p = str(tmp_path_factory.mktemp("w") / "weighted.sshash")
+    d.save(p)
+    return d, O.OracleIndex(p), _file_weights(WEIGHTED_FASTA, 31), p
+
+
+def test_weights_equal_the_abundances_of_the_input_file(weighted_case):
+    import sshash_amd
+
+    d, oracle, want, path = weighted_case
+    assert d.weighted() and d.num_kmers() == want.size
+    ids = np.arange(want.size, dtype=np.uint64)
+    assert (oracle.weights(ids) == want).all()          # the restatement against the file
+    assert (d.weight(ids) == want).all()                # the host side of the library
+    d2 = sshash_amd.Dictionary.load(path)               # round trip through the index file
+    assert d2.weighted() and (d2.weight(ids[::97]) == want[::97]).all()
+    with pytest.raises(sshash_amd.SSHashError):
+        d.weight([want.size])                           # out of range
+
+
+def test_unweighted_dictionary_refuses_weight_queries(case_skew_regular):
+    import sshash_amd
+
+    assert not case_skew_regular.dict.weighted()
+    with pytest.raises(sshash_amd.SSHashError) as e:
+        case_skew_regular.dict.weight([0])
+    assert "does not store weights" in str(e.value)
+    with pytest.raises(ValueError):
+        case_skew_regular.oracle.weights([0])
+
+
+def test_malformed_weight_headers_are_rejected(tmp_path):
+    import sshash_amd
+
+    seq = "ACGTTGCAAGGCTTAACCGGTTAAGGCCTTAACGT"  # 35 bases -> 5 k-mers at k = 31
+    for header in (">0 LN:i:35 ab:Z:1 1 1", ">0 LN:i:34 ab:Z:1 1 1 1", ">0 ab:Z:1 1 1 1 1", ">0 LN:i:35 1 1 1 1 1"):
+        p = tmp_path / "bad.fa"
+        p.write_text(header + "\n" + seq + "\n")
+        with pytest.raises(sshash_amd.SSHashError):
+            sshash_amd.Dictionary.build(str(p), k=31, m=11, weighted=True)
+    p = tmp_path / "good.fa"
+    p.write_text(">0 LN:i:35 ab:Z:7 7 9 9 7\n" + seq + "\n")
+    d = sshash_amd.Dictionary.build(str(p), k=31, m=11, weighted=True)
+    assert list(d.weight(range(5))) == [7, 7, 9, 9, 7]
