@@ -181,6 +181,20 @@ sshash_status sshash_route_packed_device(const sshash_dict* d, int device, const
                                          uint32_t num_shards, uint32_t* owner_forward, uint32_t* owner_reverse,
                                          void* hip_stream);
 
+/* The same routing with the bucketing done on the device, two calls on one stream:
+ *   1. send == slots == NULL: cursors[s] += number of messages for shard s (one message per query and distinct
+ *      owner; `cursors`: num_shards device uint64, zeroed by the caller) -- the send counts of the all-to-all;
+ *   2. cursors[s] = index of the first message of shard s (exclusive prefix sum of the counts): message t gets
+ *      send[t*W .. t*W+W) = the packed k-mer and slots[t] = the index of its query. Messages of one shard are
+ *      contiguous; their order inside the shard is unspecified. n < 2^32, num_shards <= 1024.
+ * sshash_route_combine_device: out[slots[t]] = replies[t] for every reply != UINT64_MAX (`out` pre-filled with
+ * UINT64_MAX by the caller); owners that both find a k-mer return the same id. */
+sshash_status sshash_route_bucket_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                         uint32_t num_shards, int check_reverse_complement, uint64_t* cursors,
+                                         uint64_t* send, uint32_t* slots, void* hip_stream);
+sshash_status sshash_route_combine_device(const sshash_dict* d, int device, const uint64_t* replies, const uint32_t* slots,
+                                          uint64_t m, uint64_t* out, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

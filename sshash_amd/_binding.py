@@ -155,6 +155,8 @@ def _load() -> C.CDLL:
         "sshash_streaming_query": (C.c_int, [P, P, P, C.c_uint64, C.POINTER(_Report)]),
         "sshash_streaming_query_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, P, P]),
         "sshash_route_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_uint32, P, P, P]),
+        "sshash_route_bucket_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_uint32, C.c_int, P, P, P, P]),
+        "sshash_route_combine_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, P, P]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here == ABI symbol missing: fail loudly
@@ -172,7 +174,7 @@ C_ABI_SYMBOLS = (
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
     "sshash_access_packed_device sshash_weight sshash_weight_device "
     "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device "
-    "sshash_route_packed_device"
+    "sshash_route_packed_device sshash_route_bucket_device sshash_route_combine_device"
 ).split()
 
 
@@ -444,6 +446,17 @@ class Dictionary:
     def weight_device(self, device: int, d_kmer_ids: int, n: int, d_out: int, stream: int = 0) -> None:
         _check(_load().sshash_weight_device(self._h, int(device), C.c_void_p(d_kmer_ids), int(n), C.c_void_p(d_out),
                                             C.c_void_p(stream)))
+
+    def route_bucket_device(self, device: int, d_kmers: int, n: int, num_shards: int, d_cursors: int, d_send: int = 0,
+                            d_slots: int = 0, check_reverse_complement: bool = True, stream: int = 0) -> None:
+        """Count (d_send == 0) or scatter the messages of a routed batch; see include/sshash_amd.h."""
+        _check(_load().sshash_route_bucket_device(self._h, int(device), C.c_void_p(d_kmers), int(n), int(num_shards),
+                                                  1 if check_reverse_complement else 0, C.c_void_p(d_cursors),
+                                                  C.c_void_p(d_send or None), C.c_void_p(d_slots or None), C.c_void_p(stream)))
+
+    def route_combine_device(self, device: int, d_replies: int, d_slots: int, m: int, d_out: int, stream: int = 0) -> None:
+        _check(_load().sshash_route_combine_device(self._h, int(device), C.c_void_p(d_replies), C.c_void_p(d_slots), int(m),
+                                                   C.c_void_p(d_out), C.c_void_p(stream)))
 
     def route_device(self, device: int, d_kmers: int, n: int, num_shards: int, d_owner_fwd: int, d_owner_rc: int,
                      stream: int = 0) -> None:

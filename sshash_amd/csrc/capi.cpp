@@ -339,4 +339,17 @@ sshash_status sshash_route_packed_device(const sshash_dict* d, int device, const
     return guarded([&] { d->eng->route_packed_device(device, kmers, n, num_shards, owner_forward, owner_reverse, hip_stream); });
 }
 
+sshash_status sshash_route_bucket_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                         uint32_t num_shards, int check_rc, uint64_t* cursors, uint64_t* send,
+                                         uint32_t* slots, void* hip_stream) {
+    if (!d || (n && !kmers) || !cursors) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->route_bucket_device(device, kmers, n, num_shards, check_rc != 0, cursors, send, slots, hip_stream); });
+}
+
+sshash_status sshash_route_combine_device(const sshash_dict* d, int device, const uint64_t* replies, const uint32_t* slots,
+                                          uint64_t m, uint64_t* out, void* hip_stream) {
+    if (!d || (m && (!replies || !slots || !out))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->route_combine_device(device, replies, slots, m, out, hip_stream); });
+}
+
 }  // extern "C"

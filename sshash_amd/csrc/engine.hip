@@ -631,6 +631,96 @@ void engine::route_packed_device(int device, uint64_t const* d_kmers, uint64_t n
     HIP_CHECK(hipGetLastError());
 }
 
+/* Bucketing of a batch by owner shard (sharded.py): one message per (query, distinct owner). Every workgroup
+   counts its messages per shard in LDS, reserves one contiguous range per shard with a single global atomic
+   and (SCATTER) writes its messages there: the packed k-mer and the index of its query. With SCATTER off the
+   same reservations simply add up to the per-shard message counts. */
+constexpr uint32_t ROUTE_MAX_SHARDS = 1024;
+
+template <int W, bool SCATTER>
+__global__ void __launch_bounds__(256)
+route_bucket_kernel(const dict_view d, const uint64_t* __restrict__ kmers, const uint64_t n, const uint32_t num_shards,
+                    const bool check_rc, unsigned long long* __restrict__ cursors, uint64_t* __restrict__ send,
+                    uint32_t* __restrict__ slots) {
+    __shared__ uint32_t local_count[ROUTE_MAX_SHARDS];
+    __shared__ unsigned long long base[ROUTE_MAX_SHARDS];
+    for (uint32_t t = threadIdx.x; t < num_shards; t += blockDim.x) local_count[t] = 0;
+    __syncthreads();
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    kmer_w<W> x = kmer_zero<W>();
+    uint32_t owner_f = 0, owner_r = 0, rank_f = 0, rank_r = 0;
+    if (active) {
+        x = load_query<W, false>(kmers, i, d.k);
+        const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
+        uint64_t f = compute_minimizer<W>(x, d.k, d.m, d.hash_magic).value;
+        uint64_t r = compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic).value;
+        if (d.canonical) f = r = (r < f ? r : f);
+        if (!check_rc) r = f;
+        owner_f = shard_of_minimizer(f, num_shards);
+        owner_r = shard_of_minimizer(r, num_shards);
+        rank_f = atomicAdd(&local_count[owner_f], 1u);
+        if (owner_r != owner_f) rank_r = atomicAdd(&local_count[owner_r], 1u);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < num_shards; t += blockDim.x) {
+        const uint32_t c = local_count[t];
+        base[t] = c ? atomicAdd(cursors + t, (unsigned long long)c) : 0ull;
+    }
+    if constexpr (SCATTER) {
+        __syncthreads();
+        if (active) {
+            const uint64_t at = base[owner_f] + rank_f;
+            for (int j = 0; j < W; ++j) send[at * W + j] = x.w[j];
+            slots[at] = uint32_t(i);
+            if (owner_r != owner_f) {
+                const uint64_t at2 = base[owner_r] + rank_r;
+                for (int j = 0; j < W; ++j) send[at2 * W + j] = x.w[j];
+                slots[at2] = uint32_t(i);
+            }
+        }
+    }
+}
+
+void engine::route_bucket_device(int device, uint64_t const* d_kmers, uint64_t n, uint32_t num_shards, bool check_rc,
+                                 uint64_t* d_cursors, uint64_t* d_send, uint32_t* d_slots, void* stream) const {
+    device_replica const* rep = replica(device);
+    if (num_shards == 0 || num_shards > ROUTE_MAX_SHARDS) throw error(error_kind::argument, "num_shards must be in [1, 1024]");
+    if (n >= (uint64_t(1) << 32)) throw error(error_kind::argument, "at most 2^32 - 1 queries per routed batch");
+    if ((d_send == nullptr) != (d_slots == nullptr)) throw error(error_kind::argument, "send and slots go together");
+    if (n == 0) return;
+    device_guard guard(device);
+    const dim3 grid(uint32_t((n + 255) / 256)), block(256);
+    auto* cursors = reinterpret_cast<unsigned long long*>(d_cursors);
+    hipStream_t s = hipStream_t(stream);
+    const bool wide = rep->view.k > 31, scatter = d_send != nullptr;
+    if (!wide && !scatter) hipLaunchKernelGGL((route_bucket_kernel<1, false>), grid, block, 0, s, rep->view, d_kmers, n, num_shards, check_rc, cursors, d_send, d_slots);
+    else if (!wide && scatter) hipLaunchKernelGGL((route_bucket_kernel<1, true>), grid, block, 0, s, rep->view, d_kmers, n, num_shards, check_rc, cursors, d_send, d_slots);
+    else if (wide && !scatter) hipLaunchKernelGGL((route_bucket_kernel<2, false>), grid, block, 0, s, rep->view, d_kmers, n, num_shards, check_rc, cursors, d_send, d_slots);
+    else hipLaunchKernelGGL((route_bucket_kernel<2, true>), grid, block, 0, s, rep->view, d_kmers, n, num_shards, check_rc, cursors, d_send, d_slots);
+    HIP_CHECK(hipGetLastError());
+}
+
+/* replies of the owners, aligned with `slots`: a reply that found its k-mer settles its query (two owners
+   that both find it return the same id: a k-mer occurs once in the strings) */
+__global__ void __launch_bounds__(256)
+route_combine_kernel(const uint64_t* __restrict__ replies, const uint32_t* __restrict__ slots, const uint64_t m,
+                     uint64_t* __restrict__ out) {
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const uint64_t id = replies[t];
+    if (id != INVALID_U64) out[slots[t]] = id;
+}
+
+void engine::route_combine_device(int device, uint64_t const* d_replies, uint32_t const* d_slots, uint64_t m, uint64_t* d_out,
+                                  void* stream) const {
+    (void)replica(device);
+    if (m == 0) return;
+    device_guard guard(device);
+    hipLaunchKernelGGL(route_combine_kernel, dim3(uint32_t((m + 255) / 256)), dim3(256), 0, hipStream_t(stream), d_replies, d_slots, m, d_out);
+    HIP_CHECK(hipGetLastError());
+}
+
 /* ---- access(kmer_id) on the device: include/spectrum_preserving_string_set.hpp:114-118 with
         offsets::id_to_offset (include/offsets.hpp:41-65) as a binary search over the endpoints ---- */
 

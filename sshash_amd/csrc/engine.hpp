@@ -62,6 +62,12 @@ public:
     void route_packed_device(int device, uint64_t const* d_kmers, uint64_t n, uint32_t num_shards, uint32_t* d_owner_fwd,
                              uint32_t* d_owner_rc, void* stream) const;
 
+    /* the same routing, bucketed on the device (see sshash_route_bucket_device in include/sshash_amd.h) */
+    void route_bucket_device(int device, uint64_t const* d_kmers, uint64_t n, uint32_t num_shards, bool check_rc,
+                             uint64_t* d_cursors, uint64_t* d_send, uint32_t* d_slots, void* stream) const;
+    void route_combine_device(int device, uint64_t const* d_replies, uint32_t const* d_slots, uint64_t m, uint64_t* d_out,
+                              void* stream) const;
+
     /* Host-buffer entry points: shard the batch over every replica, stream chunks through
        pinned staging buffers, results land in the caller's arrays. */
     void lookup_packed_host(uint64_t const* h_kmers, uint64_t n, bool check_rc, out_mode mode,

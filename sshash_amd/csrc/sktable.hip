@@ -213,7 +213,7 @@ void build_sk_table(device_replica& rep, host_index const& idx) {
     const uint64_t num_waves = (positions + 1 + NEW_PER_WAVE - 1) / NEW_PER_WAVE;
     const uint64_t threads = num_waves * WAVE;
     const dim3 block(256), grid(uint32_t((threads + 255) / 256));
-    if ((threads + 255) / 256 >= (uint64_t(1) << 31)) return;
+    if ((threads + 255) / 256 >= (uint64_t(1) << 31) || num_waves >= (uint64_t(1) << 31)) return;  // hipCUB item counts are int
 
     temp_buffers tmp;
     uint32_t* counts = tmp.alloc<uint32_t>(num_waves);

@@ -8,19 +8,21 @@ not fit one HBM: rank r holds only the buckets of the minimizers with ``shard_of
 
 Lookup of a local batch on rank r (all device-side except the split-size exchange):
 
- 1. route      ``sshash_route_packed_device``: owner of the forward minimizer and of the reverse-complement
-               minimizer of every query (equal for canonical dictionaries);
+ 1. route      ``sshash_route_bucket_device`` twice: owner of the forward minimizer and of the reverse-complement
+               minimizer of every query (equal for canonical dictionaries); count the messages per owner, then
+               scatter them into contiguous per-owner regions (LDS histogram + one reservation per workgroup and
+               owner) together with the index of the query each one is about;
  2. exchange   one message per (query, distinct owner): the packed k-mer; ``all_to_all_single`` over
                RCCL (xGMI) -- 8*W bytes per message out, 8 bytes back;
  3. lookup     every rank runs the ordinary batched lookup on what it received: a probe whose minimizer
                lives on another shard simply misses (its fingerprint is not there);
  4. return     ids travel back with the inverse all-to-all;
- 5. combine    the reply of the forward-minimizer owner wins when it found the k-mer (that is the
-               reference's forward probe, src/dictionary.cpp:70), else the reverse owner's reply.
+ 5. combine    ``sshash_route_combine_device``: a reply that found the k-mer settles its query (a k-mer occurs
+               once in the strings, so two owners that both find it return the same id).
 
 Results are identical to the unsharded dictionary: ids derive from string offsets, which are global.
-torch is used for what it is good at here -- sort / bincount / index plumbing and ``torch.distributed``;
-the k-mer work stays in the HIP kernels behind the C ABI. With a ``gloo`` group (tests) the payloads are
+torch is used for device memory and ``torch.distributed``; routing, bucketing, lookup and combine are HIP
+kernels behind the C ABI. With a ``gloo`` group (tests) the payloads are
 staged through host memory.
 """
 from __future__ import annotations
@@ -89,36 +91,33 @@ class ShardedDictionary:
         W = self.shard.words_per_kmer()
         n = d_kmers.numel() // W
         stream = torch.cuda.current_stream(self._dev).cuda_stream
-        q = d_kmers.view(n, W)
-        owner_f = torch.empty(n, dtype=torch.int32, device=self._dev)
-        owner_r = torch.empty(n, dtype=torch.int32, device=self._dev)
+        # 1. count the messages per owner, then scatter them into per-owner regions (HIP kernels behind the C ABI)
+        counts = torch.zeros(self.world, dtype=torch.int64, device=self._dev)
         if n:
-            self.shard.route_device(self.device, d_kmers.data_ptr(), n, self.world, owner_f.data_ptr(), owner_r.data_ptr(),
-                                    stream=stream)
-        if not check_reverse_complement:
-            owner_r = owner_f
-        second = (owner_r != owner_f).nonzero(as_tuple=True)[0]
-        slot = torch.cat([torch.arange(n, device=self._dev), second])            # which local query a message is about
-        dest = torch.cat([owner_f.long(), owner_r.long()[second]])
-        order = torch.sort(dest, stable=True)[1]
-        slot, dest = slot[order], dest[order]
-        send_counts = torch.bincount(dest, minlength=self.world).tolist()
+            self.shard.route_bucket_device(self.device, d_kmers.data_ptr(), n, self.world, counts.data_ptr(),
+                                           check_reverse_complement=check_reverse_complement, stream=stream)
+        send_counts = [int(c) for c in counts.tolist()]
+        total = sum(send_counts)
+        cursors = torch.cumsum(counts, 0) - counts                                  # first message of every region
+        send = torch.empty((max(total, 1), W), dtype=torch.int64, device=self._dev)
+        slots = torch.empty(max(total, 1), dtype=torch.int32, device=self._dev)     # which local query a message is about
+        if n:
+            self.shard.route_bucket_device(self.device, d_kmers.data_ptr(), n, self.world, cursors.data_ptr(), send.data_ptr(),
+                                           slots.data_ptr(), check_reverse_complement=check_reverse_complement, stream=stream)
+        # 2. exchange, 3. lookup what arrived, 4. return the ids
         recv_counts = self._exchange_counts(send_counts)
-        received = self._all_to_all(q[slot], send_counts, recv_counts)            # (m, W) packed k-mers to look up here
+        received = self._all_to_all(send[:total], send_counts, recv_counts)           # (m, W) packed k-mers to look up here
         m = received.shape[0]
         ids = torch.full((max(m, 1),), -1, dtype=torch.int64, device=self._dev)
         if m:
             received = received.contiguous()
             self.shard.lookup_device(self.device, received.data_ptr(), m, ids.data_ptr(),
                                      check_reverse_complement=check_reverse_complement, stream=stream)
-        replies = self._all_to_all(ids[:m].view(m, 1), recv_counts, send_counts).view(-1)  # aligned with `slot`
+        replies = self._all_to_all(ids[:m].view(m, 1), recv_counts, send_counts).view(-1).contiguous()  # aligned with `slots`
+        # 5. combine: a reply that found the k-mer settles its query
         out = torch.full((n,), -1, dtype=torch.int64, device=self._dev)
-        is_first = order < n                                                       # message went to the forward owner
-        found = replies != -1
-        back = found & ~is_first
-        out[slot[back]] = replies[back]                                            # reverse-complement owner's answer ...
-        front = found & is_first
-        out[slot[front]] = replies[front]                                          # ... unless the forward probe hit
+        if total:
+            self.shard.route_combine_device(self.device, replies.data_ptr(), slots.data_ptr(), total, out.data_ptr(), stream=stream)
         return out
 
     def lookup(self, kmers: np.ndarray, check_reverse_complement: bool = True) -> np.ndarray:
