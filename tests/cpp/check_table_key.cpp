@@ -1,0 +1,63 @@
+// check_table_key.cpp -- host-side properties of the super-k-mer table's key function (csrc/device_layout.hpp):
+// a k-mer and its reverse complement must elect the same m-mer occurrence, or the table could not serve both
+// strands with one slot. Plain g++, no GPU. Prints "OK <checked> <ties>" or the first counter-example.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../sshash_amd/csrc/device_layout.hpp"
+
+using namespace sshash_amd;
+
+template <int W>
+static int check(uint32_t k, uint32_t m, uint64_t trials, std::mt19937_64& rng, uint64_t& ties) {
+    const uint64_t mask = low_mask(2 * m);
+    for (uint64_t t = 0; t < trials; ++t) {
+        kmer_w<W> x;
+        for (int j = 0; j < W; ++j) x.w[j] = rng();
+        if (t % 7 == 0) x.w[0] &= 0x3333333333333333ULL;  // low-complexity k-mers: repeated m-mers inside one window
+        x = kmer_take_chars<W>(x, k);
+        const kmer_w<W> y = kmer_revcomp<W>(x, k);
+        const sk_key_t a = sk_key<W>(x, y, k, m), b = sk_key<W>(y, x, k, m);
+        if (a.tie != b.tie) return printf("tie flag differs between strands (k=%u m=%u)\n", k, m), 1;
+        if (a.tie) {
+            ++ties;
+            continue;
+        }
+        if (a.key != b.key) return printf("different keys for the two strands (k=%u m=%u)\n", k, m), 1;
+        if (a.rc == b.rc) return printf("both strands claim the same orientation (k=%u m=%u)\n", k, m), 1;
+        if (a.pos != b.pos) return printf("different positions on the winning strand (k=%u m=%u)\n", k, m), 1;
+        if (a.pos > k - m) return printf("position outside the k-mer (k=%u m=%u)\n", k, m), 1;
+        const kmer_w<W>& winner = a.rc ? y : x;
+        if ((kmer_shr_chars<W>(winner, a.pos).w[0] & mask) != a.key) return printf("key is not the m-mer at its position\n"), 1;
+        /* leftmost among equal hashes on the winning strand */
+        for (uint32_t i = 0; i < a.pos; ++i)
+            if (sk_mmer_hash(kmer_shr_chars<W>(winner, i).w[0] & mask) <= sk_mmer_hash(a.key))
+                return printf("an earlier m-mer has a hash at least as small (k=%u m=%u)\n", k, m), 1;
+    }
+    return 0;
+}
+
+int main() {
+    std::mt19937_64 rng(12345);
+    uint64_t ties = 0, checked = 0;
+    const uint32_t cases[][2] = {{31, 21}, {31, 13}, {15, 7}, {21, 21}, {31, 1}, {63, 25}, {63, 31}, {47, 20}, {33, 5}};
+    for (auto const& c : cases) {
+        const uint64_t trials = 200000;
+        const uint64_t before = ties;
+        const int bad = c[0] <= 31 ? check<1>(c[0], c[1], trials, rng, ties) : check<2>(c[0], c[1], trials, rng, ties);
+        if (bad) return 1;
+        checked += trials;
+        fprintf(stderr, "k=%u m=%u: %llu ties in %llu k-mers\n", c[0], c[1], (unsigned long long)(ties - before), (unsigned long long)trials);
+    }
+    /* slot hashing: three independent-looking choices inside the table */
+    for (uint64_t key = 1; key < 100000; key += 7) {
+        const sk_hash_t h = sk_hash(key * 0x9E3779B97F4A7C15ULL >> 22, 1000003u);
+        for (uint32_t c = 0; c < SK_CHOICES; ++c)
+            if (h.slot[c] >= 1000003u) return printf("slot out of range\n"), 1;
+        if (h.fingerprint >> 24) return printf("fingerprint wider than 24 bits\n"), 1;
+    }
+    printf("OK %llu %llu\n", (unsigned long long)checked, (unsigned long long)ties);
+    return 0;
+}

@@ -119,3 +119,18 @@ def test_product_does_not_touch_the_oracle():
                 assert "oracle" not in text.lower().replace("no pure-python", ""), f"{f} mentions the oracle"
     hdr = open(os.path.join(ROOT, "include", "sshash_amd.h")).read()
     assert "oracle" not in hdr.lower()
+
+
+def test_table_key_function_is_strand_symmetric(tmp_path):
+    """The super-k-mer table serves a k-mer and its reverse complement from one slot: its key function
+    (csrc/device_layout.hpp, host+device code) must elect the same m-mer occurrence for both strands.
+    tests/cpp/check_table_key.cpp checks that with g++ on the host, k <= 31 and k <= 63."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "check_table_key")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "check_table_key.cpp"), "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.startswith("OK "), p.stdout + p.stderr
