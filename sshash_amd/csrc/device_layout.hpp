@@ -60,7 +60,7 @@
 //               over both strands (equal minima = tie, left to the structures above) -- one key for both
 //               strands, whatever the dictionary's own minimizer flavour. Built and probed with the same
 //               function, the table need not follow the reference's minimizer hash: it uses a 32-bit one;
-//        slot   32 bytes, 32-byte aligned; a key lives in one of three hashed slots (first free one
+//        slot   32 bytes, 32-byte aligned; a key lives in one of four hashed slots (first free one
 //               wins, 3 slots per key), SK_CHOICES = 4:
 //                 d0  bit0 valid | bit1 list | bit2 strand | bits 3-6 go-on flags, one per choice |
 //                     bits 8-13 left | bits 14-19 right
