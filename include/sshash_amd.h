@@ -162,6 +162,11 @@ sshash_status sshash_neighbours_packed_device(const sshash_dict* d, int device, 
 sshash_status sshash_neighbours_packed(const sshash_dict* d, const uint64_t* kmers, uint64_t n,
                                        int check_reverse_complement, const sshash_results* out);
 
+/* dictionary::string_neighbours(string_id, bool): include/dictionary.hpp:62, src/dictionary.cpp:189-201 -- the
+ * forward neighbours of the string's last k-mer and the backward neighbours of its first one, same layout. */
+sshash_status sshash_string_neighbours(const sshash_dict* d, const uint64_t* string_ids, uint64_t n,
+                                       int check_reverse_complement, const sshash_results* out);
+
 /* ---- dictionary::streaming_query_from_file (include/dictionary.hpp:81-82, src/query.cpp:118-175)
  *      and streaming_query<Dict,canonical> over reads in memory (include/streaming_query.hpp) -- */
 sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char* filename, int multiline,

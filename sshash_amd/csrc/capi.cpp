@@ -232,6 +232,14 @@ sshash_status sshash_neighbours_packed(const sshash_dict* d, const uint64_t* kme
     });
 }
 
+sshash_status sshash_string_neighbours(const sshash_dict* d, const uint64_t* string_ids, uint64_t n, int check_rc,
+                                       const sshash_results* out) {
+    if (!d || !out || (!string_ids && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        d->eng->string_neighbours_host(string_ids, n, check_rc != 0, wants_full(out) ? out_mode::full : out_mode::ids, to_view(out));
+    });
+}
+
 sshash_status sshash_is_member_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
                                              int check_rc, uint8_t* out, void* hip_stream) {
     if (!d || !out || (!kmers && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");

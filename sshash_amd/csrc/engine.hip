@@ -601,6 +601,38 @@ void engine::neighbours_packed_host(uint64_t const* h_kmers, uint64_t n, bool ch
     lookup_packed_host(expanded.data(), 8 * n, check_rc, mode, h_out, nullptr);
 }
 
+void engine::string_neighbours_host(uint64_t const* h_string_ids, uint64_t n, bool check_rc, out_mode mode,
+                                    result_view const& h_out) const {
+    host_index const& idx = *m_idx;
+    const uint32_t k = idx.k, W = idx.words_per_kmer();
+    std::vector<uint64_t> expanded(8 * n * W);
+    uint64_t first[2], last[2];
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t s = h_string_ids[i];
+        if (s >= idx.num_strings) throw error(error_kind::argument, "string_id out of range");
+        /* ids of the string's first and last k-mer (include/offsets.hpp:41-65 inverted) */
+        const uint64_t first_id = idx.endpoints[s] - s * (k - 1), last_id = idx.endpoints[s + 1] - k - s * (k - 1);
+        access_kmer_packed(idx, first_id, first);
+        access_kmer_packed(idx, last_id, last);
+        for (uint32_t which = 0; which < 8; ++which) {
+            uint64_t const* from = which < 4 ? last : first;  // suffix of the string forward, prefix backward
+            if (W == 1) {
+                kmer_w<1> x;
+                x.w[0] = from[0];
+                expanded[8 * i + which] = kmer_neighbour<1>(x, which, k).w[0];
+            } else {
+                kmer_w<2> x;
+                x.w[0] = from[0];
+                x.w[1] = from[1];
+                const kmer_w<2> y = kmer_neighbour<2>(x, which, k);
+                expanded[2 * (8 * i + which)] = y.w[0];
+                expanded[2 * (8 * i + which) + 1] = y.w[1];
+            }
+        }
+    }
+    lookup_packed_host(expanded.data(), 8 * n, check_rc, mode, h_out, nullptr);
+}
+
 /* ---- routing of queries to the owners of their minimizers (minimizer-sharded index) ------------ */
 
 template <int W>

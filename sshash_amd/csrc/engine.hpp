@@ -50,6 +50,11 @@ public:
     void neighbours_packed_host(uint64_t const* h_kmers, uint64_t n, bool check_rc, out_mode mode,
                                 result_view const& h_out) const;
 
+    /* string_neighbours (src/dictionary.cpp:189-201): forward neighbours of the last k-mer and backward neighbours
+       of the first k-mer of every string; same 8-entry layout. Host buffers. */
+    void string_neighbours_host(uint64_t const* h_string_ids, uint64_t n, bool check_rc, out_mode mode,
+                                result_view const& h_out) const;
+
     /* access(kmer_id) for a batch of ids, device buffers: out gets n*W packed words
        (all-ones for an id >= num_kmers). */
     void access_packed_device(int device, uint64_t const* d_ids, uint64_t n, uint64_t* d_out, void* stream) const;

@@ -390,3 +390,28 @@ def test_weights_on_the_device_equal_the_abundances_of_the_input_file(tmp_path):
     plain = sshash_amd.Dictionary.build(WEIGHTED_FASTA, k=31, m=15, num_threads=8).to_device(0)
     with pytest.raises(sshash_amd.SSHashError):
         plain.weight_device(0, ids.data_ptr(), 4, out.data_ptr())
+
+
+@pytest.mark.parametrize("case_name", ["case_skew_regular", "case_k63_canonical"])
+def test_string_neighbours(case_name, request):
+    """string_neighbours(s) = forward part of kmer_neighbours(last k-mer of s) + backward part of
+    kmer_neighbours(first k-mer of s) (src/dictionary.cpp:189-201)."""
+    case = request.getfixturevalue(case_name)
+    d = case.dict.to_device(0)
+    k, W = case.k, case.W
+    sids = np.arange(0, len(case.sequences), 3)
+    got = d.string_neighbours(sids).reshape(-1, 8)
+    first_ids, last_ids = [], []
+    kid = 0
+    starts = []
+    for s in case.sequences:
+        starts.append(kid)
+        kid += len(s) - k + 1
+    for s in sids:
+        first_ids.append(starts[s])
+        last_ids.append(starts[s] + len(case.sequences[s]) - k)
+    want_f = case.oracle.lookup_packed(_expand_neighbours(case.gt.kmers(np.array(last_ids)), k, W))["kmer_id"].reshape(-1, 8)
+    want_b = case.oracle.lookup_packed(_expand_neighbours(case.gt.kmers(np.array(first_ids)), k, W))["kmer_id"].reshape(-1, 8)
+    assert (got[:, :4] == want_f[:, :4]).all() and (got[:, 4:] == want_b[:, 4:]).all()
+    with pytest.raises(sshash_amd.SSHashError):
+        d.string_neighbours([len(case.sequences)])
