@@ -415,3 +415,33 @@ def test_string_neighbours(case_name, request):
     assert (got[:, :4] == want_f[:, :4]).all() and (got[:, 4:] == want_b[:, 4:]).all()
     with pytest.raises(sshash_amd.SSHashError):
         d.string_neighbours([len(case.sequences)])
+
+
+def test_concurrent_host_callers_on_one_handle(case_se_regular):
+    """The query entry points are re-entrant on a handle (const methods in the reference): four host threads
+    looking up different batches at once (ctypes drops the GIL) get the answers of sequential calls."""
+    import threading
+
+    case = case_se_regular
+    d = case.dict.to_device(0)
+    batches = [case.queries(150000, 150000, seed=100 + t) for t in range(4)]
+    want = [case.oracle.lookup_ids(q) for q in batches]
+    got = [None] * 4
+    errors = []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                got[t] = d.lookup(batches[t]).kmer_id
+                assert (d.is_member(batches[t]) == (got[t] != sshash_amd.INVALID_U64)).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(4):
+        assert (got[t] == want[t]).all()
