@@ -7,6 +7,8 @@
 // memory system can deliver for this granularity.
 //
 //   gather_bench <array MiB> <lanes> <depth> <width: 8|16|32|64, or 65 = 16 B + dependent 8 B in the same sector> [repeats]
+//                [window MiB: the workgroups in flight at one time confine their reads to one random window of this
+//                 size (0 = whole array): what sorting a batch by table region could buy]
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -31,12 +33,18 @@ __device__ __forceinline__ uint64_t mix(uint64_t x) {
 }
 
 template <int WIDTH>
-__global__ void __launch_bounds__(256) chase(const uint64_t* __restrict__ a, uint64_t n_units, int depth, uint64_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) chase(const uint64_t* __restrict__ a, uint64_t n_units, int depth, uint64_t* __restrict__ out,
+                                             uint64_t window_units) {
     const uint64_t tid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    uint64_t base = 0;
+    if (window_units) {  // 8192 consecutive workgroups (about four times what is resident) share a window
+        base = uint64_t((__uint128_t(mix((blockIdx.x >> 13) + 77)) * (n_units - window_units)) >> 64);
+        n_units = window_units;
+    }
     uint64_t x = mix(tid * 0x9E3779B97F4A7C15ULL + 1);
     uint64_t acc = 0;
     for (int d = 0; d < depth; ++d) {
-        const uint64_t unit = uint64_t((__uint128_t(x) * n_units) >> 64);
+        const uint64_t unit = base + uint64_t((__uint128_t(x) * n_units) >> 64);
         if constexpr (WIDTH == 8) {
             acc += a[unit];
         } else if constexpr (WIDTH == 16) {
@@ -67,6 +75,7 @@ int main(int argc, char** argv) {
     const int depth = argc > 3 ? atoi(argv[3]) : 4;
     const int width = argc > 4 ? atoi(argv[4]) : 16;
     const int repeats = argc > 5 ? atoi(argv[5]) : 5;
+    const uint64_t window_mib = argc > 6 ? strtoull(argv[6], nullptr, 10) : 0;
     const uint64_t bytes = mib << 20;
     uint64_t* a = nullptr;
     uint64_t* out = nullptr;
@@ -80,6 +89,7 @@ int main(int argc, char** argv) {
             CHECK(hipMemcpy(reinterpret_cast<char*>(a) + off, h.data(), std::min<uint64_t>(h.size() * 8, bytes - off), hipMemcpyHostToDevice));
     }
     const uint64_t n_units = bytes / uint64_t(width == 65 ? 64 : width);
+    const uint64_t window_units = (window_mib << 20) / uint64_t(width == 65 ? 64 : width);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -87,11 +97,11 @@ int main(int argc, char** argv) {
     float best = 1e30f;
     for (int r = 0; r < repeats + 1; ++r) {
         CHECK(hipEventRecord(e0));
-        if (width == 8) hipLaunchKernelGGL(chase<8>, grid, block, 0, 0, a, n_units, depth, out);
-        else if (width == 16) hipLaunchKernelGGL(chase<16>, grid, block, 0, 0, a, n_units, depth, out);
-        else if (width == 32) hipLaunchKernelGGL(chase<32>, grid, block, 0, 0, a, n_units, depth, out);
-        else if (width == 64) hipLaunchKernelGGL(chase<64>, grid, block, 0, 0, a, n_units, depth, out);
-        else hipLaunchKernelGGL(chase<65>, grid, block, 0, 0, a, n_units, depth, out);
+        if (width == 8) hipLaunchKernelGGL(chase<8>, grid, block, 0, 0, a, n_units, depth, out, window_units);
+        else if (width == 16) hipLaunchKernelGGL(chase<16>, grid, block, 0, 0, a, n_units, depth, out, window_units);
+        else if (width == 32) hipLaunchKernelGGL(chase<32>, grid, block, 0, 0, a, n_units, depth, out, window_units);
+        else if (width == 64) hipLaunchKernelGGL(chase<64>, grid, block, 0, 0, a, n_units, depth, out, window_units);
+        else hipLaunchKernelGGL(chase<65>, grid, block, 0, 0, a, n_units, depth, out, window_units);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
@@ -99,9 +109,9 @@ int main(int argc, char** argv) {
         if (r > 0 && ms < best) best = ms;
     }
     const double reads = double(lanes) * depth;
-    printf("{\"array_MiB\": %llu, \"lanes\": %llu, \"depth\": %d, \"width\": %d, \"ms\": %.3f, \"Greads_per_s\": %.2f, "
+    printf("{\"array_MiB\": %llu, \"window_MiB\": %llu, \"lanes\": %llu, \"depth\": %d, \"width\": %d, \"ms\": %.3f, \"Greads_per_s\": %.2f, "
            "\"GBps_useful\": %.1f, \"GBps_64B_sectors\": %.1f}\n",
-           (unsigned long long)mib, (unsigned long long)lanes, depth, width, best, reads / best / 1e6,
+           (unsigned long long)mib, (unsigned long long)window_mib, (unsigned long long)lanes, depth, width, best, reads / best / 1e6,
            reads * width / best / 1e6, reads * 64 / best / 1e6);
     return 0;
 }
