@@ -67,11 +67,18 @@ inline uint32_t bits_for(uint64_t max_value) {  // width able to hold max_value,
 
 namespace detail {
 
+struct duplicate_keys_error : error {
+    duplicate_keys_error()
+        : error(error_kind::build, "mphf: two keys are equal (a minimizer or k-mer occurs twice: the input is not a "
+                                   "spectrum-preserving string set, every k-mer must occur once)") {}
+};
+
 struct part_build_result {
     std::vector<uint32_t> pilots;      // one per bucket
     std::vector<uint32_t> free_slots;  // table_size - num_keys entries
     uint32_t max_pilot = 0;
     bool ok = true;
+    bool duplicate_keys = false;  // two keys with the same 128-bit hash: no seed can separate them
 };
 
 /* Search the pilots of one partition. `hashes` are the (h1,h2) of this partition's keys. */
@@ -98,7 +105,21 @@ inline part_build_result build_partition(std::vector<hash128> const& hashes,
         std::vector<uint32_t> cursor(bucket_begin.begin(), bucket_begin.end() - 1);
         for (uint32_t i = 0; i < n; ++i) h2[cursor[bucket_of[i]]++] = hashes[i].second;
     }
-    /* two keys of one bucket with equal h2 can never be separated */
+    /* two keys of one bucket with equal h2 can never be separated: that is a repeated key (for the skew index, a
+       k-mer that occurs twice in the input, which is then not a spectrum-preserving string set). Fail at once
+       instead of searching 2^28 pilots under 16 seeds. */
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t begin = bucket_begin[b], size = bucket_begin[b + 1] - begin;
+        if (size < 2) continue;
+        std::sort(h2.begin() + begin, h2.begin() + begin + size);
+        for (uint32_t j = 1; j < size; ++j) {
+            if (h2[begin + j] == h2[begin + j - 1]) {
+                res.ok = false;
+                res.duplicate_keys = true;
+                return res;
+            }
+        }
+    }
     /* buckets in non-increasing size order (counting sort by size) */
     uint32_t max_size = 0;
     for (uint32_t b = 0; b < nb; ++b) max_size = std::max(max_size, bucket_begin[b + 1] - bucket_begin[b]);
@@ -268,6 +289,7 @@ inline void mphf_build_once(mphf_host& f, uint64_t n, HashOf&& hash_of, mphf_bui
     });
     uint32_t max_pilot = 0;
     for (auto& r : results) {
+        if (r.duplicate_keys) throw detail::duplicate_keys_error();
         if (!r.ok) throw error(error_kind::build, "mphf: pilot search failed");
         max_pilot = std::max(max_pilot, r.max_pilot);
     }
@@ -290,6 +312,8 @@ inline void mphf_build(mphf_host& f, uint64_t n, MakeHashOf&& make_hash_of, mphf
         try {
             mphf_build_once(f, n, make_hash_of(cfg.seed), cfg);
             return;
+        } catch (detail::duplicate_keys_error const&) {
+            throw;  // another seed cannot help
         } catch (error const&) { cfg.seed += 0x9E3779B97F4A7C15ULL; }
     }
     throw error(error_kind::build, "mphf: construction failed after 16 seeds");

@@ -134,3 +134,24 @@ def test_table_key_function_is_strand_symmetric(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "check_table_key.cpp"), "-o", exe])
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and p.stdout.startswith("OK "), p.stdout + p.stderr
+
+
+def test_repeated_kmer_in_a_heavy_bucket_fails_fast(tmp_path):
+    """Every k-mer of the input must occur once (a spectrum-preserving string set). A k-mer repeated often enough
+    to land in the skew index makes two MPHF keys equal; the builder must say so at once instead of searching
+    pilots under seed after seed."""
+    import time
+
+    rng = np.random.default_rng(5)
+    from conftest import random_dna
+
+    core = random_dna(rng, 31)
+    p = tmp_path / "dup.fa"
+    with open(p, "w") as f:
+        for i in range(200):
+            f.write(">\n" + random_dna(rng, 12) + core + random_dna(rng, 12) + "\n")
+    t0 = time.time()
+    with pytest.raises(sshash_amd.SSHashError) as e:
+        sshash_amd.Dictionary.build(str(p), k=31, m=13, num_threads=2)
+    assert e.value.status == 7 and "occur once" in str(e.value)
+    assert time.time() - t0 < 20
