@@ -475,6 +475,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 const uint64_t m = std::min(piece, n - at);
                 const uint32_t nblocks = uint32_t((m + block - 1) / block);
                 const uint32_t shard_capacity = ((nblocks + DEFER_SHARDS - 1) / DEFER_SHARDS) * block;
+                std::lock_guard<std::mutex> enqueue(rep->launch_mutex);
                 uint32_t* scratch = static_cast<uint32_t*>(
                     rep->scratch_for(stream, (uint64_t(DEFER_SHARDS) * shard_capacity + DEFER_SHARDS) * sizeof(uint32_t)));
                 HIP_CHECK(hipMemsetAsync(scratch, 0, DEFER_SHARDS * sizeof(uint32_t), stream));

@@ -53,6 +53,9 @@ struct device_replica {
        ordered, so a buffer keyed by the stream can be reused without synchronisation; it only grows
        (hipFree of the old block synchronises implicitly) and lives as long as the replica: the caller's
        streams are few and the host path's lanes keep theirs. */
+    /* held while one launch sequence (queue reset, phase 1, phase 2) is enqueued: two host threads that share a
+       stream (the null stream, typically) must not interleave their sequences, which share that stream's scratch */
+    mutable std::mutex launch_mutex;
     mutable std::mutex scratch_mutex;
     mutable std::unordered_map<void*, std::pair<void*, size_t>> scratch;
     void* scratch_for(void* stream, size_t bytes) const {

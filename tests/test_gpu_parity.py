@@ -445,3 +445,32 @@ def test_concurrent_host_callers_on_one_handle(case_se_regular):
     assert not errors, errors
     for t in range(4):
         assert (got[t] == want[t]).all()
+
+
+def test_concurrent_device_callers_on_the_null_stream(case_se_regular):
+    """Two host threads may share a stream (the null stream): their launch sequences share that stream's
+    deferred-query scratch and must be enqueued one after the other, never interleaved."""
+    import threading
+
+    import torch
+
+    case = case_se_regular
+    d = case.dict.to_device(0)
+    batches = [case.queries(200000, 200000, seed=300 + t) for t in range(4)]
+    want = [case.oracle.lookup_ids(q) for q in batches]
+    dq = [torch.from_numpy(q.view(np.int64)).cuda() for q in batches]
+    out = [torch.empty(q.size, dtype=torch.int64, device="cuda") for q in batches]
+    torch.cuda.synchronize()
+
+    def work(t):
+        for _ in range(20):
+            d.lookup_device(0, dq[t].data_ptr(), batches[t].size, out[t].data_ptr(), stream=0)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    for t in range(4):
+        assert (out[t].cpu().numpy().view(np.uint64) == want[t]).all()
