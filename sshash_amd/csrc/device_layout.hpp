@@ -60,9 +60,9 @@
 //               over both strands (equal minima = tie, left to the structures above) -- one key for both
 //               strands, whatever the dictionary's own minimizer flavour. Built and probed with the same
 //               function, the table need not follow the reference's minimizer hash: it uses a 32-bit one;
-//        slot   32 bytes, 32-byte aligned; a key lives in one of four hashed slots (first free one
-//               wins, 3 slots per key), SK_CHOICES = 4:
-//                 d0  bit0 valid | bit1 list | bit2 strand | bits 3-6 go-on flags, one per choice |
+//        slot   32 bytes, 32-byte aligned; a key lives in one of five hashed slots (first free one
+//               wins, 3 slots per key), SK_CHOICES = 5:
+//                 d0  bit0 valid | bit1 list | bit2 strand | bits 3-7 go-on flags, one per choice |
 //                     bits 8-13 left | bits 14-19 right
 //                 d1  string id (inline) or number of occurrences (list; 0 = too long, defer)
 //                 d2,d3  position of the key occurrence / list begin (40 bits) | fingerprint of the key << 40
@@ -142,8 +142,9 @@ SSH_HD uint64_t directory_entry(uint64_t code, uint32_t fp) { return code | (uin
 /* ---- super-k-mer table (5) ---- */
 constexpr uint32_t SK_VALID = 1u, SK_LIST = 2u, SK_STRAND = 4u;
 constexpr uint32_t SK_GO_ON = 8u;             // << c: a key whose choice c is this slot lives at a later choice ...
-constexpr uint32_t SK_CHOICES = 4;            // ... or, for the last choice, in no slot at all
+constexpr uint32_t SK_CHOICES = 5;            // ... or, for the last choice, in no slot at all (flags: bits 3-7)
 constexpr uint32_t SK_LEFT_SHIFT = 8, SK_RIGHT_SHIFT = 14;
+static_assert((SK_GO_ON << (SK_CHOICES - 1)) < (1u << SK_LEFT_SHIFT), "go-on flags must stay below the extent fields");
 constexpr uint32_t SK_LIST_MAX = 64;          // longer occurrence lists are left to the complete path
 constexpr double SK_SLOTS_PER_KEY = 3.0;
 
@@ -172,6 +173,7 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_slots) {
     h.slot[2] = mulhi32(uint32_t(b >> 32), num_slots);
     h.slot[3] = mulhi32(uint32_t(b), num_slots);
     const uint64_t c = (a + b) * 0xD6E8FEB86659FD93ULL;
+    h.slot[4] = mulhi32(uint32_t(c), num_slots);
     h.fingerprint = uint32_t(c >> 40);
     return h;
 }
