@@ -155,7 +155,9 @@ sshash_status sshash_weight_device(const sshash_dict* d, int device, const uint6
 
 /* ---- dictionary::kmer_neighbours(Kmer, bool): include/dictionary.hpp:59-61, src/dictionary.cpp:111-126,176-187.
  *      Batched: every array of `out` holds 8*n entries; entry 8*i + c (c = 0..3) is the lookup of the forward
- *      neighbour suffix(kmer i) + "ACGT"[c], entry 8*i + 4 + c the backward neighbour "ACGT"[c] + prefix(kmer i)
+ *      neighbour suffix(kmer i) + "ACTG"[c], entry 8*i + 4 + c the backward neighbour "ACTG"[c] + prefix(kmer i): c is
+ *      the 2-bit code of the character, the reference's alphabet order (include/kmer.hpp:118; its own checker indexes
+ *      forward[char_to_uint(next)], test/check_from_file.hpp:198-216)
  *      (neighbourhood::forward / ::backward, include/util.hpp:78-81). Same pointer rules as the lookups. */
 sshash_status sshash_neighbours_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
                                               int check_reverse_complement, const sshash_results* out, void* hip_stream);

@@ -136,7 +136,8 @@ public:
     }
 
     /* Navigational query -- include/dictionary.hpp:59-61 (kmer_neighbours): ids of the forward neighbours
-       suffix + A,C,G,T at [8*i .. 8*i+3] and of the backward neighbours A,C,G,T + prefix at [8*i+4 .. 8*i+7]
+       suffix + A,C,T,G at [8*i .. 8*i+3] and of the backward neighbours A,C,T,G + prefix at [8*i+4 .. 8*i+7]
+       (the reference's alphabet order "ACTG": index = 2-bit code of the character)
        of packed k-mer i; INVALID for a neighbour that is not in the dictionary. */
     std::vector<uint64_t> neighbours_ids(uint64_t const* kmers, uint64_t n, bool check_reverse_complement = true) const {
         std::vector<uint64_t> ids(8 * n);

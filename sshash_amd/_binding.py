@@ -389,8 +389,8 @@ class Dictionary:
 
     def neighbours(self, kmers: np.ndarray, check_reverse_complement: bool = True, full: bool = False) -> LookupResult:
         """Batched dictionary::kmer_neighbours (reference src/dictionary.cpp:111-126,176-187) over packed k-mers:
-        every array of the result has 8 entries per query -- forward neighbours with A,C,G,T appended, then
-        backward neighbours with A,C,G,T prepended."""
+        every array of the result has 8 entries per query -- forward neighbours with A,C,T,G appended (index = 2-bit
+        code of the character, the reference's alphabet order), then backward neighbours with A,C,T,G prepended."""
         a = np.ascontiguousarray(kmers, dtype=np.uint64)
         n = a.size // self.words_per_kmer()
         res = LookupResult(kmer_id=np.empty(8 * n, dtype=np.uint64))

@@ -44,7 +44,7 @@ public:
                              result_view const& d_out, uint8_t* d_member, void* stream) const;
 
     /* kmer_neighbours (src/dictionary.cpp:111-187) for a batch: the 8 lookups per query, results at 8*i + which
-       (which = 0..3 forward with A,C,G,T; 4..7 backward with A,C,G,T). Device buffers / host buffers. */
+       (which = 0..3 forward with A,C,T,G -- the character's 2-bit code --; 4..7 backward likewise). Device buffers / host buffers. */
     void neighbours_packed_device(int device, uint64_t const* d_kmers, uint64_t n, bool check_rc, out_mode mode,
                                   result_view const& d_out, void* stream) const;
     void neighbours_packed_host(uint64_t const* h_kmers, uint64_t n, bool check_rc, out_mode mode,

@@ -191,11 +191,11 @@ SSH_HD kmer_w<W> kmer_roll_rc(kmer_w<W> x, uint64_t code, uint32_t k) {
 }
 
 /* Neighbours of a k-mer in the de Bruijn graph (src/dictionary.cpp:111-126): which = 0..3 the forward
-   neighbour suffix(x) + "ACGT"[which], which = 4..7 the backward neighbour "ACGT"[which - 4] + prefix(x). */
+   neighbour suffix(x) + "ACTG"[which], which = 4..7 the backward neighbour "ACTG"[which - 4] + prefix(x):
+   neighbourhood::forward/backward are indexed by the character's code (alphabet "ACTG", include/kmer.hpp:118). */
 template <int W>
 SSH_HD kmer_w<W> kmer_neighbour(kmer_w<W> const& x, uint32_t which, uint32_t k) {
-    const uint64_t c = which & 3;
-    const uint64_t code = c ^ (c >> 1);  // A C G T -> 0 1 3 2 (include/kmer.hpp:118)
+    const uint64_t code = which & 3;
     return which < 4 ? kmer_roll<W>(x, code, k) : kmer_roll_rc<W>(x, code ^ 2, k);
 }
 

@@ -313,7 +313,7 @@ def _expand_neighbours(q, k, W):
     """Independent expansion of kmer_neighbours' 8 queries (src/dictionary.cpp:111-126) with Python integers."""
     out = np.empty(q.size * 8, dtype=np.uint64)
     mask = (1 << (2 * k)) - 1
-    codes = [0, 1, 3, 2]  # A C G T
+    codes = [0, 1, 2, 3]  # entry c = the character with code c: A C T G (reference alphabet, include/kmer.hpp:118)
     for i in range(q.size // W):
         x = int(q[i * W]) | (int(q[i * W + 1]) << 64 if W == 2 else 0)
         for c in range(4):
@@ -474,3 +474,25 @@ def test_concurrent_device_callers_on_the_null_stream(case_se_regular):
     torch.cuda.synchronize()
     for t in range(4):
         assert (out[t].cpu().numpy().view(np.uint64) == want[t]).all()
+
+
+@pytest.mark.parametrize("case_name", ["case_skew_regular", "case_skew_canonical", "case_k63_canonical"])
+def test_navigational_queries_follow_the_input_strings(case_name, request):
+    """The reference's own check (test/check_from_file.hpp:174-221): for every k-mer of the input, forward[code of
+    the next base] and backward[code of the previous base] must be in the dictionary -- here also with the id the
+    neighbour has in file order (i + 1 and i - 1)."""
+    case = request.getfixturevalue(case_name)
+    d = case.dict.to_device(0)
+    k = case.k
+    n = case.gt.num_kmers
+    ids = d.neighbours(case.gt.kmers(np.arange(n))).kmer_id.reshape(n, 8)
+    code = {"A": 0, "C": 1, "T": 2, "G": 3}
+    i = 0
+    for s in case.sequences:
+        for j in range(len(s) - k + 1):
+            if j + k < len(s):
+                assert ids[i, code[s[j + k]]] == i + 1
+            if j > 0:
+                assert ids[i, 4 + code[s[j - 1]]] == i - 1
+            i += 1
+    assert i == n
