@@ -164,6 +164,10 @@ sshash_status sshash_neighbours_packed_device(const sshash_dict* d, int device, 
 sshash_status sshash_neighbours_packed(const sshash_dict* d, const uint64_t* kmers, uint64_t n,
                                        int check_reverse_complement, const sshash_results* out);
 
+/* dictionary::string_size(string_id): include/dictionary.hpp:44-46, src/dictionary.cpp:102-109 -- the number of
+ * k-mers of each string (its length is size + k - 1). Host arrays. */
+sshash_status sshash_string_size(const sshash_dict* d, const uint64_t* string_ids, uint64_t n, uint64_t* out_sizes);
+
 /* dictionary::string_neighbours(string_id, bool): include/dictionary.hpp:62, src/dictionary.cpp:189-201 -- the
  * forward neighbours of the string's last k-mer and the backward neighbours of its first one, same layout. */
 sshash_status sshash_string_neighbours(const sshash_dict* d, const uint64_t* string_ids, uint64_t n,

@@ -147,6 +147,13 @@ public:
         return ids;
     }
 
+    /* Return the number of kmers in string -- include/dictionary.hpp:44-46 */
+    uint64_t string_size(uint64_t string_id) const {
+        uint64_t size = 0;
+        check(sshash_string_size(m_h, &string_id, 1, &size));
+        return size;
+    }
+
     /* Return the weight of the kmer given its id -- include/dictionary.hpp (weight), src/dictionary.cpp:96-100 */
     bool weighted() const { return m_info.weighted != 0; }
     uint64_t weight(uint64_t kmer_id) const {

@@ -155,3 +155,12 @@ def test_repeated_kmer_in_a_heavy_bucket_fails_fast(tmp_path):
         sshash_amd.Dictionary.build(str(p), k=31, m=13, num_threads=2)
     assert e.value.status == 7 and "occur once" in str(e.value)
     assert time.time() - t0 < 20
+
+
+def test_string_size(case_skew_regular):
+    case = case_skew_regular
+    sizes = case.dict.string_size(range(len(case.sequences)))
+    assert list(sizes) == [len(s) - case.k + 1 for s in case.sequences]
+    assert int(sizes.sum()) == case.dict.num_kmers()
+    with pytest.raises(sshash_amd.SSHashError):
+        case.dict.string_size([len(case.sequences)])
