@@ -162,6 +162,16 @@ public:
         return w;
     }
 
+    /* include/dictionary.hpp:62 (string_neighbours): same layout, forward neighbours of the string's last k-mer and
+       backward neighbours of its first one */
+    std::vector<uint64_t> string_neighbours_ids(uint64_t const* string_ids, uint64_t n, bool check_reverse_complement = true) const {
+        std::vector<uint64_t> ids(8 * n);
+        sshash_results out{};
+        out.kmer_id = ids.data();
+        check(sshash_string_neighbours(m_h, string_ids, n, check_reverse_complement, &out));
+        return ids;
+    }
+
     /* Membership queries -- include/dictionary.hpp:74-76 */
     bool is_member(char const* string_kmer, bool check_reverse_complement = true) const {
         uint8_t out = 0;

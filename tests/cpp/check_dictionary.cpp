@@ -161,6 +161,36 @@ static bool check_negative(dictionary const& dict) {
     return true;
 }
 
+/* test/check_from_file.hpp:174-221 (kmer_neighbours along the input) and test/check.hpp:99-141 (string_neighbours
+   = backward neighbours of a string's first k-mer + forward neighbours of its last one), batched */
+static bool check_navigational(dictionary const& dict, std::vector<std::string> const& seqs) {
+    std::cout << "checking correctness of navigational queries for kmers and strings..." << std::endl;
+    const uint64_t k = dict.k(), W = dict.words_per_kmer();
+    auto code = [](char c) { return (uint64_t(uint8_t(c)) >> 1) & 3; };
+    uint64_t kmer_id = 0;
+    for (uint64_t s = 0; s < seqs.size(); ++s) {
+        std::string const& seq = seqs[s];
+        const uint64_t n = seq.size() - k + 1;
+        if (dict.string_size(s) != n) FAIL("string_size of string " << s);
+        std::vector<uint64_t> packed(n * W, 0);
+        for (uint64_t i = 0; i < n; ++i)
+            for (uint64_t j = 0; j < k; ++j) packed[i * W + (2 * j) / 64] |= code(seq[i + j]) << ((2 * j) % 64);
+        const std::vector<uint64_t> nb = dict.neighbours_ids(packed.data(), n);
+        for (uint64_t i = 0; i < n; ++i) {
+            if (i + 1 < n && nb[8 * i + code(seq[i + k])] != kmer_id + i + 1) FAIL("expected forward[" << seq[i + k] << "]");
+            if (i > 0 && nb[8 * i + 4 + code(seq[i - 1])] != kmer_id + i - 1) FAIL("expected backward[" << seq[i - 1] << "]");
+        }
+        const std::vector<uint64_t> sn = dict.string_neighbours_ids(&s, 1);
+        for (uint64_t c = 0; c < 4; ++c) {
+            if (sn[c] != nb[8 * (n - 1) + c]) FAIL("string_neighbours forward of string " << s);
+            if (sn[4 + c] != nb[4 + c]) FAIL("string_neighbours backward of string " << s);
+        }
+        kmer_id += n;
+        if (s >= 400) break;  // the batched form makes one round trip per string: a prefix of the file is enough
+    }
+    return true;
+}
+
 int main(int argc, char** argv) {
     if (argc < 4) {
         std::cerr << "Usage: " << argv[0] << " <input.fa[.gz]> <k> <m> [--canonical]" << std::endl;
@@ -179,6 +209,7 @@ int main(int argc, char** argv) {
         if (!check_lookup_access(dict, seqs)) return 1;
         if (!check_every_id(dict)) return 1;
         if (!check_negative(dict)) return 1;
+        if (!check_navigational(dict, seqs)) return 1;
         /* error channel: exceptions with the reference's wording */
         try {
             dictionary other;
