@@ -495,6 +495,17 @@ void build_from_fasta(host_index& idx, std::string const& filename, build_option
             line.append(buf.data(), n);
         }
     };
+    /* Cuttlefish segment files ("<id>\t<sequence>" per line, src/builder/encode_strings.cpp:79-80) by extension,
+       as the reference does (src/builder/encode_strings.cpp:226-262) */
+    auto ends_with = [&](char const* suffix) {
+        const size_t n = strlen(suffix);
+        return filename.size() >= n && filename.compare(filename.size() - n, n, suffix) == 0;
+    };
+    const bool cf_seg = ends_with(".cf_seg") || ends_with(".cf_seg.gz");
+    if (cf_seg && opt.weighted) {
+        gzclose(f);
+        throw error(error_kind::build, "weights are read from FASTA headers: a .cf_seg input has none");
+    }
     std::string header, seq;
     bool eof = false;
     /* run-length intervals of weights over the k-mers in file order (encode_strings.cpp:73-75,120-132,216-218) */
@@ -530,8 +541,14 @@ void build_from_fasta(host_index& idx, std::string const& filename, build_option
                 }
             }
         }
-        getline(seq, eof);
-        if (eof) break;  // a last line without '\n' is dropped, as in encode_strings.cpp:139-140
+        if (cf_seg) {  // the line just read is "<id>\t<sequence>"
+            if (eof) break;
+            const size_t tab = header.find('\t');
+            seq = tab == std::string::npos ? std::string() : header.substr(tab + 1);
+        } else {
+            getline(seq, eof);
+            if (eof) break;  // a last line without '\n' is dropped, as in encode_strings.cpp:139-140
+        }
         if (!seq.empty() && seq.back() == '\r') seq.pop_back();
         if (seq.size() < opt.k) {
             gzclose(f);

@@ -164,3 +164,24 @@ def test_string_size(case_skew_regular):
     assert int(sizes.sum()) == case.dict.num_kmers()
     with pytest.raises(sshash_amd.SSHashError):
         case.dict.string_size([len(case.sequences)])
+
+
+def test_cuttlefish_segment_input(case_skew_regular, tmp_path):
+    """'.cf_seg' inputs ("<id>\\t<sequence>" per line) are recognised by extension as the reference's builder does
+    (src/builder/encode_strings.cpp:79-80,246-258): same dictionary as from the FASTA form."""
+    import gzip
+
+    case = case_skew_regular
+    plain, zipped = tmp_path / "in.cf_seg", tmp_path / "in.cf_seg.gz"
+    text = "".join(f"{i}\t{s}\n" for i, s in enumerate(case.sequences))
+    plain.write_text(text)
+    with gzip.open(zipped, "wt") as f:
+        f.write(text)
+    for p in (plain, zipped):
+        d = sshash_amd.Dictionary.build(str(p), k=case.k, m=case.m, num_threads=2)
+        assert (d.num_kmers(), d.num_strings(), d.num_minimizers()) == (case.dict.num_kmers(), case.dict.num_strings(),
+                                                                       case.dict.num_minimizers())
+        ids = np.arange(0, d.num_kmers(), 7, dtype=np.uint64)
+        assert (d.access_packed(ids) == case.dict.access_packed(ids)).all()
+    with pytest.raises(sshash_amd.SSHashError):
+        sshash_amd.Dictionary.build(str(plain), k=case.k, m=case.m, weighted=True)
