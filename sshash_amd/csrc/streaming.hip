@@ -18,6 +18,9 @@
 // Output: the six counters of streaming_query_report (include/util.hpp:21-36).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
+#include <cstring>
 #include <exception>
 #include <stdexcept>
 #include <thread>
@@ -199,62 +202,91 @@ void engine::streaming_query_device(int device, char const* d_bases, uint64_t co
     if (prev != device) HIP_CHECK(hipSetDevice(prev));
 }
 
+/* Host buffers: the reads are cut into pieces of at most ~32 MiB of bases; per replica up to eight lanes (the
+   pooled pinned pipelines of the lookup host path, replica.hpp) pull pieces from a shared counter and run
+   copy-in -> H2D -> kernel, accumulating the six counters in device memory; one read-back per lane. */
 streaming_report engine::streaming_query_host(char const* bases, uint64_t const* read_offsets, uint64_t n_reads) const {
     streaming_report total;
     if (n_reads == 0) return total;
     const std::vector<int> devs = devices();
     if (devs.empty()) throw error(error_kind::no_device, "dictionary is not resident on any device (call sshash_to_device first)");
     const uint64_t G = devs.size();
-    std::vector<std::exception_ptr> errors(G);
-    std::vector<streaming_report> partial(G);
-    std::vector<std::thread> workers;
-    for (uint64_t g = 0; g < G; ++g) {
-        workers.emplace_back([&, g] {
-            try {
-                const uint64_t lo = n_reads * g / G, hi = n_reads * (g + 1) / G;
-                if (lo == hi) return;
-                HIP_CHECK(hipSetDevice(devs[g]));
-                hipStream_t s;
-                HIP_CHECK(hipStreamCreate(&s));
-                uint64_t* d_report = nullptr;
-                HIP_CHECK(hipMalloc(&d_report, 6 * sizeof(uint64_t)));
-                HIP_CHECK(hipMemsetAsync(d_report, 0, 6 * sizeof(uint64_t), s));
-                /* chunks of at most ~1 GiB of bases */
-                const uint64_t max_bases = uint64_t(1) << 30;
-                uint64_t at = lo;
-                std::vector<uint64_t> rel;
-                while (at < hi) {
-                    uint64_t end = at;
-                    while (end < hi && (end == at || read_offsets[end + 1] - read_offsets[at] <= max_bases)) ++end;
-                    const uint64_t nb = read_offsets[end] - read_offsets[at];
-                    rel.resize(end - at + 1);
-                    for (uint64_t i = at; i <= end; ++i) rel[i - at] = read_offsets[i] - read_offsets[at];
-                    char* d_bases = nullptr;
-                    uint64_t* d_off = nullptr;
-                    HIP_CHECK(hipMalloc(&d_bases, std::max<uint64_t>(nb, 1)));
-                    HIP_CHECK(hipMalloc(&d_off, rel.size() * sizeof(uint64_t)));
-                    HIP_CHECK(hipMemcpyAsync(d_bases, bases + read_offsets[at], nb, hipMemcpyHostToDevice, s));
-                    HIP_CHECK(hipMemcpyAsync(d_off, rel.data(), rel.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-                    streaming_query_device(devs[g], d_bases, d_off, end - at, nb, d_report, s);
-                    HIP_CHECK(hipStreamSynchronize(s));
-                    HIP_CHECK(hipFree(d_bases));
-                    HIP_CHECK(hipFree(d_off));
-                    at = end;
-                }
-                uint64_t h[6];
-                HIP_CHECK(hipMemcpy(h, d_report, sizeof(h), hipMemcpyDeviceToHost));
-                HIP_CHECK(hipFree(d_report));
-                HIP_CHECK(hipStreamDestroy(s));
-                partial[g].num_kmers = h[0];
-                partial[g].num_positive_kmers = h[1];
-                partial[g].num_negative_kmers = h[2];
-                partial[g].num_invalid_kmers = h[3];
-                partial[g].num_searches = h[4];
-                partial[g].num_extensions = h[5];
-            } catch (...) { errors[g] = std::current_exception(); }
-        });
+    /* pieces: [first read, last read) with a bounded number of bases (a single longer read is its own piece) */
+    const uint64_t piece_bases = uint64_t(32) << 20, piece_reads = uint64_t(1) << 20;
+    std::vector<uint64_t> cuts{0};
+    uint64_t max_bases = 0, max_reads = 0;
+    for (uint64_t at = 0; at < n_reads;) {
+        uint64_t end = at + 1;
+        while (end < n_reads && end - at < piece_reads && read_offsets[end + 1] - read_offsets[at] <= piece_bases) ++end;
+        max_bases = std::max(max_bases, read_offsets[end] - read_offsets[at]);
+        max_reads = std::max(max_reads, end - at);
+        cuts.push_back(end);
+        at = end;
     }
-    for (auto& w : workers) w.join();
+    const uint64_t num_pieces = cuts.size() - 1;
+    const uint64_t off_bytes = (max_reads + 1) * sizeof(uint64_t);
+    const uint64_t bases_at = (off_bytes + 255) & ~uint64_t(255);
+    const uint64_t report_at = (bases_at + max_bases + 255) & ~uint64_t(255);
+    const uint64_t lane_bytes = report_at + 6 * sizeof(uint64_t);
+
+    std::atomic<uint64_t> next{0};
+    const uint64_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint64_t lanes_per_device = std::min<uint64_t>({(num_pieces + G - 1) / G, 8, std::max<uint64_t>(1, hw / G)});
+    const uint64_t num_lanes = lanes_per_device * G;
+    std::vector<std::exception_ptr> errors(num_lanes);
+    std::vector<streaming_report> partial(num_lanes);
+
+    auto run_lane = [&](uint64_t li) {
+        try {
+            const int device = devs[li % G];
+            device_replica const* rep = replica(device);
+            HIP_CHECK(hipSetDevice(device));
+            host_lane* lane = rep->acquire_lane(lane_bytes);
+            struct give_back {
+                device_replica const* rep;
+                host_lane* lane;
+                ~give_back() { rep->release_lane(lane); }
+            } guard{rep, lane};
+            hipStream_t s = lane->stream;
+            char* hp = static_cast<char*>(lane->pinned);
+            char* dp = static_cast<char*>(lane->device);
+            uint64_t* d_report = reinterpret_cast<uint64_t*>(dp + report_at);
+            HIP_CHECK(hipMemsetAsync(d_report, 0, 6 * sizeof(uint64_t), s));
+            for (;;) {
+                const uint64_t piece = next.fetch_add(1);
+                if (piece >= num_pieces) break;
+                const uint64_t first = cuts[piece], last = cuts[piece + 1];
+                const uint64_t nb = read_offsets[last] - read_offsets[first];
+                uint64_t* rel = reinterpret_cast<uint64_t*>(hp);
+                for (uint64_t i = first; i <= last; ++i) rel[i - first] = read_offsets[i] - read_offsets[first];
+                std::memcpy(hp + bases_at, bases + read_offsets[first], nb);
+                HIP_CHECK(hipMemcpyAsync(dp, hp, (last - first + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipMemcpyAsync(dp + bases_at, hp + bases_at, nb, hipMemcpyHostToDevice, s));
+                streaming_query_device(device, dp + bases_at, reinterpret_cast<uint64_t const*>(dp), last - first, nb, d_report, s);
+                HIP_CHECK(hipStreamSynchronize(s));  // the pinned block is reused by the next piece
+            }
+            uint64_t h[6];
+            HIP_CHECK(hipMemcpyAsync(h, d_report, sizeof(h), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            partial[li].num_kmers = h[0];
+            partial[li].num_positive_kmers = h[1];
+            partial[li].num_negative_kmers = h[2];
+            partial[li].num_invalid_kmers = h[3];
+            partial[li].num_searches = h[4];
+            partial[li].num_extensions = h[5];
+        } catch (...) { errors[li] = std::current_exception(); }
+    };
+
+    int prev = 0;
+    HIP_CHECK(hipGetDevice(&prev));
+    if (num_lanes == 1) {
+        run_lane(0);
+    } else {
+        std::vector<std::thread> workers;
+        for (uint64_t li = 0; li < num_lanes; ++li) workers.emplace_back(run_lane, li);
+        for (auto& w : workers) w.join();
+    }
+    (void)hipSetDevice(prev);
     for (auto const& e : errors)
         if (e) std::rethrow_exception(e);
     for (auto const& p : partial) {
