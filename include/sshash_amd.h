@@ -110,6 +110,11 @@ sshash_status sshash_get_info(const sshash_dict* d, sshash_info* info);
 /* ---- device residency (no reference counterpart: the reference is host-only) ------------- */
 int sshash_device_count(void);
 sshash_status sshash_to_device(sshash_dict* d, int device);
+/* The same, with the super-k-mer table (the largest device structure) partitioned over several
+ * GPUs: this replica builds the slots of the keys it owns only (shard `table_shard_id` of `num_table_shards`); queries
+ * are meant to reach it through sshash_route_bucket_by_key_device, but any query is still answered correctly (a key
+ * of another shard takes the complete path). Everything else is resident in full. */
+sshash_status sshash_to_device_table_shard(sshash_dict* d, int device, uint32_t num_table_shards, uint32_t table_shard_id);
 sshash_status sshash_device_bytes(const sshash_dict* d, int device, uint64_t* bytes);
 /* out = {bytes in HBM, minimizer-directory sectors (0 = disabled), sectors flagged overflow, keys in the directory,
  *        super-k-mer table slots (0 = disabled), its keys, keys held inline, keys left to the complete path} */
@@ -203,6 +208,11 @@ sshash_status sshash_route_packed_device(const sshash_dict* d, int device, const
 sshash_status sshash_route_bucket_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
                                          uint32_t num_shards, int check_reverse_complement, uint64_t* cursors,
                                          uint64_t* send, uint32_t* slots, void* hip_stream);
+/* Bucketing for table shards (sshash_to_device_table_shard): the owner of a query is the owner of its table key --
+ * strand-symmetric, so exactly ONE message per query. Same two-call protocol as above. */
+sshash_status sshash_route_bucket_by_key_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                                uint32_t num_shards, uint64_t* cursors, uint64_t* send, uint32_t* slots,
+                                                void* hip_stream);
 sshash_status sshash_route_combine_device(const sshash_dict* d, int device, const uint64_t* replies, const uint32_t* slots,
                                           uint64_t m, uint64_t* out, void* hip_stream);
 

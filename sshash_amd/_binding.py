@@ -135,6 +135,7 @@ def _load() -> C.CDLL:
         "sshash_get_info": (C.c_int, [P, C.POINTER(_Info)]),
         "sshash_device_count": (C.c_int, []),
         "sshash_to_device": (C.c_int, [P, C.c_int]),
+        "sshash_to_device_table_shard": (C.c_int, [P, C.c_int, C.c_uint32, C.c_uint32]),
         "sshash_device_bytes": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64)]),
         "sshash_device_stats": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64 * 8)]),
         "sshash_lookup_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
@@ -158,6 +159,7 @@ def _load() -> C.CDLL:
         "sshash_streaming_query_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, P, P]),
         "sshash_route_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_uint32, P, P, P]),
         "sshash_route_bucket_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_uint32, C.c_int, P, P, P, P]),
+        "sshash_route_bucket_by_key_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_uint32, P, P, P, P]),
         "sshash_route_combine_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, P, P]),
     }
     for name, (res, args) in sigs.items():
@@ -170,13 +172,13 @@ def _load() -> C.CDLL:
 
 C_ABI_SYMBOLS = (
     "sshash_last_error sshash_build_config_default sshash_build_from_fasta sshash_build_from_packed sshash_save "
-    "sshash_load sshash_free sshash_get_info sshash_device_count sshash_to_device sshash_device_bytes sshash_device_stats "
+    "sshash_load sshash_free sshash_get_info sshash_device_count sshash_to_device sshash_to_device_table_shard sshash_device_bytes sshash_device_stats "
     "sshash_lookup_packed_device sshash_lookup_ascii_device sshash_lookup_packed sshash_lookup_ascii "
     "sshash_neighbours_packed_device sshash_neighbours_packed sshash_string_neighbours sshash_string_size "
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
     "sshash_access_packed_device sshash_weight sshash_weight_device "
     "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device "
-    "sshash_route_packed_device sshash_route_bucket_device sshash_route_combine_device"
+    "sshash_route_packed_device sshash_route_bucket_device sshash_route_bucket_by_key_device sshash_route_combine_device"
 ).split()
 
 
@@ -315,7 +317,12 @@ class Dictionary:
     def weighted(self) -> bool: return bool(self._info.weighted)
 
     # ---- device residency -----------------------------------------------------------------
-    def to_device(self, device: int = 0) -> "Dictionary":
+    def to_device(self, device: int = 0, table_shards: int = 1, table_shard_id: int = 0) -> "Dictionary":
+        """Upload to `device`. table_shards > 1: the replica's super-k-mer table holds only its share of the keys
+        (see sharded.py)."""
+        if table_shards > 1:
+            _check(_load().sshash_to_device_table_shard(self._h, int(device), int(table_shards), int(table_shard_id)))
+            return self
         _check(_load().sshash_to_device(self._h, int(device)))
         return self
 
@@ -471,6 +478,13 @@ class Dictionary:
         _check(_load().sshash_route_bucket_device(self._h, int(device), C.c_void_p(d_kmers), int(n), int(num_shards),
                                                   1 if check_reverse_complement else 0, C.c_void_p(d_cursors),
                                                   C.c_void_p(d_send or None), C.c_void_p(d_slots or None), C.c_void_p(stream)))
+
+    def route_bucket_by_key_device(self, device: int, d_kmers: int, n: int, num_shards: int, d_cursors: int, d_send: int = 0,
+                                   d_slots: int = 0, stream: int = 0) -> None:
+        """The same for table shards: one message per query, to the owner of its table key."""
+        _check(_load().sshash_route_bucket_by_key_device(self._h, int(device), C.c_void_p(d_kmers), int(n), int(num_shards),
+                                                         C.c_void_p(d_cursors), C.c_void_p(d_send or None),
+                                                         C.c_void_p(d_slots or None), C.c_void_p(stream)))
 
     def route_combine_device(self, device: int, d_replies: int, d_slots: int, m: int, d_out: int, stream: int = 0) -> None:
         _check(_load().sshash_route_combine_device(self._h, int(device), C.c_void_p(d_replies), C.c_void_p(d_slots), int(m),

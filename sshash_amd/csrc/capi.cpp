@@ -362,7 +362,19 @@ sshash_status sshash_route_bucket_device(const sshash_dict* d, int device, const
                                          uint32_t num_shards, int check_rc, uint64_t* cursors, uint64_t* send,
                                          uint32_t* slots, void* hip_stream) {
     if (!d || (n && !kmers) || !cursors) return fail(SSHASH_ERR_ARGUMENT, "null argument");
-    return guarded([&] { d->eng->route_bucket_device(device, kmers, n, num_shards, check_rc != 0, cursors, send, slots, hip_stream); });
+    return guarded([&] { d->eng->route_bucket_device(device, kmers, n, num_shards, check_rc != 0, false, cursors, send, slots, hip_stream); });
+}
+
+sshash_status sshash_route_bucket_by_key_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
+                                                uint32_t num_shards, uint64_t* cursors, uint64_t* send, uint32_t* slots,
+                                                void* hip_stream) {
+    if (!d || (n && !kmers) || !cursors) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->route_bucket_device(device, kmers, n, num_shards, true, true, cursors, send, slots, hip_stream); });
+}
+
+sshash_status sshash_to_device_table_shard(sshash_dict* d, int device, uint32_t num_table_shards, uint32_t table_shard_id) {
+    if (!d) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->to_device(device, num_table_shards, table_shard_id); });
 }
 
 sshash_status sshash_route_combine_device(const sshash_dict* d, int device, const uint64_t* replies, const uint32_t* slots,

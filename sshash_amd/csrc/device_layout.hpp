@@ -78,6 +78,10 @@
 //               over-long lists and ties send the query to the complete path through (3)/(4).
 //      Ids are positions in the strings, so results are identical to the reference's; the table only
 //      changes how many reads it takes to find the position. SSHASH_AMD_SKTABLE=0 disables it.
+//      The table is by far the largest structure (~16 bytes per k-mer at k = 31); with several GPUs it can be
+//      partitioned by key (sk_owner): each replica then builds the slots of its own keys only, queries are
+//      routed to the owner of their key (one message per query, sharded.py), and a replica that meets a key
+//      it does not own simply takes the complete path -- every replica stays correct on its own.
 //
 // The remaining packed vectors (bucket offset lists, pilots, skew positions) keep their bit-packed
 // form: one 8-byte read, sometimes two adjacent ones.
@@ -153,7 +157,17 @@ struct sk_view {
     uint64_t const* occ;  // occurrences of the list keys: (position << 1) | strand
     uint32_t num_slots;
     uint32_t enabled;
+    /* table shard (multi-GPU, sharded.py): this replica's table holds only the keys with
+       sk_owner(key, num_shards) == shard_id; lookups of other keys take the complete path */
+    uint32_t num_shards;
+    uint32_t shard_id;
 };
+
+/* owner of a key when the super-k-mer table is partitioned over several GPUs (independent of the slot hashes) */
+SSH_HD uint32_t sk_owner(uint64_t key, uint32_t num_shards) {
+    const uint64_t h = (key + 0x632BE59BD9B4E019ULL) * 0xA0761D6478BD642FULL;
+    return mulhi32(uint32_t(h >> 32) ^ uint32_t(h >> 7), num_shards);
+}
 
 struct sk_hash_t {
     uint32_t slot[SK_CHOICES];

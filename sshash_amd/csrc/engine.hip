@@ -182,8 +182,9 @@ device_replica const* engine::replica(int device) const {
                              " (call sshash_to_device first)");
 }
 
-void engine::to_device(int device) {
+void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_id) {
     if (on_device(device)) return;
+    if (table_shards == 0 || table_shard_id >= table_shards) throw error(error_kind::argument, "table shard id must be < number of table shards");
     const int count = visible_device_count();
     if (count == 0) throw error(error_kind::no_device, "no HIP device visible: the lookup path requires an MI355X (no CPU fallback)");
     if (device < 0 || device >= count) throw error(error_kind::no_device, "invalid device ordinal " + std::to_string(device));
@@ -304,7 +305,7 @@ void engine::to_device(int device) {
         v.weight_starts = rep->put(idx.weight_starts);
         v.weight_values = rep->put(idx.weight_values);
     }
-    build_sk_table(*rep, idx);
+    build_sk_table(*rep, idx, table_shards, table_shard_id);
     m_replicas.push_back(std::move(rep));
 }
 
@@ -670,7 +671,7 @@ void engine::route_packed_device(int device, uint64_t const* d_kmers, uint64_t n
    same reservations simply add up to the per-shard message counts. */
 constexpr uint32_t ROUTE_MAX_SHARDS = 1024;
 
-template <int W, bool SCATTER>
+template <int W, bool SCATTER, bool BY_KEY>
 __global__ void __launch_bounds__(256)
 route_bucket_kernel(const dict_view d, const uint64_t* __restrict__ kmers, const uint64_t n, const uint32_t num_shards,
                     const bool check_rc, unsigned long long* __restrict__ cursors, uint64_t* __restrict__ send,
@@ -686,12 +687,19 @@ route_bucket_kernel(const dict_view d, const uint64_t* __restrict__ kmers, const
     if (active) {
         x = load_query<W, false>(kmers, i, d.k);
         const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
-        uint64_t f = compute_minimizer<W>(x, d.k, d.m, d.hash_magic).value;
-        uint64_t r = compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic).value;
-        if (d.canonical) f = r = (r < f ? r : f);
-        if (!check_rc) r = f;
-        owner_f = shard_of_minimizer(f, num_shards);
-        owner_r = shard_of_minimizer(r, num_shards);
+        if constexpr (BY_KEY) {
+            /* table shards: the owner of the k-mer's table key; a k-mer without a key (tie) can go to any
+               replica -- they all hold the complete path -- so it goes where its smaller strand hashes */
+            const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
+            owner_f = owner_r = sk_owner(kk.tie ? (kmer_less<W>(x_rc, x) ? x_rc.w[0] : x.w[0]) : kk.key, num_shards);
+        } else {
+            uint64_t f = compute_minimizer<W>(x, d.k, d.m, d.hash_magic).value;
+            uint64_t r = compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic).value;
+            if (d.canonical) f = r = (r < f ? r : f);
+            if (!check_rc) r = f;
+            owner_f = shard_of_minimizer(f, num_shards);
+            owner_r = shard_of_minimizer(r, num_shards);
+        }
         rank_f = atomicAdd(&local_count[owner_f], 1u);
         if (owner_r != owner_f) rank_r = atomicAdd(&local_count[owner_r], 1u);
     }
@@ -716,7 +724,7 @@ route_bucket_kernel(const dict_view d, const uint64_t* __restrict__ kmers, const
 }
 
 void engine::route_bucket_device(int device, uint64_t const* d_kmers, uint64_t n, uint32_t num_shards, bool check_rc,
-                                 uint64_t* d_cursors, uint64_t* d_send, uint32_t* d_slots, void* stream) const {
+                                 bool by_table_key, uint64_t* d_cursors, uint64_t* d_send, uint32_t* d_slots, void* stream) const {
     device_replica const* rep = replica(device);
     if (num_shards == 0 || num_shards > ROUTE_MAX_SHARDS) throw error(error_kind::argument, "num_shards must be in [1, 1024]");
     if (n >= (uint64_t(1) << 32)) throw error(error_kind::argument, "at most 2^32 - 1 queries per routed batch");
@@ -727,10 +735,18 @@ void engine::route_bucket_device(int device, uint64_t const* d_kmers, uint64_t n
     auto* cursors = reinterpret_cast<unsigned long long*>(d_cursors);
     hipStream_t s = hipStream_t(stream);
     const bool wide = rep->view.k > 31, scatter = d_send != nullptr;
-    if (!wide && !scatter) hipLaunchKernelGGL((route_bucket_kernel<1, false>), grid, block, 0, s, rep->view, d_kmers, n, num_shards, check_rc, cursors, d_send, d_slots);
-    else if (!wide && scatter) hipLaunchKernelGGL((route_bucket_kernel<1, true>), grid, block, 0, s, rep->view, d_kmers, n, num_shards, check_rc, cursors, d_send, d_slots);
-    else if (wide && !scatter) hipLaunchKernelGGL((route_bucket_kernel<2, false>), grid, block, 0, s, rep->view, d_kmers, n, num_shards, check_rc, cursors, d_send, d_slots);
-    else hipLaunchKernelGGL((route_bucket_kernel<2, true>), grid, block, 0, s, rep->view, d_kmers, n, num_shards, check_rc, cursors, d_send, d_slots);
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, s, rep->view, d_kmers, n, num_shards, check_rc, cursors, d_send, d_slots); };
+    if (by_table_key) {
+        if (!wide && !scatter) go(route_bucket_kernel<1, false, true>);
+        else if (!wide && scatter) go(route_bucket_kernel<1, true, true>);
+        else if (wide && !scatter) go(route_bucket_kernel<2, false, true>);
+        else go(route_bucket_kernel<2, true, true>);
+    } else {
+        if (!wide && !scatter) go(route_bucket_kernel<1, false, false>);
+        else if (!wide && scatter) go(route_bucket_kernel<1, true, false>);
+        else if (wide && !scatter) go(route_bucket_kernel<2, false, false>);
+        else go(route_bucket_kernel<2, true, false>);
+    }
     HIP_CHECK(hipGetLastError());
 }
 

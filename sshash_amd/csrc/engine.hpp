@@ -27,7 +27,8 @@ public:
     host_index const& index() const { return *m_idx; }
 
     /* Copy the dictionary into the HBM of `device` (no-op when already there). */
-    void to_device(int device);
+    /* table_shards > 1: this replica's super-k-mer table holds only its share of the keys (device_layout.hpp (5)) */
+    void to_device(int device, uint32_t table_shards = 1, uint32_t table_shard_id = 0);
     bool on_device(int device) const;
     std::vector<int> devices() const;
     uint64_t device_bytes(int device) const;
@@ -69,7 +70,7 @@ public:
 
     /* the same routing, bucketed on the device (see sshash_route_bucket_device in include/sshash_amd.h) */
     void route_bucket_device(int device, uint64_t const* d_kmers, uint64_t n, uint32_t num_shards, bool check_rc,
-                             uint64_t* d_cursors, uint64_t* d_send, uint32_t* d_slots, void* stream) const;
+                             bool by_table_key, uint64_t* d_cursors, uint64_t* d_send, uint32_t* d_slots, void* stream) const;
     void route_combine_device(int device, uint64_t const* d_replies, uint32_t const* d_slots, uint64_t m, uint64_t* d_out,
                               void* stream) const;
 

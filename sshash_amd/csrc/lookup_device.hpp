@@ -430,6 +430,11 @@ __device__ __forceinline__ fast_t fast_lookup_one(dict_view const& d, kmer_w<W> 
    sk_probe: follow the key's slot sequence. HIT / final MISS / DEFER to the complete path. `key_seen`:
    some slot on the way carried the key's fingerprint; a MISS without it proves that no k-mer with this
    key is in the dictionary (the streaming query's negative short-cut uses that). */
+/* may this replica's table settle a k-mer with key `kk`? (not on a tie; not a key owned by another table shard) */
+__device__ __forceinline__ bool sk_usable(dict_view const& d, sk_key_t const& kk) {
+    return !kk.tie && (d.sk.num_shards <= 1 || sk_owner(kk.key, d.sk.num_shards) == d.sk.shard_id);
+}
+
 template <int W>
 __device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
                                            bool& key_seen) {
@@ -516,7 +521,7 @@ template <int W>
 __device__ __forceinline__ fast_t sk_lookup_one(dict_view const& d, kmer_w<W> const& x, bool allow_rc, int8_t miss_orientation) {
     const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
     const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
-    if (kk.tie) return fast_unsettled(true);  // no strand-symmetric key
+    if (!sk_usable(d, kk)) return fast_unsettled(true);  // no strand-symmetric key, or a key of another table shard
     bool key_seen;
     fast_t r = sk_probe<W>(d, x, x_rc, kk, key_seen);
     if (r.outcome == FAST_MISS || (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc)) {

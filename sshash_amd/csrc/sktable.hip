@@ -44,7 +44,7 @@ sk_scan_kernel(const dict_view d, const uint64_t num_waves, uint32_t* __restrict
             const kmer_w<W> x = w.kmer;
             const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
             const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
-            if (!kk.tie) {
+            if (sk_usable(d, kk)) {  // (another table shard's key is left out like a tie)
                 key = kk.key;
                 const uint64_t p = uint64_t(i) + (kk.rc ? (d.k - d.m) - kk.pos : kk.pos);
                 val = (p << 1) | (kk.rc ? 1u : 0u);
@@ -198,12 +198,14 @@ struct temp_buffers {  // freed on every exit path
 
 }  // namespace
 
-void build_sk_table(device_replica& rep, host_index const& idx) {
+void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_shards, uint32_t table_shard_id) {
     dict_view& v = rep.view;
     v.sk.slots = nullptr;
     v.sk.occ = nullptr;
     v.sk.num_slots = 0;
     v.sk.enabled = 0;
+    v.sk.num_shards = table_shards;  // read by the scan kernel's filter
+    v.sk.shard_id = table_shard_id;
     const char* env = std::getenv("SSHASH_AMD_SKTABLE");
     if (env && env[0] == '0') return;
     if (idx.num_shards > 1 || idx.num_kmers == 0) return;  // a shard holds only its own minimizers' buckets: keep its path

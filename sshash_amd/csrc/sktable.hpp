@@ -10,6 +10,7 @@ struct device_replica;
 
 /* Leaves rep.view.sk disabled when the table does not apply (a minimizer shard, SSHASH_AMD_SKTABLE=0,
    not enough free HBM). Runs on the current device. */
-void build_sk_table(device_replica& rep, host_index const& idx);
+/* table_shards > 1: only the keys with sk_owner(key, table_shards) == table_shard_id get slots */
+void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_shards = 1, uint32_t table_shard_id = 0);
 
 }  // namespace sshash_amd

@@ -102,7 +102,7 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
             /* seed() */
             if constexpr (SK) {
                 const sk_key_t kk = sk_key<W>(x, x_rc, k, d.m);
-                if (!kk.tie) {
+                if (sk_usable(d, kk)) {
                     if (neg_unknown_mini && kk.key == prev_f) {
                         ++c_negative;
                         in_run = false;

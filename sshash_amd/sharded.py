@@ -21,6 +21,10 @@ Lookup of a local batch on rank r (all device-side except the split-size exchang
                once in the strings, so two owners that both find it return the same id).
 
 Results are identical to the unsharded dictionary: ids derive from string offsets, which are global.
+
+A second partitioning, by = "table": every rank keeps the complete reference structures and strings but only its
+share of the super-k-mer table (about three quarters of a replica's HBM); queries are routed by their table key,
+which is strand-symmetric, so a query has ONE owner and the exchange carries one message per query.
 torch is used for device memory and ``torch.distributed``; routing, bucketing, lookup and combine are HIP
 kernels behind the C ABI. With a ``gloo`` group (tests) the payloads are
 staged through host memory.
@@ -35,28 +39,50 @@ from ._binding import INVALID_U64, Dictionary
 
 
 class ShardedDictionary:
-    def __init__(self, shard: Dictionary, device: int, group=None):
+    """by = "minimizer": `shard` is rank r's minimizer shard of the index (built with num_shards/shard_id).
+    by = "table": `shard` is the COMPLETE dictionary; only the device's super-k-mer table -- the largest structure
+    in HBM -- is partitioned: rank r builds the slots of the keys it owns, and a query goes to the owner of its
+    (strand-symmetric) table key: one message per query instead of up to two."""
+
+    def __init__(self, shard: Dictionary, device: int, group=None, by: str = "minimizer"):
         import torch
         import torch.distributed as dist
 
+        if by not in ("minimizer", "table"):
+            raise ValueError("by must be 'minimizer' or 'table'")
         self.shard = shard
+        self.by = by
         self.device = int(device)
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        if shard.num_shards() != self.world or shard.shard_id() != self.rank:
-            raise ValueError(f"rank {self.rank}/{self.world} was given shard {shard.shard_id()}/{shard.num_shards()}")
         self._on_host = dist.get_backend(group) == "gloo"
         self._dev = torch.device("cuda", self.device)
-        shard.to_device(self.device)
+        if by == "table":
+            if shard.num_shards() != 1:
+                raise ValueError("table sharding partitions the device table of a complete dictionary")
+            shard.to_device(self.device, table_shards=self.world, table_shard_id=self.rank)
+        else:
+            if shard.num_shards() != self.world or shard.shard_id() != self.rank:
+                raise ValueError(f"rank {self.rank}/{self.world} was given shard {shard.shard_id()}/{shard.num_shards()}")
+            shard.to_device(self.device)
 
     @classmethod
-    def build(cls, input_filename: str, device: int, group=None, **build_kwargs) -> "ShardedDictionary":
+    def build(cls, input_filename: str, device: int, group=None, by: str = "minimizer", **build_kwargs) -> "ShardedDictionary":
         import torch.distributed as dist
 
+        if by == "table":
+            return cls(Dictionary.build(input_filename, **build_kwargs), device, group, by)
         shard = Dictionary.build(input_filename, num_shards=dist.get_world_size(group), shard_id=dist.get_rank(group),
                                  **build_kwargs)
         return cls(shard, device, group)
+
+    def _route(self, d_kmers, n, cursors, send, slots, check_rc, stream):
+        if self.by == "table":
+            self.shard.route_bucket_by_key_device(self.device, d_kmers, n, self.world, cursors, send, slots, stream=stream)
+        else:
+            self.shard.route_bucket_device(self.device, d_kmers, n, self.world, cursors, send, slots,
+                                           check_reverse_complement=check_rc, stream=stream)
 
     # -- collectives -----------------------------------------------------------------------------
     def _all_to_all(self, send, send_counts, recv_counts):
@@ -94,16 +120,14 @@ class ShardedDictionary:
         # 1. count the messages per owner, then scatter them into per-owner regions (HIP kernels behind the C ABI)
         counts = torch.zeros(self.world, dtype=torch.int64, device=self._dev)
         if n:
-            self.shard.route_bucket_device(self.device, d_kmers.data_ptr(), n, self.world, counts.data_ptr(),
-                                           check_reverse_complement=check_reverse_complement, stream=stream)
+            self._route(d_kmers.data_ptr(), n, counts.data_ptr(), 0, 0, check_reverse_complement, stream)
         send_counts = [int(c) for c in counts.tolist()]
         total = sum(send_counts)
         cursors = torch.cumsum(counts, 0) - counts                                  # first message of every region
         send = torch.empty((max(total, 1), W), dtype=torch.int64, device=self._dev)
         slots = torch.empty(max(total, 1), dtype=torch.int32, device=self._dev)     # which local query a message is about
         if n:
-            self.shard.route_bucket_device(self.device, d_kmers.data_ptr(), n, self.world, cursors.data_ptr(), send.data_ptr(),
-                                           slots.data_ptr(), check_reverse_complement=check_reverse_complement, stream=stream)
+            self._route(d_kmers.data_ptr(), n, cursors.data_ptr(), send.data_ptr(), slots.data_ptr(), check_reverse_complement, stream)
         # 2. exchange, 3. lookup what arrived, 4. return the ids
         recv_counts = self._exchange_counts(send_counts)
         received = self._all_to_all(send[:total], send_counts, recv_counts)           # (m, W) packed k-mers to look up here

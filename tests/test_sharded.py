@@ -63,11 +63,14 @@ WORKER = textwrap.dedent(
     from oracle import oracle as O
     from oracle.ground_truth import GroundTruth, read_fasta_sequences, _revcomp_u64
 
-    fasta, canonical = sys.argv[2], sys.argv[3] == "1"
+    fasta, canonical, by = sys.argv[2], sys.argv[3] == "1", sys.argv[4]
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
-    sd = ShardedDictionary.build(fasta, device=0, k=31, m=13, canonical=canonical, num_threads=4)
+    sd = ShardedDictionary.build(fasta, device=0, by=by, k=31, m=13, canonical=canonical, num_threads=4)
+    if by == "table":  # each rank holds its share of the table only, everything else in full
+        stats = sd.shard.device_stats(0)
+        assert 0 < stats["sk_keys"] < 0.6 * sshash_amd.Dictionary.build(fasta, k=31, m=13, canonical=canonical, num_threads=4).to_device(0).device_stats(0)["sk_keys"]
     # expected ids: the whole dictionary through the oracle
     whole = sshash_amd.Dictionary.build(fasta, k=31, m=13, canonical=canonical, num_threads=4)
     path = f"/tmp/sshash_sharded_test_{os.getpid()}.sshash"
@@ -98,15 +101,38 @@ WORKER = textwrap.dedent(
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("canonical", [False, True])
-def test_two_rank_sharded_lookup_on_gpu(canonical, tmp_path):
+@pytest.mark.parametrize("canonical,by", [(False, "minimizer"), (True, "minimizer"), (False, "table"), (True, "table")])
+def test_two_rank_sharded_lookup_on_gpu(canonical, by, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541" if canonical else "29540", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, SE_FASTA, "1" if canonical else "0"],
+    port = 29540 + int(canonical) + 2 * int(by == "table")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, SE_FASTA, "1" if canonical else "0", by],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
     assert "SHARDED OK 60000" in outs[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case_name", ["case_skew_regular", "case_k63_canonical"])
+def test_a_table_shard_answers_every_query_on_its_own(case_name, request):
+    """A replica whose super-k-mer table holds one third of the keys must still answer ANY query correctly: a key
+    of another shard takes the complete path (slower, never wrong)."""
+    case = request.getfixturevalue(case_name)
+    d = sshash_amd.Dictionary.load(case.index_path).to_device(0, table_shards=3, table_shard_id=1)
+    full = case.dict.to_device(0).device_stats()["sk_keys"]
+    mine = d.device_stats()["sk_keys"]
+    assert 0 < mine < full
+    n = case.gt.num_kmers
+    allq = case.gt.kmers(np.arange(n))
+    assert (d.lookup(allq).kmer_id == np.arange(n, dtype=np.uint64)).all()
+    q = case.queries(3000, 3000, seed=9)
+    want = case.oracle.lookup_ids(q)
+    assert (d.lookup(q).kmer_id == want).all()
+    assert (d.is_member(q) == (want != np.uint64(0xFFFFFFFFFFFFFFFF))).all()
+    reads = ["".join(case.sequences[i]) for i in range(0, len(case.sequences), 5)]
+    got, ref = d.streaming_query(reads), case.oracle.streaming_query(reads)
+    assert [getattr(got, f) for f in ref] == list(ref.values())

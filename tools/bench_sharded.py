@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--m", type=int, default=21)
     ap.add_argument("--canonical", action="store_true")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--by", choices=["minimizer", "table"], default="minimizer",
+                    help="minimizer: rank r holds its minimizer shard of the index; table: every rank holds the complete "
+                         "index and 1/N of the device's super-k-mer table, one message per query")
     args = ap.parse_args()
 
     import torch
@@ -51,9 +54,10 @@ def main():
     dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
     words, ends = make_spss(args.bases, k=args.k, m=args.m)
     t0 = time.time()
+    parts = (world, rank) if args.by == "minimizer" else (1, 0)
     shard = sshash_amd.Dictionary.build_from_packed(words, ends, k=args.k, m=args.m, canonical=args.canonical, num_threads=0,
-                                                    num_shards=world, shard_id=rank)
-    sd = ShardedDictionary(shard, local)
+                                                    num_shards=parts[0], shard_id=parts[1])
+    sd = ShardedDictionary(shard, local, by=args.by)
     build_s = time.time() - t0
     q = draw_queries(shard, args.queries, 0.5, seed=1234 + rank)
     dq = torch.from_numpy(q.view(np.int64)).to(dev)
@@ -85,7 +89,7 @@ def main():
         if not ok:
             raise SystemExit("PARITY FAILURE in sharded mode")
     if rank == 0:
-        print(json.dumps({"metric": "k-mer Lookups/sec, minimizer-sharded index with all-to-all routing", "n_gpus": world,
+        print(json.dumps({"metric": "k-mer Lookups/sec, %s-sharded index with all-to-all routing" % args.by, "n_gpus": world,
                           "value": round(args.queries * world * args.steps / float(elapsed), 1), "unit": "lookups/s",
                           "ms_per_step": round(float(elapsed) / args.steps * 1e3, 3), "queries_per_gpu": args.queries,
                           "num_kmers": shard.num_kmers(), "shard_minimizers": shard.num_minimizers(),
