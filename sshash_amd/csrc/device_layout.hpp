@@ -60,7 +60,7 @@
 //               over both strands (equal minima = tie, left to the structures above) -- one key for both
 //               strands, whatever the dictionary's own minimizer flavour. Built and probed with the same
 //               function, the table need not follow the reference's minimizer hash: it uses a 32-bit one;
-//        slot   32 bytes, 32-byte aligned; a key lives in one of five hashed slots (first free one
+//        slot   32 bytes, 32-byte aligned; a key lives in one of five slots -- a hashed one, its 64-byte-line sibling, three more hashed ones -- (first free one
 //               wins, 3 slots per key), SK_CHOICES = 5:
 //                 d0  bit0 valid | bit1 list | bit2 strand | bits 3-7 go-on flags, one per choice |
 //                     bits 8-13 left | bits 14-19 right
@@ -183,7 +183,8 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_slots) {
     b ^= b >> 31;
     sk_hash_t h;
     h.slot[0] = mulhi32(uint32_t(a >> 32), num_slots);
-    h.slot[1] = mulhi32(uint32_t(a), num_slots);
+    h.slot[1] = h.slot[0] ^ 1u;  // the other half of the first slot's 64-byte line (num_slots is even): the line is
+                                 // in L2 once the first choice has been read, so this probe costs no DRAM access
     h.slot[2] = mulhi32(uint32_t(b >> 32), num_slots);
     h.slot[3] = mulhi32(uint32_t(b), num_slots);
     const uint64_t c = (a + b) * 0xD6E8FEB86659FD93ULL;

@@ -279,7 +279,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
         const double want = std::atof(e);
         if (want >= 1.5 && want <= 16.0) slots_per_key = want;
     }
-    const uint64_t num_slots = uint64_t(double(K) * slots_per_key) + 16;
+    const uint64_t num_slots = (uint64_t(double(K) * slots_per_key) + 16) & ~uint64_t(1);  // even: slots pair up in 64-byte lines
     const uint64_t slot_bytes = wide ? 64 : 32;
     if (K == 0 || num_slots >= (uint64_t(1) << 32)) return;
     {
