@@ -61,7 +61,7 @@
 //               strands, whatever the dictionary's own minimizer flavour. Built and probed with the same
 //               function, the table need not follow the reference's minimizer hash: it uses a 32-bit one;
 //        slot   32 bytes, 32-byte aligned; a key lives in one of five slots -- a hashed one, its 64-byte-line sibling, three more hashed ones -- (first free one
-//               wins, 3 slots per key), SK_CHOICES = 5:
+//               wins, 4 slots per key), SK_CHOICES = 5:
 //                 d0  bit0 valid | bit1 list | bit2 strand | bits 3-7 go-on flags, one per choice |
 //                     bits 8-13 left | bits 14-19 right
 //                 d1  string id (inline) or number of occurrences (list; 0 = too long, defer)
@@ -150,7 +150,7 @@ constexpr uint32_t SK_CHOICES = 5;            // ... or, for the last choice, in
 constexpr uint32_t SK_LEFT_SHIFT = 8, SK_RIGHT_SHIFT = 14;
 static_assert((SK_GO_ON << (SK_CHOICES - 1)) < (1u << SK_LEFT_SHIFT), "go-on flags must stay below the extent fields");
 constexpr uint32_t SK_LIST_MAX = 64;          // longer occurrence lists are left to the complete path
-constexpr double SK_SLOTS_PER_KEY = 3.0;
+constexpr double SK_SLOTS_PER_KEY = 4.0;
 
 struct sk_view {
     void const* slots;    // num_slots x 32 bytes (k <= 31) or x 64 bytes (k <= 63)
