@@ -1,21 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- batched random k-mer Lookup throughput on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (sshash_lookup_packed_device: packed k-mers in HBM ->
-k-mer ids in HBM) over one batch of synthetic queries per GPU. Workload = BASELINE.json
-configs[1]: an index of the size statistics of the S. enterica pangenome (k=31, m=21; the real
-collection is not available offline, so a synthetic stand-in is generated -- sshash_amd/synthetic.py),
-100 M queries per batch, 50 % positive (half of those reverse-complemented), 50 % uniform random,
-shuffled, seeded.
+A "step" is one pass of the hot path (sshash_lookup_packed_device: packed k-mers in HBM -> k-mer ids in
+HBM) over ONE batch of synthetic queries, split over the GPUs. Default workload = BASELINE.json configs[2]
+(C3, the configuration the metric and the >= 1e9 lookups/s target are quoted on): a human-genome-scale k=31
+m=21 index (the real unitigs are not available offline, so a synthetic stand-in with the human build's size
+statistics is generated -- sshash_amd/synthetic.py; reference benchmarks/results-10-11-25/k31/regular-build.json:3)
+replicated in every GPU's HBM, and one batch of 10^9 random queries -- 50 % positive (half of those
+reverse-complemented), 50 % uniform random (tools/perf.hpp:38-74), seeded, drawn on the device -- sharded over
+the ranks ("scaling": "strong"). `--workload c2` selects configs[1] (S. enterica pangenome scale, 10^8 queries).
 
-    python bench.py [--gpus N --steps K --warmup W] [--bases B --queries Q] [--canonical]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2] [--bases B --queries Q] [--canonical]
 
-Multi-GPU: one process per GPU, the index replicated in each HBM, every rank looks up its own batch
-(weak scaling); no collective on the data path -- torch.distributed (RCCL) is used only for the
-barriers around the timed region and the max-over-ranks of the elapsed time.
+`--gpus N` with N > 1 starts the N ranks itself (python -m torch.distributed.run, rendezvous on 127.0.0.1);
+launched under torch.distributed.run it uses the ranks it is given. One process per GPU; no collective on the
+data path -- torch.distributed (RCCL) carries only the barriers around the timed region and the reductions of
+the elapsed times.
 
-Rank 0 prints ONE JSON line (fields: see the task contract; `roofline` and `cpu_baseline` added).
+Rank 0 prints ONE JSON line (fields: the task contract; `roofline`, `cpu_baseline`, `per_rank` added).
 """
 from __future__ import annotations
 
@@ -23,6 +25,8 @@ import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +36,14 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (bases, mean string length, queries in the batch, description)
+    "c3": (2_813_553_873, 274.0, 1_000_000_000,
+           "C3 stand-in: synthetic SPSS with the human-genome k=31 build's size statistics"),
+    "c2": (1_387_536_274, 85.0, 100_000_000,
+           "C2 stand-in: synthetic SPSS with S. enterica pangenome size statistics"),
+}
 
 
 def log(*a):
@@ -50,6 +62,27 @@ def effective_cores() -> int:
     return n
 
 
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def spawn_ranks(n: int, script: str, argv: list[str]) -> int:
+    """`python bench.py --gpus N ...` outside torch.distributed.run: start the N ranks on this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, effective_cores() // n)))
+    return subprocess.call(cmd, env=env)
+
+
+def split_batch(total: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous share [lo, hi) of a batch of `total` queries for `rank` (tests/test_multiproc_gloo.py)."""
+    return total * rank // world, total * (rank + 1) // world
+
+
 def get_index(args, rank: int, world: int, barrier):
     """Build the synthetic dictionary once (rank 0), cache it on local disk, load it on every rank."""
     import sshash_amd
@@ -65,6 +98,7 @@ def get_index(args, rank: int, world: int, barrier):
         t0 = time.time()
         d = sshash_amd.Dictionary.build_from_packed(words, endpoints, k=args.k, m=args.m, canonical=args.canonical,
                                                     num_threads=0, verbose=args.verbose)
+        del words
         log(f"dictionary built in {time.time() - t0:.1f}s: {d.num_kmers()} k-mers, {d.num_minimizers()} minimizers, "
             f"{d.num_bits() / 8e6:.0f} MB ({d.num_bits() / d.num_kmers():.2f} bits/k-mer)")
         tmp = path + f".tmp{os.getpid()}"
@@ -81,23 +115,55 @@ def get_index(args, rank: int, world: int, barrier):
     return d, path
 
 
+def traffic_record(d, n_local: int, args):
+    """HBM bytes per step from the PMC passes of THIS workload (profiles/traffic.json, written by
+    tools/jobs/*traffic*.sh from rocprofv3 --pmc runs of this very command); None when the tracked record is of
+    another workload. The provenance (file, commit, counters) is printed with the number."""
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(prof))
+    except Exception:
+        return None, None
+    same = (rec.get("queries") == n_local and rec.get("bases") == args.bases and rec.get("canonical") == args.canonical
+            and rec.get("k", 31) == args.k)
+    if not same:
+        return None, None
+    return rec.get("hbm_bytes_per_launch"), {"file": "profiles/traffic.json", "commit": rec.get("commit"),
+                                            "counters": rec.get("counters"), "note": rec.get("note")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--bases", type=int, default=1_387_536_274, help="bases in the synthetic SPSS (C2: S. enterica pangenome)")
-    ap.add_argument("--queries", type=int, default=100_000_000, help="queries per GPU per step")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--bases", type=int, default=None, help="bases in the synthetic SPSS (default: the workload's)")
+    ap.add_argument("--queries", type=int, default=None, help="queries in the batch, ALL GPUs together (default: the workload's)")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--m", type=int, default=21)
-    ap.add_argument("--mean-len", type=float, default=85.0, help="mean string length of the synthetic SPSS")
+    ap.add_argument("--mean-len", type=float, default=None, help="mean string length of the synthetic SPSS")
     ap.add_argument("--canonical", action="store_true")
+    ap.add_argument("--positive", type=float, default=0.5, help="fraction of positive queries in the batch")
+    ap.add_argument("--negatives", choices=["random", "mutated"], default="random",
+                    help="negative queries: uniform random k-mers (the reference's protocol) or indexed k-mers with one substitution")
     ap.add_argument("--seed", type=int, default=0x5555AAAA)
     ap.add_argument("--cache-dir", default=os.environ.get("SSHASH_BENCH_CACHE", "/tmp"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-mixes", action="store_true", help="skip the untimed-region side measurements (other query mixes)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="queries per CPU-baseline pass")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
+    bases, mean_len, queries, what = WORKLOADS[args.workload]
+    if args.bases is None:
+        args.bases = bases
+    if args.mean_len is None:
+        args.mean_len = mean_len
+    if args.queries is None:
+        args.queries = queries
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -106,7 +172,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the lookup path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -123,26 +189,29 @@ def main():
         if use_dist:
             dist.barrier()
 
-    from sshash_amd.synthetic import draw_queries
+    from sshash_amd.synthetic import draw_queries_device
 
     d, index_path = get_index(args, rank, world, barrier)
     t0 = time.time()
     d.to_device(local_rank)
+    stats = d.device_stats(local_rank)
     if rank == 0:
-        log(f"replica in HBM: {d.device_bytes(local_rank) / 1e6:.0f} MB (upload {time.time() - t0:.1f}s); {d.device_stats(local_rank)}")
+        log(f"replica in HBM: {d.device_bytes(local_rank) / 1e6:.0f} MB (upload {time.time() - t0:.1f}s); {stats}")
 
-    n = args.queries
+    # this rank's share of the batch
+    lo, hi = split_batch(args.queries, world, rank)
+    n = hi - lo
     W = d.words_per_kmer()
     t0 = time.time()
-    queries = draw_queries(d, n, 0.5, seed=args.seed + 7919 * rank)
+    dq = draw_queries_device(d, local_rank, n, args.positive, seed=args.seed + 7919 * rank, negatives=args.negatives)
+    torch.cuda.synchronize()
     if rank == 0:
-        log(f"{n} queries drawn in {time.time() - t0:.1f}s")
-    dq = torch.from_numpy(queries.view(np.int64)).to(dev)
+        log(f"{n} queries drawn on the device in {time.time() - t0:.1f}s")
     out = torch.empty(n, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()
 
-    def step():
-        d.lookup_device(local_rank, dq.data_ptr(), n, out.data_ptr(), check_reverse_complement=True, stream=stream.cuda_stream)
+    def step(q=dq, o=out, count=n):
+        d.lookup_device(local_rank, q.data_ptr(), count, o.data_ptr(), check_reverse_complement=True, stream=stream.cuda_stream)
 
     for _ in range(args.warmup):
         step()
@@ -157,15 +226,22 @@ def main():
         step()
         stops[i].record(stream)
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t_begin
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_begin
+    kernel_ms = [starts[i].elapsed_time(stops[i]) for i in range(args.steps)]
+    avg_kernel_ms = float(np.mean(kernel_ms))
+    per_rank = [{"rank": 0, "queries": n, "ms_per_step": round(own_elapsed / args.steps * 1e3, 3), "kernel_ms_per_step": round(avg_kernel_ms, 3)}]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = [starts[i].elapsed_time(stops[i]) for i in range(args.steps)]
-    avg_kernel_ms = float(np.mean(kernel_ms))
+        mine = torch.tensor([float(n), own_elapsed / args.steps * 1e3, avg_kernel_ms], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r, "queries": int(v[0].item()), "ms_per_step": round(float(v[1].item()), 3),
+                     "kernel_ms_per_step": round(float(v[2].item()), 3)} for r, v in enumerate(every)]
 
     # ---- parity spot check + algorithmic bytes (oracle = checker only) ---------------------------
     result = None
@@ -173,50 +249,78 @@ def main():
         from oracle import oracle as O
 
         ora = O.OracleIndex(index_path)
-        sample = 200_000
+        sample = min(200_000, n)
+        head = dq[: max(sample, min(n, args.cpu_sample * 64)) * W].cpu().numpy().view(np.uint64)
         got = out[:sample].cpu().numpy().view(np.uint64)
-        want = ora.lookup_ids(queries[: sample * W], num_threads=effective_cores())
+        want = ora.lookup_ids(head[: sample * W], num_threads=effective_cores())
         if not (got == want).all():
             raise SystemExit("PARITY FAILURE: GPU ids differ from the CPU oracle")
-        found = float((got != np.uint64(0xFFFFFFFFFFFFFFFF)).mean())
-        bytes_per_lookup = ora.count_bytes(queries[: 100_000 * W]) / 100_000
+        found = float((out != -1).float().mean().item())
+        bytes_per_lookup = ora.count_bytes(head[: min(sample, 100_000) * W]) / min(sample, 100_000)
         achieved = bytes_per_lookup * n / (avg_kernel_ms * 1e-3) / 1e9
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
-            try:
-                rec = json.load(open(prof))
-                if rec.get("queries") == n and rec.get("bases") == args.bases and rec.get("canonical") == args.canonical:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        pieces = -(-n // (1 << 27))  # launch pairs per step (engine.hip: at most 2^27 queries per pair, equal pieces)
+        traffic, provenance = traffic_record(d, n, args)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel": "fast_lookup_kernel<W=%d,canonical=%d,ids,%s> + deferred_lookup_kernel (one pair per step; "
-                              "avg_kernel_ms = HIP-event time around the pair)"
-                              % (W, int(d.canonical()), "super-k-mer table" if d.device_stats(local_rank)["sk_slots"] else "directory"),
-                    "algorithmic_bytes_per_lookup": round(bytes_per_lookup, 2), "avg_kernel_ms": round(avg_kernel_ms, 3)}
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_provenance": provenance,
+                    "kernel": "fast_lookup_kernel<W=%d,canonical=%d,ids,%s> + deferred_lookup_kernel (%d launch pair(s) of "
+                              "equal size per step; avg_kernel_ms = HIP-event time around one step, on the launch stream)"
+                              % (W, int(d.canonical()), "super-k-mer table" if stats["sk_slots"] else "directory", pieces),
+                    "launches_per_step": pieces,
+                    "algorithmic_bytes_per_lookup": round(bytes_per_lookup, 2),
+                    "algorithmic_bytes_rule": "SURVEY 8(d): 8 B per distinct 64-bit index word the REFERENCE algorithm dereferences "
+                                              "+ query in + id out, counted by the instrumented oracle on this batch",
+                    "avg_kernel_ms": round(avg_kernel_ms, 3)}
+        own = d.read_counts_device(local_rank, dq.data_ptr(), min(n, 10_000_000)) if hasattr(d, "read_counts_device") else None
+        if own:
+            own_bytes = own["bytes_per_lookup"]
+            roofline["own_useful_bytes_per_lookup"] = round(own_bytes, 2)
+            roofline["frac_own_useful_bytes"] = round(own_bytes * n / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            roofline["own_reads_per_lookup"] = own["reads_per_lookup"]
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cores = effective_cores()
             m = min(args.cpu_sample, n)
-            q1 = queries[: m * W]
             t0 = time.perf_counter()
-            ora.lookup_ids(q1, num_threads=1)
+            ora.lookup_ids(head[: m * W], num_threads=1)
             t1 = time.perf_counter() - t0
             reps = max(1, min(64, int(20.0 / max(1e-3, t1 / cores * 4))))
-            big = min(n, m * reps)
-            qa = queries[: big * W]
+            big = min(head.size // W, m * reps)
             t0 = time.perf_counter()
-            ids_all = ora.lookup_ids(qa, num_threads=cores)
+            ids_all = ora.lookup_ids(head[: big * W], num_threads=cores)
             ta = time.perf_counter() - t0
-            assert (ids_all[: min(big, n)] == out[:big].cpu().numpy().view(np.uint64)).all()
+            assert (ids_all == out[:big].cpu().numpy().view(np.uint64)).all()
             cpu = {"value": round(big / ta, 1), "unit": "lookups/s", "cores": cores, "kind": "port",
                    "sample": f"{big} queries of the same batch on {cores} threads (= usable CPUs: affinity {os.cpu_count()}, "
                              f"cgroup quota applied; contiguous chunks); "
                              f"1 thread: {m / t1:.0f} lookups/s = {t1 / m * 1e9:.0f} ns/lookup over {m} queries",
-                   "single_thread_value": round(m / t1, 1)}
-        total = n * world * args.steps
+                   "single_thread_value": round(m / t1, 1),
+                   "published_reference_ns_per_lookup": "738-768 ns (real S. enterica index, one 5.4 GHz core; BASELINE.md)"}
+        extra = None
+        if world == 1 and not args.no_extra_mixes:
+            # side measurements OUTSIDE the timed region: other query mixes on 10^8-query batches, ids of a sample checked
+            extra = {}
+            m = min(n, 100_000_000)
+            for name, pf, neg in (("positive100", 1.0, "random"), ("negative100_random", 0.0, "random"),
+                                  ("mix50_mutated_negatives", 0.5, "mutated")):
+                q2 = draw_queries_device(d, local_rank, m, pf, seed=args.seed + 101, negatives=neg)
+                o2 = out[:m]
+                step(q2, o2, m)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(3):
+                    step(q2, o2, m)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 3
+                s2 = min(m, 50_000)
+                w2 = ora.lookup_ids(q2[: s2 * W].cpu().numpy().view(np.uint64), num_threads=effective_cores())
+                if not (o2[:s2].cpu().numpy().view(np.uint64) == w2).all():
+                    raise SystemExit(f"PARITY FAILURE in side measurement {name}")
+                extra[name] = {"lookups_per_s": round(m / ms * 1e3, 1), "ms": round(ms, 3), "queries": m,
+                               "fraction_found": round(float((o2 != -1).float().mean().item()), 4)}
+                del q2
+        total = args.queries * args.steps
         result = {
             "metric": "k-mer Lookups/sec (batched random queries, bit-exact ids)",
             "value": round(total / elapsed, 1),
@@ -226,19 +330,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "C2 stand-in: synthetic SPSS with S. enterica pangenome size statistics, "
-                                   f"k={d.k()} m={d.m()} {'canonical' if d.canonical() else 'regular'}, "
-                                   f"{d.num_kmers()} k-mers / {d.num_strings()} strings / {d.num_bases()} bases, "
-                                   f"{n} packed queries per GPU per step (50% positive, half of them reverse-complemented)",
-                       "queries_per_gpu": n, "num_kmers": d.num_kmers(), "k": d.k(), "m": d.m(),
+            "config": {"workload": f"{what}, k={d.k()} m={d.m()} {'canonical' if d.canonical() else 'regular'}, "
+                                   f"{d.num_kmers()} k-mers / {d.num_strings()} strings / {d.num_bases()} bases, index replicated in "
+                                   f"every GPU's HBM; ONE batch of {args.queries} packed queries per step "
+                                   f"({args.positive:.0%} positive, half of them reverse-complemented; negatives: {args.negatives}) "
+                                   f"split over {world} GPU(s)",
+                       "queries_per_step": args.queries, "queries_per_gpu": n, "num_kmers": d.num_kmers(), "k": d.k(), "m": d.m(),
                        "canonical": d.canonical(), "index_replicated_per_gpu": True,
-                       "positive_fraction_found": round(found, 4), "device_index_bytes": d.device_bytes(local_rank)},
+                       "positive_fraction_found": round(found, 4), "device_index_bytes": d.device_bytes(local_rank),
+                       "device_bytes_per_kmer": round(d.device_bytes(local_rank) / d.num_kmers(), 2),
+                       "device_stats": stats},
+            "per_rank": per_rank,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "other_mixes": extra,
         }
     barrier()
     if use_dist:

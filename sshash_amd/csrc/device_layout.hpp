@@ -52,7 +52,7 @@
 //      MPHF lands on. Built on the GPU at upload; SSHASH_AMD_DIRECTORY=0 disables it.
 //
 //  (5) a *super-k-mer table*, built on the GPU at upload from the strings alone (described for k <= 31;
-//      for k <= 63 the slot is 64 bytes -- the same 16-byte head, then 128 bases -- and 48 of them are read). Structures
+//      for k <= 63 a slot is 64 bytes -- the same 16-byte head, then 128 bases -- and a bucket two 64-byte lines). Structures
 //      (1)-(4) answer a positive lookup with two dependent random reads per probe (minimizer ->
 //      position, then the strings) and a regular index probes both strands (src/dictionary.cpp:70-75);
 //      what bounds the batch is the number of such reads. The table answers most lookups with ONE:
@@ -60,25 +60,33 @@
 //               over both strands (equal minima = tie, left to the structures above) -- one key for both
 //               strands, whatever the dictionary's own minimizer flavour. Built and probed with the same
 //               function, the table need not follow the reference's minimizer hash: it uses a 32-bit one;
-//        slot   32 bytes, 32-byte aligned; a key lives in one of five slots -- a hashed one, its 64-byte-line sibling, three more hashed ones -- (first free one
-//               wins, 4 slots per key), SK_CHOICES = 5:
-//                 d0  bit0 valid | bit1 list | bit2 strand | bits 3-7 go-on flags, one per choice |
-//                     bits 8-13 left | bits 14-19 right
+//        bucket one 64-byte line = the unit the memory system fetches (TCC_EA0_RDREQ is always a 64-byte request,
+//               profiles/r02/tlb_probe_counters.txt) = TWO 32-byte slots. A key lives in one of SK_CHOICES = 4
+//               hashed buckets, in the first of them that had a free slot when it was placed; two slots per key
+//               (load factor 0.5). The four lanes of a quad fetch the line of one of them together -- 16 bytes each,
+//               ONE load instruction, straight into LDS (global_load_lds_dwordx4) -- so that the memory pipeline sees
+//               one request and ONE address translation per lookup: with one lane issuing the 16-byte loads of its
+//               own slot every load is a separate UTCL1 miss once the table outgrows the ~2 GiB the per-CU
+//               translation cache covers, and the translation-request rate (75 G/s chip-wide), not DRAM, is what
+//               capped round 1's table at 38 G reads/s;
+//        slot   32 bytes:
+//                 d0  bit0 valid | bit1 list | bit2 strand | bits 3-6 go-on flags of the BUCKET, one per choice
+//                     (kept in slot 0 only) | bits 8-13 left | bits 14-19 right
 //                 d1  string id (inline) or number of occurrences (list; 0 = too long, defer)
 //                 d2,d3  position of the key occurrence / list begin (40 bits) | fingerprint of the key << 40
 //                 d4-d7  inline: the 64 bases starting k-m bases before the occurrence, i.e. every k-mer
 //                        of the super-k-mer; list of <= 2: the occurrences themselves
 //               A key with exactly one occurrence in the strings (~90 % of the k-mers) is *inline*: the
 //               slot holds the super-k-mer, how far it may extend inside its string (left/right), and the
-//               string id, so the lookup ends at the slot. Other keys carry a list of occurrences
+//               string id, so the lookup ends at the bucket. Other keys carry a list of occurrences
 //               ((position << 1) | strand, in `occ`), scanned through the atoms of (1).
-//        flags  go-on flag c of a slot says "a key whose c-th choice is this slot lives further along its
+//        flags  go-on flag c of a bucket says "a key whose c-th choice is this bucket lives further along its
 //               sequence"; a probe that finds neither its k-mer nor that flag is a final miss -- negative
-//               queries end after ~1.1 reads. The last choice's flag (a key that found no slot at all),
+//               queries end after ~1.1 line reads. The last choice's flag (a key that found no slot at all),
 //               over-long lists and ties send the query to the complete path through (3)/(4).
 //      Ids are positions in the strings, so results are identical to the reference's; the table only
 //      changes how many reads it takes to find the position. SSHASH_AMD_SKTABLE=0 disables it.
-//      The table is by far the largest structure (~16 bytes per k-mer at k = 31); with several GPUs it can be
+//      The table is the largest structure (~11 bytes per k-mer at k = 31, m = 21); with several GPUs it can be
 //      partitioned by key (sk_owner): each replica then builds the slots of its own keys only, queries are
 //      routed to the owner of their key (one message per query, sharded.py), and a replica that meets a key
 //      it does not own simply takes the complete path -- every replica stays correct on its own.
@@ -145,17 +153,19 @@ SSH_HD uint64_t directory_entry(uint64_t code, uint32_t fp) { return code | (uin
 
 /* ---- super-k-mer table (5) ---- */
 constexpr uint32_t SK_VALID = 1u, SK_LIST = 2u, SK_STRAND = 4u;
-constexpr uint32_t SK_GO_ON = 8u;             // << c: a key whose choice c is this slot lives at a later choice ...
-constexpr uint32_t SK_CHOICES = 5;            // ... or, for the last choice, in no slot at all (flags: bits 3-7)
+constexpr uint32_t SK_GO_ON = 8u;             // << c: a key whose choice c is this bucket lives at a later choice ...
+constexpr uint32_t SK_CHOICES = 4;            // ... or, for the last choice, in no slot at all (flags: bits 3-6 of slot 0)
+constexpr uint32_t SK_BUCKET_SLOTS = 2;       // slots per bucket: one 64-byte line at k <= 31
 constexpr uint32_t SK_LEFT_SHIFT = 8, SK_RIGHT_SHIFT = 14;
 static_assert((SK_GO_ON << (SK_CHOICES - 1)) < (1u << SK_LEFT_SHIFT), "go-on flags must stay below the extent fields");
+static_assert(SK_CHOICES == 4, "sk_hash and sk_choice spell out four choices");
 constexpr uint32_t SK_LIST_MAX = 64;          // longer occurrence lists are left to the complete path
-constexpr double SK_SLOTS_PER_KEY = 4.0;
+constexpr double SK_SLOTS_PER_KEY = 2.0;
 
 struct sk_view {
-    void const* slots;    // num_slots x 32 bytes (k <= 31) or x 64 bytes (k <= 63)
+    void const* slots;    // num_buckets x 2 slots of 32 bytes (k <= 31) or of 64 bytes (k <= 63)
     uint64_t const* occ;  // occurrences of the list keys: (position << 1) | strand
-    uint32_t num_slots;
+    uint32_t num_buckets;
     uint32_t enabled;
     /* table shard (multi-GPU, sharded.py): this replica's table holds only the keys with
        sk_owner(key, num_shards) == shard_id; lookups of other keys take the complete path */
@@ -170,11 +180,11 @@ SSH_HD uint32_t sk_owner(uint64_t key, uint32_t num_shards) {
 }
 
 struct sk_hash_t {
-    uint32_t slot[SK_CHOICES];
+    uint32_t bucket[SK_CHOICES];
     uint32_t fingerprint;  // 24 bits
 };
 
-SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_slots) {
+SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_buckets) {
     uint64_t a = key * 0xFF51AFD7ED558CCDULL;
     a ^= a >> 32;
     a *= 0xC4CEB9FE1A85EC53ULL;
@@ -182,13 +192,11 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_slots) {
     uint64_t b = (a ^ key) * 0x9E3779B97F4A7C15ULL;
     b ^= b >> 31;
     sk_hash_t h;
-    h.slot[0] = mulhi32(uint32_t(a >> 32), num_slots);
-    h.slot[1] = h.slot[0] ^ 1u;  // the other half of the first slot's 64-byte line (num_slots is even): the line is
-                                 // in L2 once the first choice has been read, so this probe costs no DRAM access
-    h.slot[2] = mulhi32(uint32_t(b >> 32), num_slots);
-    h.slot[3] = mulhi32(uint32_t(b), num_slots);
+    h.bucket[0] = mulhi32(uint32_t(a >> 32), num_buckets);
+    h.bucket[1] = mulhi32(uint32_t(b >> 32), num_buckets);
+    h.bucket[2] = mulhi32(uint32_t(b), num_buckets);
     const uint64_t c = (a + b) * 0xD6E8FEB86659FD93ULL;
-    h.slot[4] = mulhi32(uint32_t(c), num_slots);
+    h.bucket[3] = mulhi32(uint32_t(c), num_buckets);
     h.fingerprint = uint32_t(c >> 40);
     return h;
 }

@@ -169,7 +169,7 @@ void engine::device_stats(int device, uint64_t out[8]) const {
     out[1] = r->view.directory.enabled ? r->view.directory.num_buckets : 0;
     out[2] = r->directory_overflowed;
     out[3] = r->directory_entries;
-    out[4] = r->view.sk.enabled ? r->view.sk.num_slots : 0;
+    out[4] = r->view.sk.enabled ? uint64_t(r->view.sk.num_buckets) * SK_BUCKET_SLOTS : 0;
     out[5] = r->sk_keys;
     out[6] = r->sk_inline_keys;
     out[7] = r->sk_long_lists + r->sk_unplaced;
@@ -353,19 +353,25 @@ __device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries
 
 /* Phase 1 of the two-phase lookup (lookup_device.hpp): one query per lane, common case only. Queries it
    cannot settle are appended to `queue` (their index in the batch). SK: through the super-k-mer table
-   (device_layout.hpp (5)) instead of directory + atoms. */
+   (device_layout.hpp (5)) instead of directory + atoms; the four lanes of a quad fetch each other's buckets
+   together, through LDS (sk_probe_wave), so no lane leaves before the probe. */
 template <int W, bool CANON, int MODE, bool ASCII, bool SK>
 __global__ void __launch_bounds__(256)
 fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const uint64_t n, const bool check_rc,
                    const result_view out, uint8_t* __restrict__ member, uint32_t* __restrict__ queue,
                    uint32_t* __restrict__ queue_counts, const uint32_t shard_capacity) {
+    /* LDS: the ASCII tile (256 * k characters) and, afterwards, the staged bucket lines (64 * W bytes per lane) */
+    constexpr uint32_t TILE_WORDS = ASCII ? 64 * (W == 1 ? 31 : 63) + 8 : 0;
+    constexpr uint32_t STAGE_WORDS = SK ? 256 * 16 * W : 0;
+    __shared__ uint4 lds[(TILE_WORDS > STAGE_WORDS ? TILE_WORDS : STAGE_WORDS) / 4 + 1];
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    kmer_w<W> x;
+    const bool active = i < n;
+    kmer_w<W> x = kmer_zero<W>();
     if constexpr (ASCII) {
         /* util::string_to_uint_kmer (include/util.hpp:207-213) for a whole workgroup: the 256*k
            characters of this workgroup's queries are one contiguous run of the input; it is staged in
            LDS with 16-byte loads and every lane then packs its own k characters, four at a time */
-        __shared__ uint32_t tile[64 * (W == 1 ? 31 : 63) + 8];
+        uint32_t* tile = reinterpret_cast<uint32_t*>(lds);
         const uint64_t first = uint64_t(blockIdx.x) * blockDim.x;
         const uint32_t count = uint32_t(n - first < blockDim.x ? n - first : blockDim.x);
         const uint32_t bytes = count * d.k;
@@ -382,25 +388,31 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
             for (uint32_t b = threadIdx.x; b < bytes; b += blockDim.x) reinterpret_cast<char*>(tile)[b] = src[b];
         }
         __syncthreads();
-        if (i >= n) return;
-        x = kmer_zero<W>();
-        const uint32_t start = threadIdx.x * d.k, w0 = start >> 2, sh = start & 3;
-        for (uint32_t j = 0; 4 * j < d.k; ++j) {
-            const uint32_t four = __builtin_amdgcn_alignbyte(tile[w0 + j + 1], tile[w0 + j], sh);
-            uint32_t c = (four >> 1) & 0x03030303u;  // (c >> 1) & 3 for four characters at once
-            c = (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xFFu;
-            const uint32_t rem = d.k - 4 * j;
-            if (rem < 4) c &= (1u << (2 * rem)) - 1;
-            if (8 * j < 64) x.w[0] |= uint64_t(c) << (8 * j);
-            else if constexpr (W == 2) x.w[1] |= uint64_t(c) << (8 * j - 64);
+        if (active) {
+            const uint32_t start = threadIdx.x * d.k, w0 = start >> 2, sh = start & 3;
+            for (uint32_t j = 0; 4 * j < d.k; ++j) {
+                const uint32_t four = __builtin_amdgcn_alignbyte(tile[w0 + j + 1], tile[w0 + j], sh);
+                uint32_t c = (four >> 1) & 0x03030303u;  // (c >> 1) & 3 for four characters at once
+                c = (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xFFu;
+                const uint32_t rem = d.k - 4 * j;
+                if (rem < 4) c &= (1u << (2 * rem)) - 1;
+                if (8 * j < 64) x.w[0] |= uint64_t(c) << (8 * j);
+                else if constexpr (W == 2) x.w[1] |= uint64_t(c) << (8 * j - 64);
+            }
         }
+        if constexpr (SK) __syncthreads();  // the tile's LDS is reused for the bucket lines
     } else {
-        if (i >= n) return;
-        x = load_query<W, false>(queries, i, d.k);
+        if (active) x = load_query<W, false>(queries, i, d.k);
     }
     fast_t r;
-    if constexpr (SK) r = sk_lookup_one<W>(d, x, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1));
-    else r = fast_lookup_one<W, CANON>(d, x, check_rc);
+    if constexpr (SK) {
+        r = sk_lookup_wave<W>(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1),
+                              lds + (threadIdx.x >> 6) * (64 * 4 * W));
+        if (!active) return;
+    } else {
+        if (!active) return;
+        r = fast_lookup_one<W, CANON>(d, x, check_rc);
+    }
     /* every lane stores first (a deferred lane's value is a placeholder that phase 2 overwrites), the
        queue push comes last: no lane leaves the wave between the probe and its store */
     if constexpr (MODE == int(out_mode::member)) {
@@ -470,7 +482,8 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
         if ((d.directory.enabled || d.sk.enabled) && !(MODE == int(out_mode::full) && out.minimizer_found)) {
             /* two-phase: at most 2^27 queries per launch pair (queue indices are 32-bit; the scratch
                queue stays at 0.5 GiB) */
-            const uint64_t piece = uint64_t(1) << 27;
+            const uint64_t pieces = (n + (uint64_t(1) << 27) - 1) >> 27;
+            const uint64_t piece = ((n + pieces - 1) / pieces + block - 1) / block * block;  // equal pieces, whole workgroups
             const size_t qbytes = size_t(W) * 8, kbytes = d.k;
             for (uint64_t at = 0; at < n; at += piece) {
                 const uint64_t m = std::min(piece, n - at);

@@ -427,7 +427,7 @@ __device__ __forceinline__ fast_t fast_lookup_one(dict_view const& d, kmer_w<W> 
 }
 
 /* ---- lookup through the super-k-mer table (device_layout.hpp (5)) -------------------------------
-   sk_probe: follow the key's slot sequence. HIT / final MISS / DEFER to the complete path. `key_seen`:
+   A probe follows the key's bucket sequence: HIT / final MISS / DEFER to the complete path. `key_seen`:
    some slot on the way carried the key's fingerprint; a MISS without it proves that no k-mer with this
    key is in the dictionary (the streaming query's negative short-cut uses that). */
 /* may this replica's table settle a k-mer with key `kk`? (not on a tie; not a key owned by another table shard) */
@@ -435,30 +435,70 @@ __device__ __forceinline__ bool sk_usable(dict_view const& d, sk_key_t const& kk
     return !kk.tie && (d.sk.num_shards <= 1 || sk_owner(kk.key, d.sk.num_shards) == d.sk.shard_id);
 }
 
+/* what a probe compares the slots of a bucket with */
 template <int W>
-__device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
-                                           bool& key_seen) {
-    const bool s = kk.rc;       // the key was read on the reverse complement of x
-    const uint32_t j = kk.pos;  // where the key starts in y
-    const kmer_w<W> y = s ? x_rc : x, y_rc = s ? x : x_rc;
+struct sk_query_t {
+    kmer_w<W> y, y_rc;     // the k-mer as read on the key's strand, and its reverse complement
+    uint32_t j;            // where the key starts in y
+    uint32_t fingerprint;  // of the key
+    bool s;                // the key was read on the reverse complement of x
+};
+
+template <int W>
+__device__ __forceinline__ sk_query_t<W> sk_make_query(kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
+                                                        uint32_t fingerprint) {
+    sk_query_t<W> q;
+    q.s = kk.rc;
+    q.j = kk.pos;
+    q.y = kk.rc ? x_rc : x;
+    q.y_rc = kk.rc ? x : x_rc;
+    q.fingerprint = fingerprint;
+    return q;
+}
+
+template <int W>
+__device__ __forceinline__ kmer_w<W> kmer_pick(bool first, kmer_w<W> const& a, kmer_w<W> const& b) {
+    kmer_w<W> out;
+    for (int t = 0; t < W; ++t) out.w[t] = first ? a.w[t] : b.w[t];
+    return out;
+}
+
+/* c-th bucket of a key; c is uniform over the wave wherever this is called, so these are scalar selects */
+__device__ __forceinline__ uint32_t sk_choice(sk_hash_t const& h, uint32_t c) {
+    return c == 0 ? h.bucket[0] : c == 1 ? h.bucket[1] : c == 2 ? h.bucket[2] : h.bucket[3];
+}
+
+/* One bucket (choice c of the key) against one query. `piece(slot, i)` yields the i-th 16-byte piece of a slot of
+   the bucket -- out of LDS, where the quad staged the line, or out of global memory. `go_on`: the bucket's flag for
+   choice c. */
+template <int W, class Piece>
+__device__ __forceinline__ void sk_examine_bucket(dict_view const& d, sk_query_t<W> const Q, uint32_t c, Piece piece, fast_t& r,
+                                                  bool& key_seen, uint32_t& go_on) {
     const uint32_t km = d.k - d.m;
-    const sk_hash_t h = sk_hash(kk.key, d.sk.num_slots);
-    fast_t r = fast_unsettled(false);
-    key_seen = false;
+    const uint32_t j = Q.j;
+    /* values, not references into Q: a select between two members of a by-reference struct is compiled into an
+       indexed load, which pins the struct in scratch memory */
+    kmer_w<W> y, y_rc;
+    for (int t = 0; t < W; ++t) {
+        y.w[t] = Q.y.w[t];
+        y_rc.w[t] = Q.y_rc.w[t];
+    }
+    go_on = 0;
 #pragma unroll 1
-    for (uint32_t c = 0; c < SK_CHOICES; ++c) {
-        const uint4* S = reinterpret_cast<const uint4*>(d.sk.slots) + (2 * W) * uint64_t(h.slot[c]);
-        const uint4 q0 = S[0], q1 = S[1];
+    for (uint32_t slot = 0; slot < SK_BUCKET_SLOTS; ++slot) {
+        const uint4 q0 = piece(slot, 0), q1 = piece(slot, 1);
         uint4 q2 = q1;
-        if constexpr (W == 2) q2 = S[2];
+        if constexpr (W == 2) q2 = piece(slot, 2);
         const uint32_t meta = q0.x;
-        /* decided now, in its own register: hipcc 7.2 has been seen recycling a slot word that is only
-           consumed after the list scan */
-        uint32_t go_on = meta & (SK_GO_ON << c);
-        asm volatile("" : "+v"(go_on));
+        if (slot == 0) {
+            /* decided now, in its own register: hipcc 7.2 has been seen recycling a slot word that is only
+               consumed after the list scan */
+            go_on = meta & (SK_GO_ON << c);
+            asm volatile("" : "+v"(go_on));
+        }
         if (meta & SK_VALID) {
             const uint64_t at = uint64_t(q0.z) | (uint64_t(q0.w & 0xFFu) << 32);
-            const bool same_fingerprint = (q0.w >> 8) == h.fingerprint;
+            const bool same_fingerprint = (q0.w >> 8) == Q.fingerprint;
             key_seen = key_seen || same_fingerprint;
             if (!(meta & SK_LIST)) {
                 /* inline super-k-mer: the strings read the key forward (strand 0: y aligns, key at km - a)
@@ -480,51 +520,144 @@ __device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& 
                 }
                 cand = kmer_take_chars<W>(cand, d.k);
                 const uint32_t left = (meta >> SK_LEFT_SHIFT) & 63u, right = (meta >> SK_RIGHT_SHIFT) & 63u;
-                if (kmer_eq<W>(cand, o ? y_rc : y) && a + left >= km && a <= right) {
+                if (kmer_eq<W>(cand, kmer_pick<W>(o, y_rc, y)) && a + left >= km && a <= right) {
                     r.kmer_offset = at + a - km;
                     r.string_id = q0.y;
-                    r.orientation = (o != s) ? -1 : 1;
+                    r.orientation = (o != Q.s) ? -1 : 1;
                     r.outcome = FAST_HIT;
                 }
             } else if (same_fingerprint) {
                 const uint32_t size = q0.y;
                 if (size == 0) r.outcome = FAST_DEFER;  // list longer than SK_LIST_MAX
+                /* the two inline occurrences; selected by arithmetic (a ternary on t turns the slot into a scratch array) */
+                const uint64_t in0 = uint64_t(q1.x) | (uint64_t(q1.y) << 32), in1 = uint64_t(q1.z) | (uint64_t(q1.w) << 32);
                 for (uint32_t t = 0; t < size; ++t) {
-                    uint64_t v;
-                    if (size <= 2) v = t == 0 ? (uint64_t(q1.x) | (uint64_t(q1.y) << 32)) : (uint64_t(q1.z) | (uint64_t(q1.w) << 32));
-                    else v = d.sk.occ[at + t];
+                    uint64_t v = in0 ^ ((in0 ^ in1) & (uint64_t(0) - uint64_t(t & 1u)));
+                    if (size > 2) v = d.sk.occ[at + t];
                     const bool o = (v & 1) != 0;
                     const uint64_t p = v >> 1;
                     const uint32_t a = o ? j : km - j;
                     if (p + a < km) continue;
                     const window_t<W> w = read_window<W>(d.granules, p + a - km, d.k);
-                    if (kmer_eq<W>(w.kmer, o ? y_rc : y) && !w.crosses) {
+                    if (kmer_eq<W>(w.kmer, kmer_pick<W>(o, y_rc, y)) && !w.crosses) {
                         r.kmer_offset = p + a - km;
                         r.string_id = w.string_id;
-                        r.orientation = (o != s) ? -1 : 1;
+                        r.orientation = (o != Q.s) ? -1 : 1;
                         r.outcome = FAST_HIT;
                         break;
                     }
                 }
             }
         }
+        if (r.outcome != FAST_MISS) break;  // settled: the other slot need not be looked at
+    }
+}
+
+/* One lane on its own, every piece read from global memory: the streaming query, whose lanes are at different
+   points of their reads when they need a seed. */
+template <int W>
+__device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
+                                           bool& key_seen) {
+    const sk_hash_t h = sk_hash(kk.key, d.sk.num_buckets);
+    const sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, h.fingerprint);
+    fast_t r = fast_unsettled(false);
+    key_seen = false;
+#pragma unroll 1
+    for (uint32_t c = 0; c < SK_CHOICES; ++c) {
+        const uint4* B = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(sk_choice(h, c));
+        uint32_t go_on;
+        sk_examine_bucket<W>(d, Q, c, [B](uint32_t slot, uint32_t i) { return B[slot * (2 * W) + i]; }, r, key_seen, go_on);
         if (r.outcome != FAST_MISS || go_on == 0) break;  // settled, or nobody who hashed here lives elsewhere
         if (c + 1 == SK_CHOICES) r.outcome = FAST_DEFER;  // a key that found no slot: complete path
     }
     return r;
 }
 
-/* Same contract as fast_lookup_one. `allow_rc` false (regular dictionary, check_reverse_complement off:
-   src/dictionary.cpp:70-71) turns a hit on the other strand into a miss. `miss_orientation`: what a miss
-   reports (-1 after a regular dictionary's reverse-complement probe, src/dictionary.cpp:74-75). */
+/* ---- the same probe by a whole wave: quad-cooperative line fetch into LDS ------------------------------------
+   Must be called by all 64 lanes of the wave together (lanes without a query pass want = false). Round p of a
+   bucket fetch: the four lanes of every quad read the four 16-byte pieces of ONE 64-byte line -- the bucket of the
+   quad's lane p & 3 -- with one global_load_lds_dwordx4, which deposits lane L's piece at region p + 16 L of the
+   wave's staging area: quad q's line lands contiguously at region p + 64 q, so the transposition from "lane = piece"
+   to "lane = owner of the whole line" costs no instruction and no register. 4 W rounds fetch the buckets of all 64
+   lanes. The memory pipeline sees one request (and one address translation) per line instead of one per 16-byte load
+   (device_layout.hpp (5)). */
+typedef __attribute__((address_space(3))) void* sk_lds_ptr;
+typedef const __attribute__((address_space(1))) void* sk_global_ptr;
+
+template <int OWNER>
+__device__ __forceinline__ uint32_t quad_broadcast(uint32_t v) {
+    return uint32_t(__builtin_amdgcn_mov_dpp(int(v), OWNER * 0x55, 0xf, 0xf, true));
+}
+
+template <int W, int P>
+__device__ __forceinline__ void sk_stage_round(char const* __restrict__ slots, uint32_t bucket, uint32_t need, uint32_t sub,
+                                               uint4* wave_stage) {
+    constexpr int OWNER = P & 3, LINE = P >> 2;
+    const uint32_t ob = quad_broadcast<OWNER>(bucket);
+    const uint32_t on = quad_broadcast<OWNER>(need);
+    if (on)
+        __builtin_amdgcn_global_load_lds((sk_global_ptr)(slots + uint64_t(ob) * (64 * W) + 64 * LINE + 16 * sub),
+                                         (sk_lds_ptr)(wave_stage + P * 64), 16, 0, 0);
+}
+
 template <int W>
-__device__ __forceinline__ fast_t sk_lookup_one(dict_view const& d, kmer_w<W> const& x, bool allow_rc, int8_t miss_orientation) {
+__device__ __forceinline__ fast_t sk_probe_wave(dict_view const& d, sk_query_t<W> const& Q, sk_hash_t const& h, bool want,
+                                                uint4* wave_stage /* 64 * 4 * W uint4 of LDS, this wave's own */,
+                                                bool& key_seen) {
+    fast_t r = fast_unsettled(false);
+    key_seen = false;
+    bool need = want;
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & 3u;
+    char const* slots = static_cast<char const*>(d.sk.slots);
+    const uint4* mine = wave_stage + sub * 64 + (lane >> 2) * 4;  // region (lane & 3), line of quad (lane >> 2)
+#pragma unroll 1
+    for (uint32_t c = 0; c < SK_CHOICES; ++c) {
+        if (__ballot(need) == 0) break;  // wave-uniform
+        const uint32_t bucket = need ? sk_choice(h, c) : 0u;
+        const uint32_t n32 = need ? 1u : 0u;
+        sk_stage_round<W, 0>(slots, bucket, n32, sub, wave_stage);
+        sk_stage_round<W, 1>(slots, bucket, n32, sub, wave_stage);
+        sk_stage_round<W, 2>(slots, bucket, n32, sub, wave_stage);
+        sk_stage_round<W, 3>(slots, bucket, n32, sub, wave_stage);
+        if constexpr (W == 2) {
+            sk_stage_round<W, 4>(slots, bucket, n32, sub, wave_stage);
+            sk_stage_round<W, 5>(slots, bucket, n32, sub, wave_stage);
+            sk_stage_round<W, 6>(slots, bucket, n32, sub, wave_stage);
+            sk_stage_round<W, 7>(slots, bucket, n32, sub, wave_stage);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (need) {
+            uint32_t go_on;
+            /* W = 1: the line holds both slots (pieces 0-1, 2-3); W = 2: slot 1 is the second line, four regions on */
+            sk_examine_bucket<W>(d, Q, c, [mine](uint32_t slot, uint32_t i) { return W == 1 ? mine[2 * slot + i] : mine[slot * 256 + i]; },
+                                 r, key_seen, go_on);
+            need = r.outcome == FAST_MISS && go_on != 0;
+            if (need && c + 1 == SK_CHOICES) {
+                r.outcome = FAST_DEFER;  // a key that found no slot: complete path
+                need = false;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return r;
+}
+
+/* Same contract as fast_lookup_one, for a whole wave (lanes beyond the batch pass active = false and get a
+   placeholder). `allow_rc` false (regular dictionary, check_reverse_complement off: src/dictionary.cpp:70-71) turns a
+   hit on the other strand into a miss. `miss_orientation`: what a miss reports (-1 after a regular dictionary's
+   reverse-complement probe, src/dictionary.cpp:74-75). */
+template <int W>
+__device__ __forceinline__ fast_t sk_lookup_wave(dict_view const& d, kmer_w<W> const& x, bool active, bool allow_rc,
+                                                 int8_t miss_orientation, uint4* wave_stage) {
     const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
     const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
-    if (!sk_usable(d, kk)) return fast_unsettled(true);  // no strand-symmetric key, or a key of another table shard
+    const bool usable = active && sk_usable(d, kk);  // else: no strand-symmetric key, or a key of another table shard
+    const sk_hash_t h = sk_hash(kk.key, d.sk.num_buckets);
+    const sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, h.fingerprint);
     bool key_seen;
-    fast_t r = sk_probe<W>(d, x, x_rc, kk, key_seen);
-    if (r.outcome == FAST_MISS || (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc)) {
+    fast_t r = sk_probe_wave<W>(d, Q, h, usable, wave_stage, key_seen);
+    if (!usable) r = fast_unsettled(active);
+    else if (r.outcome == FAST_MISS || (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc)) {
         r = fast_unsettled(false);
         r.orientation = miss_orientation;
     }

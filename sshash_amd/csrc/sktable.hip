@@ -8,8 +8,9 @@
 //               whose occurrence differs from its left neighbour's starts a super-k-mer and emits one
 //               tuple. Two passes (count, exclusive scan, emit) keep the tuples in string order.
 //   2. sort     stable radix sort of the tuples by key (hipCUB), run-length encode -> one run per key.
-//   3. place    SK_CHOICES rounds, one per hashed slot choice: a key claims its slot with a CAS on the slot's
-//               flag word; a key that loses sets the slot's "go on" flag and waits for the next round.
+//   3. place    SK_CHOICES rounds, one per hashed bucket choice: a key claims the first free slot of the bucket with a
+//               CAS on the slot's flag word; a key that finds the bucket full sets the bucket's "go on" flag and waits
+//               for the next round.
 //   4. fill     the winner writes its slot: the 64 bases around a single occurrence, how far the
 //               super-k-mer may extend inside its string, the string id -- or the occurrence list.
 #include <hip/hip_runtime.h>
@@ -103,27 +104,32 @@ template <int W>
 __global__ void __launch_bounds__(256)
 sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_keys, const uint64_t* __restrict__ keys,
                 const uint32_t* __restrict__ run_sizes, const uint32_t* __restrict__ run_begins, const uint64_t* __restrict__ occ,
-                uint32_t* __restrict__ slots, const uint32_t num_slots, uint8_t* __restrict__ placed,
+                uint32_t* __restrict__ slots, const uint32_t num_buckets, uint8_t* __restrict__ placed,
                 unsigned long long* __restrict__ stats) {
     const uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     bool is_inline = false, too_long = false, unplaced = false;
     if (r < num_keys && !placed[r]) {
         const uint64_t key = keys[r];
-        const sk_hash_t h = sk_hash(key, num_slots);
-        uint32_t* S = slots + (8 * W) * uint64_t(h.slot[choice]);
-        /* claim: set the valid bit unless somebody holds it (other lanes may be OR-ing flags into the same word) */
-        uint32_t cur = __hip_atomic_load(S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const sk_hash_t h = sk_hash(key, num_buckets);
+        uint32_t* B = slots + (SK_BUCKET_SLOTS * 8 * W) * uint64_t(h.bucket[choice]);  // slot 0 of the bucket: carries the flags
+        /* claim the first free slot of the bucket: set its valid bit unless somebody holds it (other lanes may be
+           OR-ing flags into slot 0's word) */
+        uint32_t* S = B;
         bool mine = false;
-        while (!(cur & SK_VALID)) {
-            const uint32_t seen = atomicCAS(S, cur, cur | SK_VALID);
-            if (seen == cur) {
-                mine = true;
-                break;
+        for (uint32_t slot = 0; slot < SK_BUCKET_SLOTS && !mine; ++slot) {
+            S = B + slot * (8 * W);
+            uint32_t cur = __hip_atomic_load(S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (!(cur & SK_VALID)) {
+                const uint32_t seen = atomicCAS(S, cur, cur | SK_VALID);
+                if (seen == cur) {
+                    mine = true;
+                    break;
+                }
+                cur = seen;
             }
-            cur = seen;
         }
         if (!mine) {
-            atomicOr(S, SK_GO_ON << choice);
+            atomicOr(B, SK_GO_ON << choice);
             unplaced = choice + 1 == SK_CHOICES;
         } else {
             placed[r] = 1;
@@ -202,7 +208,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     dict_view& v = rep.view;
     v.sk.slots = nullptr;
     v.sk.occ = nullptr;
-    v.sk.num_slots = 0;
+    v.sk.num_buckets = 0;
     v.sk.enabled = 0;
     v.sk.num_shards = table_shards;  // read by the scan kernel's filter
     v.sk.shard_id = table_shard_id;
@@ -277,11 +283,12 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     double slots_per_key = SK_SLOTS_PER_KEY;
     if (const char* e = std::getenv("SSHASH_AMD_SK_SLOTS_PER_KEY")) {  // measurement knob
         const double want = std::atof(e);
-        if (want >= 1.5 && want <= 16.0) slots_per_key = want;
+        if (want >= 1.2 && want <= 16.0) slots_per_key = want;
     }
-    const uint64_t num_slots = (uint64_t(double(K) * slots_per_key) + 16) & ~uint64_t(1);  // even: slots pair up in 64-byte lines
+    const uint64_t num_buckets = uint64_t(double(K) * slots_per_key / SK_BUCKET_SLOTS) + 8;
+    const uint64_t num_slots = num_buckets * SK_BUCKET_SLOTS;
     const uint64_t slot_bytes = wide ? 64 : 32;
-    if (K == 0 || num_slots >= (uint64_t(1) << 32)) return;
+    if (K == 0 || num_buckets >= (uint64_t(1) << 32)) return;
     {
         size_t free_bytes = 0, total_bytes = 0;
         HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
@@ -304,10 +311,10 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     for (uint32_t choice = 0; choice < SK_CHOICES; ++choice) {
         if (wide)
             hipLaunchKernelGGL(sk_place_kernel<2>, dim3(uint32_t((K + 255) / 256)), block, 0, 0, v, choice, K, keys, run_sizes,
-                               run_begins, occ, slots, uint32_t(num_slots), placed, stats);
+                               run_begins, occ, slots, uint32_t(num_buckets), placed, stats);
         else
             hipLaunchKernelGGL(sk_place_kernel<1>, dim3(uint32_t((K + 255) / 256)), block, 0, 0, v, choice, K, keys, run_sizes,
-                               run_begins, occ, slots, uint32_t(num_slots), placed, stats);
+                               run_begins, occ, slots, uint32_t(num_buckets), placed, stats);
         HIP_CHECK(hipGetLastError());
     }
     unsigned long long h_stats[4];
@@ -325,7 +332,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     rep.sk_unplaced = h_stats[2];
     v.sk.slots = slots;
     v.sk.occ = occ;
-    v.sk.num_slots = uint32_t(num_slots);
+    v.sk.num_buckets = uint32_t(num_buckets);
     v.sk.enabled = 1;
 }
 

@@ -179,3 +179,96 @@ def draw_queries(d, n: int, positive_fraction: float = 0.5, seed: int = 0x5555AA
     allq = np.concatenate([pos, neg])
     allq = allq[rng.permutation(n)]  # (a row shuffle of an (n,1) array is an order of magnitude slower)
     return np.ascontiguousarray(allq).reshape(-1)
+
+
+# ---- the same query mix, drawn on the GPU (10^9-query batches: BASELINE.json configs[2]) ---------------------
+
+def _s64(v: int) -> int:
+    """Python int (unsigned 64-bit pattern) -> the int64 value with the same bits."""
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _shr(x, s: int):
+    """Logical right shift of an int64 tensor (torch's >> is arithmetic)."""
+    return (x >> s) & ((1 << (64 - s)) - 1) if s else x
+
+
+def _reverse_pairs64(x):
+    """Reverse the order of the 32 two-bit groups of every int64 (torch has no byteswap)."""
+    x = ((x & 0x3333333333333333) << 2) | (_shr(x, 2) & 0x3333333333333333)
+    x = ((x & 0x0F0F0F0F0F0F0F0F) << 4) | (_shr(x, 4) & 0x0F0F0F0F0F0F0F0F)
+    x = ((x & 0x00FF00FF00FF00FF) << 8) | (_shr(x, 8) & 0x00FF00FF00FF00FF)
+    x = ((x & 0x0000FFFF0000FFFF) << 16) | (_shr(x, 16) & 0x0000FFFF0000FFFF)
+    return (x << 32) | _shr(x, 32)
+
+
+def revcomp_device(q, k: int):
+    """Reverse complement of packed k-mers held in an int64 torch tensor of shape (n, W)
+    (reference include/kmer.hpp:159-165: complement = x ^ 0xAAAA..., reverse the 2-bit groups, shift down)."""
+    comp = _s64(0xAAAAAAAAAAAAAAAA)
+    if q.shape[1] == 1:
+        return _shr(_reverse_pairs64(q[:, 0] ^ comp), 64 - 2 * k).unsqueeze(1)
+    import torch
+
+    r_hi, r_lo = _reverse_pairs64(q[:, 0] ^ comp), _reverse_pairs64(q[:, 1] ^ comp)  # the words swap (kmer.hpp:162)
+    s = 128 - 2 * k  # 2 <= s <= 62 for 33 <= k <= 63
+    return torch.stack([_shr(r_lo, s) | (r_hi << (64 - s)), _shr(r_hi, s)], dim=1)
+
+
+def draw_queries_device(d, device: int, n: int, positive_fraction: float = 0.5, seed: int = 0x5555AAAA,
+                        negatives: str = "random", chunk: int = 1 << 26):
+    """draw_queries() on the GPU: -> int64 torch tensor of n*W packed words on cuda:`device`.
+
+    positives = access(random id) on the device (sshash_access_packed_device), every other one (a fair coin)
+    reverse-complemented; negatives = "random": uniformly random k-mers (tools/perf.hpp:67-74), or "mutated": a
+    random indexed k-mer with ONE base substituted -- absent (unless the substitution lands on an indexed sibling)
+    but sharing its minimizers with the index, the way reads of a related genome do. Positions are mixed by an
+    independent coin per query, so no shuffle is needed. Deterministic for (seed, n, chunk)."""
+    import torch
+
+    dev = torch.device("cuda", device)
+    W, k, nk = d.words_per_kmer(), d.k(), d.num_kmers()
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+    out = torch.empty((n, W), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def indexed(m):
+        ids = torch.randint(0, nk, (m,), generator=g, device=dev, dtype=torch.int64)
+        x = torch.empty((m, W), dtype=torch.int64, device=dev)
+        d.access_packed_device(device, ids.data_ptr(), m, x.data_ptr(), stream=stream)
+        return x
+
+    def rand64(m):
+        hi = torch.randint(0, 1 << 32, (m,), generator=g, device=dev, dtype=torch.int64)
+        lo = torch.randint(0, 1 << 32, (m,), generator=g, device=dev, dtype=torch.int64)
+        return (hi << 32) | lo
+
+    for at in range(0, n, chunk):
+        m = min(chunk, n - at)
+        pos = indexed(m)
+        flip = torch.rand(m, generator=g, device=dev) < 0.5
+        pos = torch.where(flip.unsqueeze(1), revcomp_device(pos, k), pos)
+        if negatives == "random":
+            neg = torch.stack([rand64(m) for _ in range(W)], dim=1)
+            if W == 1:
+                neg[:, 0] &= (1 << (2 * k)) - 1
+            else:
+                neg[:, 1] &= (1 << (2 * k - 64)) - 1
+        elif negatives == "mutated":
+            neg = indexed(m)
+            p = torch.randint(0, k, (m,), generator=g, device=dev, dtype=torch.int64)
+            delta = torch.randint(1, 4, (m,), generator=g, device=dev, dtype=torch.int64)
+            if W == 1:
+                neg[:, 0] ^= delta << (2 * p)
+            else:
+                low = p < 32
+                neg[:, 0] ^= torch.where(low, delta << (2 * (p & 31)), torch.zeros_like(delta))
+                neg[:, 1] ^= torch.where(low, torch.zeros_like(delta), delta << (2 * (p & 31)))
+            flip = torch.rand(m, generator=g, device=dev) < 0.5
+            neg = torch.where(flip.unsqueeze(1), revcomp_device(neg, k), neg)
+        else:
+            raise ValueError("negatives must be 'random' or 'mutated'")
+        is_pos = torch.rand(m, generator=g, device=dev) < positive_fraction
+        out[at:at + m] = torch.where(is_pos.unsqueeze(1), pos, neg)
+    return out.reshape(-1)

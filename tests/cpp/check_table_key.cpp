@@ -51,11 +51,11 @@ int main() {
         checked += trials;
         fprintf(stderr, "k=%u m=%u: %llu ties in %llu k-mers\n", c[0], c[1], (unsigned long long)(ties - before), (unsigned long long)trials);
     }
-    /* slot hashing: three independent-looking choices inside the table */
+    /* bucket hashing: every choice inside the table */
     for (uint64_t key = 1; key < 100000; key += 7) {
         const sk_hash_t h = sk_hash(key * 0x9E3779B97F4A7C15ULL >> 22, 1000003u);
         for (uint32_t c = 0; c < SK_CHOICES; ++c)
-            if (h.slot[c] >= 1000003u) return printf("slot out of range\n"), 1;
+            if (h.bucket[c] >= 1000003u) return printf("bucket out of range\n"), 1;
         if (h.fingerprint >> 24) return printf("fingerprint wider than 24 bits\n"), 1;
     }
     printf("OK %llu %llu\n", (unsigned long long)checked, (unsigned long long)ties);
