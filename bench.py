@@ -254,7 +254,9 @@ def main():
         got = out[:sample].cpu().numpy().view(np.uint64)
         want = ora.lookup_ids(head[: sample * W], num_threads=effective_cores())
         if not (got == want).all():
-            raise SystemExit("PARITY FAILURE: GPU ids differ from the CPU oracle")
+            bad = np.nonzero(got != want)[0]
+            raise SystemExit(f"PARITY FAILURE: GPU ids differ from the CPU oracle for {bad.size} of {sample} sampled queries; first: "
+                             + ", ".join(f"#{int(i)} kmer={int(head[i * W]):#x} got={int(got[i])} want={int(want[i])}" for i in bad[:6]))
         found = float((out != -1).float().mean().item())
         bytes_per_lookup = ora.count_bytes(head[: min(sample, 100_000) * W]) / min(sample, 100_000)
         achieved = bytes_per_lookup * n / (avg_kernel_ms * 1e-3) / 1e9

@@ -64,26 +64,31 @@
 //               profiles/r02/tlb_probe_counters.txt) = TWO 32-byte slots. A key lives in one of SK_CHOICES = 4
 //               hashed buckets, in the first of them that had a free slot when it was placed; two slots per key
 //               (load factor 0.5). The four lanes of a quad fetch the line of one of them together -- 16 bytes each,
-//               ONE load instruction, straight into LDS (global_load_lds_dwordx4) -- so that the memory pipeline sees
+//               ONE load instruction, transposed through LDS (lookup_device.hpp) -- so that the memory pipeline sees
 //               one request and ONE address translation per lookup: with one lane issuing the 16-byte loads of its
 //               own slot every load is a separate UTCL1 miss once the table outgrows the ~2 GiB the per-CU
 //               translation cache covers, and the translation-request rate (75 G/s chip-wide), not DRAM, is what
 //               capped round 1's table at 38 G reads/s;
 //        slot   32 bytes:
-//                 d0  bit0 valid | bit1 list | bit2 strand | bits 3-6 go-on flags of the BUCKET, one per choice
+//                 d0  bit0 valid | bit1 marker | bit2 strand | bits 3-6 go-on flags of the BUCKET, one per choice
 //                     (kept in slot 0 only) | bits 8-13 left | bits 14-19 right
-//                 d1  string id (inline) or number of occurrences (list; 0 = too long, defer)
-//                 d2,d3  position of the key occurrence / list begin (40 bits) | fingerprint of the key << 40
-//                 d4-d7  inline: the 64 bases starting k-m bases before the occurrence, i.e. every k-mer
-//                        of the super-k-mer; list of <= 2: the occurrences themselves
-//               A key with exactly one occurrence in the strings (~90 % of the k-mers) is *inline*: the
-//               slot holds the super-k-mer, how far it may extend inside its string (left/right), and the
-//               string id, so the lookup ends at the bucket. Other keys carry a list of occurrences
-//               ((position << 1) | strand, in `occ`), scanned through the atoms of (1).
+//                 d1  string id (marker: number of occurrences of the key)
+//                 d2,d3  position of the key occurrence (40 bits) | fingerprint of the key << 40
+//                 d4-d7  the 64 bases starting k-m bases before the occurrence, i.e. every k-mer of the super-k-mer
+//               An *inline* slot holds one occurrence of its key: the super-k-mer around it, how far it may extend
+//               inside its string (left/right), and the string id, so a lookup that finds its k-mer there ends
+//               there. A key with up to SK_INLINE_MAX = 4 occurrences in the strings (one for ~96 % of the keys)
+//               holds one inline slot per occurrence, spread along its bucket sequence (two per bucket). A key with
+//               more (a *heavy* key: repeats, low-complexity sequence) holds ONE *marker* slot, and every k-mer of
+//               every one of its super-k-mers is entered a second time under a key of its own -- a hash of the
+//               canonical k-mer (sk_kmer_key) -- as a copy of its super-k-mer's inline slot: a probe that meets its
+//               key's marker switches to the k-mer's own bucket sequence and finds the k-mer after one more read,
+//               however many thousand occurrences the key has (what the reference's skew index does for its heavy
+//               buckets, include/sparse_and_skew_index.hpp:34-44, with the table's own machinery).
 //        flags  go-on flag c of a bucket says "a key whose c-th choice is this bucket lives further along its
 //               sequence"; a probe that finds neither its k-mer nor that flag is a final miss -- negative
-//               queries end after ~1.1 line reads. The last choice's flag (a key that found no slot at all),
-//               over-long lists and ties send the query to the complete path through (3)/(4).
+//               queries end after ~1.1 line reads. The last choice's flag (a key or k-mer that found no slot at all)
+//               and ties send the query to the complete path through (3)/(4).
 //      Ids are positions in the strings, so results are identical to the reference's; the table only
 //      changes how many reads it takes to find the position. SSHASH_AMD_SKTABLE=0 disables it.
 //      The table is the largest structure (~11 bytes per k-mer at k = 31, m = 21); with several GPUs it can be
@@ -152,19 +157,19 @@ SSH_HD uint32_t directory_fingerprint(uint64_t h) { return uint32_t(h) & 0xFFFFu
 SSH_HD uint64_t directory_entry(uint64_t code, uint32_t fp) { return code | (uint64_t(fp) << 40) | (uint64_t(1) << 56); }
 
 /* ---- super-k-mer table (5) ---- */
-constexpr uint32_t SK_VALID = 1u, SK_LIST = 2u, SK_STRAND = 4u;
+constexpr uint32_t SK_VALID = 1u, SK_MARKER = 2u, SK_STRAND = 4u;
 constexpr uint32_t SK_GO_ON = 8u;             // << c: a key whose choice c is this bucket lives at a later choice ...
 constexpr uint32_t SK_CHOICES = 4;            // ... or, for the last choice, in no slot at all (flags: bits 3-6 of slot 0)
 constexpr uint32_t SK_BUCKET_SLOTS = 2;       // slots per bucket: one 64-byte line at k <= 31
 constexpr uint32_t SK_LEFT_SHIFT = 8, SK_RIGHT_SHIFT = 14;
 static_assert((SK_GO_ON << (SK_CHOICES - 1)) < (1u << SK_LEFT_SHIFT), "go-on flags must stay below the extent fields");
 static_assert(SK_CHOICES == 4, "sk_hash and sk_choice spell out four choices");
-constexpr uint32_t SK_LIST_MAX = 64;          // longer occurrence lists are left to the complete path
+constexpr uint32_t SK_INLINE_MAX = 4;         // a key with up to this many occurrences holds one inline slot per occurrence;
+                                              // a heavier key holds a marker and its k-mers are keyed one by one
 constexpr double SK_SLOTS_PER_KEY = 2.0;
 
 struct sk_view {
     void const* slots;    // num_buckets x 2 slots of 32 bytes (k <= 31) or of 64 bytes (k <= 63)
-    uint64_t const* occ;  // occurrences of the list keys: (position << 1) | strand
     uint32_t num_buckets;
     uint32_t enabled;
     /* table shard (multi-GPU, sharded.py): this replica's table holds only the keys with
@@ -199,6 +204,16 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_buckets) {
     h.bucket[3] = mulhi32(uint32_t(c), num_buckets);
     h.fingerprint = uint32_t(c >> 40);
     return h;
+}
+
+/* Key under which the k-mers of a heavy key are entered one by one: a hash of the canonical k-mer, so that both
+   strands agree. (sk_hash mixes it further; equal keys of different k-mers only cost a comparison.) */
+template <int W>
+SSH_HD uint64_t sk_kmer_key(kmer_w<W> const& x, kmer_w<W> const& x_rc) {
+    kmer_w<W> const& c = kmer_less<W>(x_rc, x) ? x_rc : x;
+    uint64_t v = c.w[0];
+    if constexpr (W == 2) v ^= (c.w[1] + 0x9E3779B97F4A7C15ULL) * 0xD6E8FEB86659FD93ULL;
+    return (v ^ (v >> 29)) * 0xBF58476D1CE4E5B9ULL + 0x632BE59BD9B4E019ULL;
 }
 
 /* Key of a k-mer (k <= 31) for the super-k-mer table: an m-mer occurrence chosen so that a k-mer and its

@@ -171,8 +171,8 @@ void engine::device_stats(int device, uint64_t out[8]) const {
     out[3] = r->directory_entries;
     out[4] = r->view.sk.enabled ? uint64_t(r->view.sk.num_buckets) * SK_BUCKET_SLOTS : 0;
     out[5] = r->sk_keys;
-    out[6] = r->sk_inline_keys;
-    out[7] = r->sk_long_lists + r->sk_unplaced;
+    out[6] = r->sk_keys - r->sk_heavy_keys;
+    out[7] = r->sk_unplaced;
 }
 
 device_replica const* engine::replica(int device) const {
@@ -338,6 +338,20 @@ lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const v
 constexpr uint32_t DEFER_SHARDS = 2048;  // power of two
 constexpr uint32_t DEFER_BLOCKS_PER_SHARD = 4;
 
+/* The per-stream scratch of one launch sequence: two queues sharded over DEFER_SHARDS counters.
+     resume  queries the first table pass hands to the second (index | choice, and the packed k-mer); half a
+             piece's worth of places -- a query that finds it full goes to `defer` instead;
+     defer   queries for the complete path (index only); a whole piece's worth: a query is pushed at most once. */
+struct pass_queues {
+    uint32_t* defer_counts;
+    uint32_t* resume_counts;
+    uint32_t* defer_index;
+    uint32_t* resume_index;
+    uint64_t* resume_kmers;
+    uint32_t defer_capacity;   // places per shard
+    uint32_t resume_capacity;
+};
+
 template <int W, bool ASCII>
 __device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries, uint64_t i, uint32_t k) {
     kmer_w<W> x;
@@ -358,8 +372,7 @@ __device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries
 template <int W, bool CANON, int MODE, bool ASCII, bool SK>
 __global__ void __launch_bounds__(256)
 fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const uint64_t n, const bool check_rc,
-                   const result_view out, uint8_t* __restrict__ member, uint32_t* __restrict__ queue,
-                   uint32_t* __restrict__ queue_counts, const uint32_t shard_capacity) {
+                   const result_view out, uint8_t* __restrict__ member, const pass_queues q) {
     /* LDS: the ASCII tile (256 * k characters) and, afterwards, the staged bucket lines (64 * W bytes per lane) */
     constexpr uint32_t TILE_WORDS = ASCII ? 64 * (W == 1 ? 31 : 63) + 8 : 0;
     constexpr uint32_t STAGE_WORDS = SK ? 256 * 16 * W : 0;
@@ -405,16 +418,31 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
         if (active) x = load_query<W, false>(queries, i, d.k);
     }
     fast_t r;
+    const uint32_t shard = blockIdx.x & (DEFER_SHARDS - 1);  // the queues are sharded by workgroup: one hot counter would
+                                                             // serialise at ~90 atomics/us
     if constexpr (SK) {
-        r = sk_lookup_wave<W>(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1),
-                              lds + (threadIdx.x >> 6) * (64 * 4 * W));
+        r = sk_first_pass_wave<W>(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1),
+                                  lds + (threadIdx.x >> 6) * (64 * 4 * W));
+        /* whatever needs a second dependent read joins the compacted second pass, with its packed k-mer (no lane leaves
+           before this: the queue places are handed out per wave) */
+        bool resume = active && r.outcome == FAST_CONTINUE;
+        const uint32_t place = wave_queue_place(resume, q.resume_counts + shard);
+        if (resume) {
+            if (place < q.resume_capacity) {
+                const uint64_t at = uint64_t(shard) * q.resume_capacity + place;
+                q.resume_index[at] = uint32_t(i) | uint32_t(r.kmer_offset);
+                for (int j = 0; j < W; ++j) q.resume_kmers[at * W + j] = x.w[j];
+            } else {
+                r.outcome = FAST_DEFER;  // queue full (more than half of the batch resumes): the complete path takes it
+            }
+        }
         if (!active) return;
     } else {
         if (!active) return;
         r = fast_lookup_one<W, CANON>(d, x, check_rc);
     }
-    /* every lane stores first (a deferred lane's value is a placeholder that phase 2 overwrites), the
-       queue push comes last: no lane leaves the wave between the probe and its store */
+    /* every remaining lane stores first (a deferred or resumed lane's value is a placeholder that a later pass
+       overwrites), the deferred-queue push comes last */
     if constexpr (MODE == int(out_mode::member)) {
         member[i] = r.outcome == FAST_HIT ? 1 : 0;
     } else {
@@ -426,10 +454,46 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
         h.minimizer_found = true;  // never stored on this path (see launch())
         store_result<MODE == int(out_mode::full)>(d, out, i, h);
     }
-    if (r.outcome == FAST_DEFER) {
-        /* the queue is sharded by workgroup: one hot counter would serialise at ~90 atomics/us */
-        const uint32_t shard = blockIdx.x & (DEFER_SHARDS - 1);
-        queue[uint64_t(shard) * shard_capacity + atomicAdd(queue_counts + shard, 1u)] = uint32_t(i);
+    if (r.outcome == FAST_DEFER) q.defer_index[uint64_t(shard) * q.defer_capacity + atomicAdd(q.defer_counts + shard, 1u)] = uint32_t(i);
+}
+
+/* Second pass of the table lookup: the queries the first pass could not settle with one bucket read (their key's
+   first bucket was full when the key was placed, or the key has an occurrence list), compacted, so that these
+   dependent reads are issued by full waves instead of by the few lanes of every first-pass wave that need them.
+   RESUME_PARTS workgroups walk one shard of the queue. */
+constexpr uint32_t RESUME_PARTS = 4;
+
+template <int W, bool CANON, int MODE>
+__global__ void __launch_bounds__(256)
+resume_lookup_kernel(const dict_view d, const bool check_rc, const result_view out, uint8_t* __restrict__ member, const pass_queues q) {
+    __shared__ uint4 lds[256 * 4 * W];
+    const uint32_t shard = blockIdx.x & (DEFER_SHARDS - 1), part = blockIdx.x / DEFER_SHARDS;
+    const uint32_t pushed = q.resume_counts[shard];
+    const uint32_t total = pushed < q.resume_capacity ? pushed : q.resume_capacity;
+    for (uint32_t base = part * blockDim.x; base < total; base += RESUME_PARTS * blockDim.x) {  // uniform over the workgroup
+        const uint32_t j = base + threadIdx.x;
+        const bool active = j < total;
+        const uint64_t at = uint64_t(shard) * q.resume_capacity + (active ? j : 0u);
+        const uint32_t entry = q.resume_index[at];
+        const uint64_t i = entry & ((1u << RESUME_CHOICE_SHIFT) - 1);
+        kmer_w<W> x;
+        for (int t = 0; t < W; ++t) x.w[t] = q.resume_kmers[at * W + t];
+        const fast_t r = sk_second_pass_wave<W>(d, x, active, entry, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1),
+                                                lds + (threadIdx.x >> 6) * (64 * 4 * W));
+        if (!active) continue;
+        if (r.outcome == FAST_DEFER) {
+            q.defer_index[uint64_t(shard) * q.defer_capacity + atomicAdd(q.defer_counts + shard, 1u)] = uint32_t(i);
+        } else if constexpr (MODE == int(out_mode::member)) {
+            member[i] = r.outcome == FAST_HIT ? 1 : 0;
+        } else {
+            hit_t h;
+            h.kmer_offset = r.kmer_offset;
+            h.string_id = r.string_id;
+            h.orientation = r.orientation;
+            h.found = r.outcome == FAST_HIT;
+            h.minimizer_found = true;
+            store_result<MODE == int(out_mode::full)>(d, out, i, h);
+        }
     }
 }
 
@@ -437,14 +501,12 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
 template <int W, bool CANON, int MODE, bool ASCII>
 __global__ void __launch_bounds__(256)
 deferred_lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const void* __restrict__ queries,
-                       const bool check_rc, const result_view out, uint8_t* __restrict__ member,
-                       const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queue_counts,
-                       const uint32_t shard_capacity) {
+                       const bool check_rc, const result_view out, uint8_t* __restrict__ member, const pass_queues q) {
     /* DEFER_BLOCKS_PER_SHARD workgroups share a shard: the deferred queries are the ones with the longest
        dependent chains, so they get as many lanes as there are entries rather than a few busy ones */
     const uint32_t shard = blockIdx.x & (DEFER_SHARDS - 1), part = blockIdx.x / DEFER_SHARDS;
-    const uint32_t total = queue_counts[shard];
-    const uint32_t* mine = queue + uint64_t(shard) * shard_capacity;
+    const uint32_t total = q.defer_counts[shard];
+    const uint32_t* mine = q.defer_index + uint64_t(shard) * q.defer_capacity;
     for (uint32_t j = part * blockDim.x + threadIdx.x; j < total; j += DEFER_BLOCKS_PER_SHARD * blockDim.x) {
         const uint64_t i = mine[j];
         const kmer_w<W> x = load_query<W, ASCII>(queries, i, d.k);
@@ -480,30 +542,41 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
        on, so only the MPHF path can reproduce it (device_layout.hpp (4)). */
     {
         if ((d.directory.enabled || d.sk.enabled) && !(MODE == int(out_mode::full) && out.minimizer_found)) {
-            /* two-phase: at most 2^27 queries per launch pair (queue indices are 32-bit; the scratch
-               queue stays at 0.5 GiB) */
+            /* multi-pass: at most 2^27 queries per launch sequence (queue entries are 32-bit; the scratch
+               queues stay below 1.3 GiB (2.1 for 128-bit k-mers)) */
             const uint64_t pieces = (n + (uint64_t(1) << 27) - 1) >> 27;
             const uint64_t piece = ((n + pieces - 1) / pieces + block - 1) / block * block;  // equal pieces, whole workgroups
             const size_t qbytes = size_t(W) * 8, kbytes = d.k;
             for (uint64_t at = 0; at < n; at += piece) {
                 const uint64_t m = std::min(piece, n - at);
                 const uint32_t nblocks = uint32_t((m + block - 1) / block);
-                const uint32_t shard_capacity = ((nblocks + DEFER_SHARDS - 1) / DEFER_SHARDS) * block;
+                pass_queues pq{};
+                pq.defer_capacity = ((nblocks + DEFER_SHARDS - 1) / DEFER_SHARDS) * block;
+                pq.resume_capacity = d.sk.enabled ? (pq.defer_capacity + 1) / 2 : 0;
+                const uint64_t defer_places = uint64_t(DEFER_SHARDS) * pq.defer_capacity, resume_places = uint64_t(DEFER_SHARDS) * pq.resume_capacity;
                 std::lock_guard<std::mutex> enqueue(rep->launch_mutex);
-                uint32_t* scratch = static_cast<uint32_t*>(
-                    rep->scratch_for(stream, (uint64_t(DEFER_SHARDS) * shard_capacity + DEFER_SHARDS) * sizeof(uint32_t)));
-                HIP_CHECK(hipMemsetAsync(scratch, 0, DEFER_SHARDS * sizeof(uint32_t), stream));
+                char* scratch = static_cast<char*>(rep->scratch_for(
+                    stream, 2 * DEFER_SHARDS * sizeof(uint32_t) + (defer_places + resume_places) * sizeof(uint32_t) + resume_places * W * sizeof(uint64_t) + 64));
+                HIP_CHECK(hipMemsetAsync(scratch, 0, 2 * DEFER_SHARDS * sizeof(uint32_t), stream));
+                pq.defer_counts = reinterpret_cast<uint32_t*>(scratch);
+                pq.resume_counts = pq.defer_counts + DEFER_SHARDS;
+                pq.resume_kmers = reinterpret_cast<uint64_t*>(pq.resume_counts + DEFER_SHARDS);  // 8-byte aligned: 2 * 2048 * 4 bytes in
+                pq.defer_index = reinterpret_cast<uint32_t*>(pq.resume_kmers + resume_places * W);
+                pq.resume_index = pq.defer_index + defer_places;
                 const void* qa = static_cast<const char*>(q) + at * (ASCII ? kbytes : qbytes);
                 const result_view ids = advance(out, at);
                 uint8_t* mem = member ? member + at : nullptr;
-                if (d.sk.enabled)
+                if (d.sk.enabled) {
                     hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII, true>), dim3(nblocks), dim3(block), 0, stream, d, qa,
-                                       m, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
-                else
+                                       m, check_rc, ids, mem, pq);
+                    hipLaunchKernelGGL((resume_lookup_kernel<W, CANON, MODE>), dim3(DEFER_SHARDS * RESUME_PARTS), dim3(block), 0, stream, d,
+                                       check_rc, ids, mem, pq);
+                } else {
                     hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII, false>), dim3(nblocks), dim3(block), 0, stream, d, qa,
-                                       m, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
+                                       m, check_rc, ids, mem, pq);
+                }
                 hipLaunchKernelGGL((deferred_lookup_kernel<W, CANON, MODE, ASCII>), dim3(DEFER_SHARDS * DEFER_BLOCKS_PER_SHARD), dim3(block), 0, stream, d,
-                                   skew, qa, check_rc, ids, mem, scratch + DEFER_SHARDS, scratch, shard_capacity);
+                                   skew, qa, check_rc, ids, mem, pq);
                 HIP_CHECK(hipGetLastError());
             }
             return;

@@ -345,7 +345,7 @@ __device__ __forceinline__ hit_t lookup_one(dict_view const& d, skew_part_dev co
    buckets, probes left open by an overflowed directory bucket, canonical minimizer ties); deferred
    queries are compacted into a queue and re-run through `lookup_one` by a second, small launch. */
 
-enum fast_outcome : int { FAST_MISS = 0, FAST_HIT = 1, FAST_DEFER = 2 };
+enum fast_outcome : int { FAST_MISS = 0, FAST_HIT = 1, FAST_DEFER = 2, FAST_CONTINUE = 3 /* table probe to be resumed; kmer_offset = queue-entry flags */ };
 
 struct fast_t {
     uint64_t kmer_offset;
@@ -463,17 +463,18 @@ __device__ __forceinline__ kmer_w<W> kmer_pick(bool first, kmer_w<W> const& a, k
     return out;
 }
 
-/* c-th bucket of a key; c is uniform over the wave wherever this is called, so these are scalar selects */
+/* c-th bucket of a key */
 __device__ __forceinline__ uint32_t sk_choice(sk_hash_t const& h, uint32_t c) {
     return c == 0 ? h.bucket[0] : c == 1 ? h.bucket[1] : c == 2 ? h.bucket[2] : h.bucket[3];
 }
 
-/* One bucket (choice c of the key) against one query. `piece(slot, i)` yields the i-th 16-byte piece of a slot of
-   the bucket -- out of LDS, where the quad staged the line, or out of global memory. `go_on`: the bucket's flag for
-   choice c. */
+/* One bucket (choice c of the sequence being followed) against one query. `piece(slot, i)` yields the i-th 16-byte
+   piece of a slot of the bucket -- out of LDS, where the quad staged the line, or out of global memory. Both slots
+   are compared in straight-line code (selects, no branch). Out: r (a hit), `go_on` (the bucket's flag for choice c),
+   `marker` (a slot says that the key is heavy: its k-mers are entered under keys of their own), `key_seen`. */
 template <int W, class Piece>
 __device__ __forceinline__ void sk_examine_bucket(dict_view const& d, sk_query_t<W> const Q, uint32_t c, Piece piece, fast_t& r,
-                                                  bool& key_seen, uint32_t& go_on) {
+                                                  bool& key_seen, uint32_t& go_on, bool& marker) {
     const uint32_t km = d.k - d.m;
     const uint32_t j = Q.j;
     /* values, not references into Q: a select between two members of a by-reference struct is compiled into an
@@ -484,7 +485,8 @@ __device__ __forceinline__ void sk_examine_bucket(dict_view const& d, sk_query_t
         y_rc.w[t] = Q.y_rc.w[t];
     }
     go_on = 0;
-#pragma unroll 1
+    marker = false;
+#pragma unroll
     for (uint32_t slot = 0; slot < SK_BUCKET_SLOTS; ++slot) {
         const uint4 q0 = piece(slot, 0), q1 = piece(slot, 1);
         uint4 q2 = q1;
@@ -492,65 +494,102 @@ __device__ __forceinline__ void sk_examine_bucket(dict_view const& d, sk_query_t
         const uint32_t meta = q0.x;
         if (slot == 0) {
             /* decided now, in its own register: hipcc 7.2 has been seen recycling a slot word that is only
-               consumed after the list scan */
+               consumed much later */
             go_on = meta & (SK_GO_ON << c);
             asm volatile("" : "+v"(go_on));
         }
-        if (meta & SK_VALID) {
-            const uint64_t at = uint64_t(q0.z) | (uint64_t(q0.w & 0xFFu) << 32);
-            const bool same_fingerprint = (q0.w >> 8) == Q.fingerprint;
-            key_seen = key_seen || same_fingerprint;
-            if (!(meta & SK_LIST)) {
-                /* inline super-k-mer: the strings read the key forward (strand 0: y aligns, key at km - a)
-                   or reverse-complemented (strand 1: rc(y) aligns, its copy of the key sits at km - j).
-                   No fingerprint test: the k-mer comparison is the test. */
-                const bool o = (meta & SK_STRAND) != 0;
-                const uint32_t a = o ? j : km - j;
-                const uint64_t w0 = uint64_t(q1.x) | (uint64_t(q1.y) << 32), w1 = uint64_t(q1.z) | (uint64_t(q1.w) << 32);
-                kmer_w<W> cand;
-                if constexpr (W == 1) {
-                    cand.w[0] = funnel_shr(w0, w1, 2 * a);
-                } else {
-                    const uint64_t w2 = uint64_t(q2.x) | (uint64_t(q2.y) << 32), w3 = uint64_t(q2.z) | (uint64_t(q2.w) << 32);
-                    const bool up = 2 * a >= 64;  // a <= 62: the k-mer starts in word 0 or 1
-                    const uint32_t sh = (2 * a) & 63u;
-                    const uint64_t e0 = up ? w1 : w0, e1 = up ? w2 : w1, e2 = up ? w3 : w2;
-                    cand.w[0] = funnel_shr(e0, e1, sh);
-                    cand.w[1] = funnel_shr(e1, e2, sh);
-                }
-                cand = kmer_take_chars<W>(cand, d.k);
-                const uint32_t left = (meta >> SK_LEFT_SHIFT) & 63u, right = (meta >> SK_RIGHT_SHIFT) & 63u;
-                if (kmer_eq<W>(cand, kmer_pick<W>(o, y_rc, y)) && a + left >= km && a <= right) {
-                    r.kmer_offset = at + a - km;
-                    r.string_id = q0.y;
-                    r.orientation = (o != Q.s) ? -1 : 1;
-                    r.outcome = FAST_HIT;
-                }
-            } else if (same_fingerprint) {
-                const uint32_t size = q0.y;
-                if (size == 0) r.outcome = FAST_DEFER;  // list longer than SK_LIST_MAX
-                /* the two inline occurrences; selected by arithmetic (a ternary on t turns the slot into a scratch array) */
-                const uint64_t in0 = uint64_t(q1.x) | (uint64_t(q1.y) << 32), in1 = uint64_t(q1.z) | (uint64_t(q1.w) << 32);
-                for (uint32_t t = 0; t < size; ++t) {
-                    uint64_t v = in0 ^ ((in0 ^ in1) & (uint64_t(0) - uint64_t(t & 1u)));
-                    if (size > 2) v = d.sk.occ[at + t];
-                    const bool o = (v & 1) != 0;
-                    const uint64_t p = v >> 1;
-                    const uint32_t a = o ? j : km - j;
-                    if (p + a < km) continue;
-                    const window_t<W> w = read_window<W>(d.granules, p + a - km, d.k);
-                    if (kmer_eq<W>(w.kmer, kmer_pick<W>(o, y_rc, y)) && !w.crosses) {
-                        r.kmer_offset = p + a - km;
-                        r.string_id = w.string_id;
-                        r.orientation = (o != Q.s) ? -1 : 1;
-                        r.outcome = FAST_HIT;
-                        break;
-                    }
-                }
-            }
+        const bool valid = (meta & SK_VALID) != 0, is_marker = (meta & SK_MARKER) != 0;
+        const bool same_fingerprint = valid && (q0.w >> 8) == Q.fingerprint;
+        key_seen = key_seen || same_fingerprint;
+        marker = marker || (same_fingerprint && is_marker);
+        /* inline super-k-mer: the strings read the key forward (strand 0: y aligns, key at km - a)
+           or reverse-complemented (strand 1: rc(y) aligns, its copy of the key sits at km - j).
+           No fingerprint test: the k-mer comparison is the test. */
+        const uint64_t at = uint64_t(q0.z) | (uint64_t(q0.w & 0xFFu) << 32);
+        const bool o = (meta & SK_STRAND) != 0;
+        const uint32_t a = o ? j : km - j;
+        const uint64_t w0 = uint64_t(q1.x) | (uint64_t(q1.y) << 32), w1 = uint64_t(q1.z) | (uint64_t(q1.w) << 32);
+        kmer_w<W> cand;
+        if constexpr (W == 1) {
+            cand.w[0] = funnel_shr(w0, w1, 2 * a);
+        } else {
+            const uint64_t w2 = uint64_t(q2.x) | (uint64_t(q2.y) << 32), w3 = uint64_t(q2.z) | (uint64_t(q2.w) << 32);
+            const bool up = 2 * a >= 64;  // a <= 62: the k-mer starts in word 0 or 1
+            const uint32_t sh = (2 * a) & 63u;
+            const uint64_t e0 = up ? w1 : w0, e1 = up ? w2 : w1, e2 = up ? w3 : w2;
+            cand.w[0] = funnel_shr(e0, e1, sh);
+            cand.w[1] = funnel_shr(e1, e2, sh);
         }
-        if (r.outcome != FAST_MISS) break;  // settled: the other slot need not be looked at
+        cand = kmer_take_chars<W>(cand, d.k);
+        const uint32_t left = (meta >> SK_LEFT_SHIFT) & 63u, right = (meta >> SK_RIGHT_SHIFT) & 63u;
+        const bool hit = valid && !is_marker && kmer_eq<W>(cand, kmer_pick<W>(o, y_rc, y)) && a + left >= km && a <= right;
+        /* a k-mer occurs once in the strings: at most one slot hits */
+        r.kmer_offset = hit ? at + a - km : r.kmer_offset;
+        r.string_id = hit ? q0.y : r.string_id;
+        r.orientation = hit ? ((o != Q.s) ? int8_t(-1) : int8_t(1)) : r.orientation;
+        r.outcome = hit ? int(FAST_HIT) : r.outcome;
     }
+}
+
+/* Where a probe stands: the bucket sequence it follows (its key's, or -- once it has met its key's marker -- its
+   k-mer's own), the next choice of it, and the choice of the key's sequence to come back to if the k-mer's sequence
+   ends without the k-mer (the marker may have been another key's with an equal fingerprint). */
+constexpr uint32_t SK_NO_RETURN = 0xFFu;
+
+struct sk_walk_t {
+    sk_hash_t h;
+    uint32_t c;
+    uint32_t back_to;  // SK_NO_RETURN: nothing to come back to
+    bool on_kmer_sequence;
+};
+
+__device__ __forceinline__ sk_walk_t sk_walk_begin(sk_hash_t const& h, uint32_t c) {
+    sk_walk_t w;
+    w.h = h;
+    w.c = c;
+    w.back_to = SK_NO_RETURN;
+    w.on_kmer_sequence = false;
+    return w;
+}
+
+template <int W>
+__device__ __forceinline__ void sk_walk_to_kmer_sequence(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_walk_t& w,
+                                                         sk_query_t<W>& Q, bool go_on) {
+    w.back_to = go_on ? w.c + 1 : SK_NO_RETURN;
+    w.h = sk_hash(sk_kmer_key<W>(x, x_rc), d.sk.num_buckets);
+    w.c = 0;
+    w.on_kmer_sequence = true;
+    Q.fingerprint = w.h.fingerprint;
+}
+
+/* After a bucket has been examined: true = another bucket (w.c of w.h) is to be read; false = r is final (FAST_MISS
+   stands for a final miss). */
+template <int W>
+__device__ __forceinline__ bool sk_walk_step(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
+                                             sk_walk_t& w, sk_query_t<W>& Q, fast_t& r, uint32_t go_on, bool marker) {
+    if (r.outcome != FAST_MISS) return false;
+    if (marker && !w.on_kmer_sequence) {
+        sk_walk_to_kmer_sequence<W>(d, x, x_rc, w, Q, go_on != 0);
+        return true;
+    }
+    if (go_on != 0) {
+        if (++w.c < SK_CHOICES) return true;
+        r.outcome = FAST_DEFER;  // a key (or k-mer) that found no slot: complete path
+        return false;
+    }
+    if (w.on_kmer_sequence && w.back_to != SK_NO_RETURN) {
+        /* the k-mer is not under its own key: what is left is the rest of the key's sequence */
+        w.c = w.back_to;
+        w.back_to = SK_NO_RETURN;
+        if (w.c >= SK_CHOICES) {
+            r.outcome = FAST_DEFER;
+            return false;
+        }
+        w.h = sk_hash(kk.key, d.sk.num_buckets);
+        Q.fingerprint = w.h.fingerprint;
+        return true;
+    }
+    return false;
 }
 
 /* One lane on its own, every piece read from global memory: the streaming query, whose lanes are at different
@@ -558,29 +597,30 @@ __device__ __forceinline__ void sk_examine_bucket(dict_view const& d, sk_query_t
 template <int W>
 __device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
                                            bool& key_seen) {
-    const sk_hash_t h = sk_hash(kk.key, d.sk.num_buckets);
-    const sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, h.fingerprint);
+    sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), 0);
+    sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, w.h.fingerprint);
     fast_t r = fast_unsettled(false);
     key_seen = false;
+    bool more = true;
 #pragma unroll 1
-    for (uint32_t c = 0; c < SK_CHOICES; ++c) {
-        const uint4* B = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(sk_choice(h, c));
+    while (more) {
+        const uint4* B = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(sk_choice(w.h, w.c));
         uint32_t go_on;
-        sk_examine_bucket<W>(d, Q, c, [B](uint32_t slot, uint32_t i) { return B[slot * (2 * W) + i]; }, r, key_seen, go_on);
-        if (r.outcome != FAST_MISS || go_on == 0) break;  // settled, or nobody who hashed here lives elsewhere
-        if (c + 1 == SK_CHOICES) r.outcome = FAST_DEFER;  // a key that found no slot: complete path
+        bool marker, seen = false;
+        sk_examine_bucket<W>(d, Q, w.c, [B](uint32_t slot, uint32_t i) { return B[slot * (2 * W) + i]; }, r, seen, go_on, marker);
+        key_seen = key_seen || (seen && !w.on_kmer_sequence);
+        more = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
     }
     return r;
 }
 
-/* ---- the same probe by a whole wave: quad-cooperative line fetch into LDS ------------------------------------
-   Must be called by all 64 lanes of the wave together (lanes without a query pass want = false). Round p of a
+/* ---- the same probe by a whole wave: quad-cooperative line fetch through LDS -----------------------------------
+   Must be called by all 64 lanes of the wave together (lanes without a query pass need = false). Round p of a
    bucket fetch: the four lanes of every quad read the four 16-byte pieces of ONE 64-byte line -- the bucket of the
-   quad's lane p & 3 -- with one global_load_lds_dwordx4, which deposits lane L's piece at region p + 16 L of the
-   wave's staging area: quad q's line lands contiguously at region p + 64 q, so the transposition from "lane = piece"
-   to "lane = owner of the whole line" costs no instruction and no register. 4 W rounds fetch the buckets of all 64
-   lanes. The memory pipeline sees one request (and one address translation) per line instead of one per 16-byte load
-   (device_layout.hpp (5)). */
+   quad's lane p & 3 -- with one load instruction, and lane L deposits its piece at region p + 16 L of the wave's
+   staging area: quad q's line lands contiguously at region p + 64 q, which transposes "lane = piece" into "lane =
+   owner of the whole line". 4 W rounds fetch the buckets of all 64 lanes. The memory pipeline sees one request (and
+   one address translation) per line instead of one per 16-byte load (device_layout.hpp (5)). */
 typedef __attribute__((address_space(3))) void* sk_lds_ptr;
 typedef const __attribute__((address_space(1))) void* sk_global_ptr;
 
@@ -589,79 +629,153 @@ __device__ __forceinline__ uint32_t quad_broadcast(uint32_t v) {
     return uint32_t(__builtin_amdgcn_mov_dpp(int(v), OWNER * 0x55, 0xf, 0xf, true));
 }
 
+/* Every lane with need = true gets its bucket into its place of the wave's staging area. The broadcasts and the loads
+   are executed by ALL lanes, unconditionally: a quad whose owner of the round has no use for a bucket fetches bucket 0
+   (one line, shared by all such quads: an L2 hit) into a place nobody reads.
+
+   Two ways to move the pieces: through registers (global_load_dwordx4 + ds_write_b128; the default) or straight into
+   LDS with global_load_lds_dwordx4 (SSHASH_STAGE_WITH_LDS_DMA=1), which needs no staging VGPRs and no ds_write. The
+   LDS-DMA path measured the same speed (the kernel is bound by DRAM line fetches, not by issue), and some kernel
+   instances built on it -- which ones changed with unrelated edits -- reported 0.1-0.4 % of the indexed k-mers absent,
+   differently from launch to launch, although micro-benchmarks of the very same instruction sequence (tools/debug/:
+   glds_check, m0_check, vcc_check; 10^9 checked lines) never returned a wrong byte once the wait for the DMA was
+   spelled out. hipcc 7.2 models the builtin as a 16-byte store at the given LDS address (it is a 1 KiB scatter), skips
+   the wait before DS reads it believes unrelated (glds_check: 91 % stale reads) -- the explicit wait below covers that --
+   and presumably takes further liberties of the same origin that were not pinned down. The register path uses nothing
+   the compiler does not fully model; every parity test passes on it, three runs in a row, without any guard. */
 template <int W, int P>
-__device__ __forceinline__ void sk_stage_round(char const* __restrict__ slots, uint32_t bucket, uint32_t need, uint32_t sub,
-                                               uint4* wave_stage) {
-    constexpr int OWNER = P & 3, LINE = P >> 2;
-    const uint32_t ob = quad_broadcast<OWNER>(bucket);
-    const uint32_t on = quad_broadcast<OWNER>(need);
-    if (on)
-        __builtin_amdgcn_global_load_lds((sk_global_ptr)(slots + uint64_t(ob) * (64 * W) + 64 * LINE + 16 * sub),
-                                         (sk_lds_ptr)(wave_stage + P * 64), 16, 0, 0);
+__device__ __forceinline__ void sk_stage_round_dma(char const* __restrict__ slots, uint32_t bucket_of_owner, uint32_t sub, uint4* wave_stage) {
+    constexpr int LINE = P >> 2;
+    __builtin_amdgcn_global_load_lds((sk_global_ptr)(slots + uint64_t(bucket_of_owner) * (64 * W) + 64 * LINE + 16 * sub),
+                                     (sk_lds_ptr)(wave_stage + P * 64), 16, 0, 0);
 }
 
 template <int W>
-__device__ __forceinline__ fast_t sk_probe_wave(dict_view const& d, sk_query_t<W> const& Q, sk_hash_t const& h, bool want,
-                                                uint4* wave_stage /* 64 * 4 * W uint4 of LDS, this wave's own */,
-                                                bool& key_seen) {
-    fast_t r = fast_unsettled(false);
-    key_seen = false;
-    bool need = want;
-    const uint32_t lane = threadIdx.x & 63u, sub = lane & 3u;
+__device__ __forceinline__ void sk_stage_buckets(dict_view const& d, uint32_t bucket, bool need, uint4* wave_stage) {
     char const* slots = static_cast<char const*>(d.sk.slots);
-    const uint4* mine = wave_stage + sub * 64 + (lane >> 2) * 4;  // region (lane & 3), line of quad (lane >> 2)
-#pragma unroll 1
-    for (uint32_t c = 0; c < SK_CHOICES; ++c) {
-        if (__ballot(need) == 0) break;  // wave-uniform
-        const uint32_t bucket = need ? sk_choice(h, c) : 0u;
-        const uint32_t n32 = need ? 1u : 0u;
-        sk_stage_round<W, 0>(slots, bucket, n32, sub, wave_stage);
-        sk_stage_round<W, 1>(slots, bucket, n32, sub, wave_stage);
-        sk_stage_round<W, 2>(slots, bucket, n32, sub, wave_stage);
-        sk_stage_round<W, 3>(slots, bucket, n32, sub, wave_stage);
-        if constexpr (W == 2) {
-            sk_stage_round<W, 4>(slots, bucket, n32, sub, wave_stage);
-            sk_stage_round<W, 5>(slots, bucket, n32, sub, wave_stage);
-            sk_stage_round<W, 6>(slots, bucket, n32, sub, wave_stage);
-            sk_stage_round<W, 7>(slots, bucket, n32, sub, wave_stage);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (need) {
-            uint32_t go_on;
-            /* W = 1: the line holds both slots (pieces 0-1, 2-3); W = 2: slot 1 is the second line, four regions on */
-            sk_examine_bucket<W>(d, Q, c, [mine](uint32_t slot, uint32_t i) { return W == 1 ? mine[2 * slot + i] : mine[slot * 256 + i]; },
-                                 r, key_seen, go_on);
-            need = r.outcome == FAST_MISS && go_on != 0;
-            if (need && c + 1 == SK_CHOICES) {
-                r.outcome = FAST_DEFER;  // a key that found no slot: complete path
-                need = false;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+    const uint32_t sub = threadIdx.x & 3u;
+    const uint32_t mine = need ? bucket : 0u;
+    const uint32_t b0 = quad_broadcast<0>(mine), b1 = quad_broadcast<1>(mine), b2 = quad_broadcast<2>(mine), b3 = quad_broadcast<3>(mine);
+#if !SSHASH_STAGE_WITH_LDS_DMA
+    const uint32_t lane = threadIdx.x & 63u;
+    uint4 piece[4 * W];
+    const uint32_t owner_bucket[4] = {b0, b1, b2, b3};
+#pragma unroll
+    for (int p = 0; p < 4 * W; ++p)
+        piece[p] = *reinterpret_cast<const uint4*>(slots + uint64_t(owner_bucket[p & 3]) * (64 * W) + 64 * (p >> 2) + 16 * sub);
+#pragma unroll
+    for (int p = 0; p < 4 * W; ++p) wave_stage[p * 64 + lane] = piece[p];
+    /* other lanes of this wave read what this lane wrote: order the LDS accesses for the compiler (the hardware
+       executes a wave's DS instructions in order) */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    sk_stage_round_dma<W, 0>(slots, b0, sub, wave_stage);
+    sk_stage_round_dma<W, 1>(slots, b1, sub, wave_stage);
+    sk_stage_round_dma<W, 2>(slots, b2, sub, wave_stage);
+    sk_stage_round_dma<W, 3>(slots, b3, sub, wave_stage);
+    if constexpr (W == 2) {
+        sk_stage_round_dma<W, 4>(slots, b0, sub, wave_stage);
+        sk_stage_round_dma<W, 5>(slots, b1, sub, wave_stage);
+        sk_stage_round_dma<W, 6>(slots, b2, sub, wave_stage);
+        sk_stage_round_dma<W, 7>(slots, b3, sub, wave_stage);
     }
-    return r;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the lines must have landed before any DS read of the staging area
+    __builtin_amdgcn_wave_barrier();
+#endif
 }
 
-/* Same contract as fast_lookup_one, for a whole wave (lanes beyond the batch pass active = false and get a
-   placeholder). `allow_rc` false (regular dictionary, check_reverse_complement off: src/dictionary.cpp:70-71) turns a
-   hit on the other strand into a miss. `miss_orientation`: what a miss reports (-1 after a regular dictionary's
-   reverse-complement probe, src/dictionary.cpp:74-75). */
+/* what the first pass hands to the second in a queue entry, above the query's index */
+constexpr uint32_t RESUME_CHOICE_SHIFT = 28;  // bits 28-29: choice of the key's sequence the entry refers to
+constexpr uint32_t RESUME_HEAVY = 1u << 30;   // the key's marker was met there: start on the k-mer's own sequence ...
+constexpr uint32_t RESUME_GO_ON = 1u << 31;   // ... and that bucket's go-on flag was set (the key's sequence continues)
+
+/* First pass: ONE bucket read per query (choice 0 of its key's sequence). Settled: FAST_HIT / FAST_MISS (final);
+   otherwise FAST_CONTINUE with r.kmer_offset = the flags of a queue entry (above), or FAST_DEFER. Called by all 64
+   lanes (active = false: no query). `allow_rc` false (regular dictionary, check_reverse_complement off:
+   src/dictionary.cpp:70-71) turns a hit on the other strand into a miss. `miss_orientation`: what a miss reports (-1
+   after a regular dictionary's reverse-complement probe, src/dictionary.cpp:74-75). */
 template <int W>
-__device__ __forceinline__ fast_t sk_lookup_wave(dict_view const& d, kmer_w<W> const& x, bool active, bool allow_rc,
-                                                 int8_t miss_orientation, uint4* wave_stage) {
+__device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<W> const& x, bool active, bool allow_rc,
+                                                     int8_t miss_orientation, uint4* wave_stage) {
     const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
     const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
     const bool usable = active && sk_usable(d, kk);  // else: no strand-symmetric key, or a key of another table shard
     const sk_hash_t h = sk_hash(kk.key, d.sk.num_buckets);
     const sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, h.fingerprint);
-    bool key_seen;
-    fast_t r = sk_probe_wave<W>(d, Q, h, usable, wave_stage, key_seen);
-    if (!usable) r = fast_unsettled(active);
-    else if (r.outcome == FAST_MISS || (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc)) {
+    sk_stage_buckets<W>(d, usable ? h.bucket[0] : 0u, usable, wave_stage);
+    fast_t r = fast_unsettled(active && !usable);
+    if (usable) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint4* mine = wave_stage + (lane & 3u) * 64 + (lane >> 2) * 4;  // region (lane & 3), line of quad (lane >> 2)
+        uint32_t go_on;
+        bool marker, key_seen = false;
+        /* W = 1: the line holds both slots (pieces 0-1, 2-3); W = 2: slot 1 is the second line, four regions on */
+        sk_examine_bucket<W>(d, Q, 0u, [mine](uint32_t slot, uint32_t i) { return W == 1 ? mine[2 * slot + i] : mine[slot * 256 + i]; }, r,
+                             key_seen, go_on, marker);
+        if (r.outcome == FAST_MISS) {
+            if (marker) {
+                r.outcome = FAST_CONTINUE;
+                r.kmer_offset = RESUME_HEAVY | (go_on ? RESUME_GO_ON : 0u);
+            } else if (go_on) {
+                r.outcome = FAST_CONTINUE;
+                r.kmer_offset = 1u << RESUME_CHOICE_SHIFT;
+            } else {
+                r.orientation = miss_orientation;
+            }
+        } else if (r.orientation < 0 && !allow_rc) {
+            r = fast_unsettled(false);
+            r.orientation = miss_orientation;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return r;
+}
+
+/* Second pass: a queue entry of the first pass, walked to the end. Same contract; never returns FAST_CONTINUE. */
+template <int W>
+__device__ __forceinline__ fast_t sk_second_pass_wave(dict_view const& d, kmer_w<W> const& x, bool active, uint32_t entry, bool allow_rc,
+                                                      int8_t miss_orientation, uint4* wave_stage) {
+    const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
+    const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
+    sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), (entry >> RESUME_CHOICE_SHIFT) & 3u);
+    sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, w.h.fingerprint);
+    if (entry & RESUME_HEAVY) sk_walk_to_kmer_sequence<W>(d, x, x_rc, w, Q, (entry & RESUME_GO_ON) != 0);
+    fast_t r = fast_unsettled(false);
+    bool need = active;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint4* mine = wave_stage + (lane & 3u) * 64 + (lane >> 2) * 4;
+#pragma unroll 1
+    while (__ballot(need) != 0) {  // wave-uniform
+        sk_stage_buckets<W>(d, need ? sk_choice(w.h, w.c) : 0u, need, wave_stage);
+        if (need) {
+            uint32_t go_on;
+            bool marker, key_seen = false;
+            sk_examine_bucket<W>(d, Q, w.c, [mine](uint32_t slot, uint32_t i) { return W == 1 ? mine[2 * slot + i] : mine[slot * 256 + i]; }, r,
+                                 key_seen, go_on, marker);
+            need = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (r.outcome == FAST_MISS || (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc)) {
         r = fast_unsettled(false);
         r.orientation = miss_orientation;
     }
     return r;
+}
+
+/* Append to one of the sharded queues of the multi-pass lookup: one atomic per wave, the pushing lanes take
+   consecutive places. Returns the place (>= capacity: the queue is full, nothing may be written). */
+__device__ __forceinline__ uint32_t wave_queue_place(bool push, uint32_t* counter) {
+    const uint64_t mask = __ballot(push);
+    if (mask == 0) return 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t leader = uint32_t(__ffsll((unsigned long long)mask)) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, uint32_t(__popcll(mask)));
+    base = __shfl(base, int(leader), 64);
+    return base + uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
 }
 
 /* hit -> lookup_result fields (include/offsets.hpp:138-154, spss.hpp:226-228) */

@@ -11,8 +11,10 @@
 //   3. place    SK_CHOICES rounds, one per hashed bucket choice: a key claims the first free slot of the bucket with a
 //               CAS on the slot's flag word; a key that finds the bucket full sets the bucket's "go on" flag and waits
 //               for the next round.
-//   4. fill     the winner writes its slot: the 64 bases around a single occurrence, how far the
-//               super-k-mer may extend inside its string, the string id -- or the occurrence list.
+//   4. fill     the winner writes its slot: the 64 bases around one occurrence, how far the super-k-mer may extend
+//               inside its string, the string id. A key with up to SK_INLINE_MAX occurrences takes one such slot per
+//               occurrence (a lookup then never leaves the table); a key with more takes one slot pointing at its
+//               occurrence list.
 #include <hip/hip_runtime.h>
 
 #include <hipcub/hipcub.hpp>
@@ -99,79 +101,154 @@ __device__ __forceinline__ void read_bases(void const* __restrict__ blocks, int6
     }
 }
 
-/* One lane per key (run of the sorted tuples), one launch per slot choice. */
-template <int W>
+/* ---- items: what is placed into the table, one slot each ----
+   flags[t] of tuple t (sorted by key): 0 = an occurrence of a light key (<= SK_INLINE_MAX occurrences): its own inline
+   slot; 1 = first occurrence of a heavy key: the key's marker slot; 2 = further occurrence of a heavy key: no slot
+   under the key. The k-mers of the heavy keys' occurrences are items of their own (keys = sk_kmer_key). */
+constexpr uint8_t SK_ITEM_INLINE = 0, SK_ITEM_MARKER = 1, SK_ITEM_NONE = 2;
+
+/* one lane per run: classify its tuples */
 __global__ void __launch_bounds__(256)
-sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_keys, const uint64_t* __restrict__ keys,
-                const uint32_t* __restrict__ run_sizes, const uint32_t* __restrict__ run_begins, const uint64_t* __restrict__ occ,
-                uint32_t* __restrict__ slots, const uint32_t num_buckets, uint8_t* __restrict__ placed,
-                unsigned long long* __restrict__ stats) {
+sk_classify_kernel(const uint64_t num_keys, const uint32_t* __restrict__ run_sizes, const uint32_t* __restrict__ run_begins,
+                   uint8_t* __restrict__ flags, unsigned long long* __restrict__ stats) {
     const uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    bool is_inline = false, too_long = false, unplaced = false;
-    if (r < num_keys && !placed[r]) {
-        const uint64_t key = keys[r];
-        const sk_hash_t h = sk_hash(key, num_buckets);
-        uint32_t* B = slots + (SK_BUCKET_SLOTS * 8 * W) * uint64_t(h.bucket[choice]);  // slot 0 of the bucket: carries the flags
-        /* claim the first free slot of the bucket: set its valid bit unless somebody holds it (other lanes may be
-           OR-ing flags into slot 0's word) */
-        uint32_t* S = B;
-        bool mine = false;
-        for (uint32_t slot = 0; slot < SK_BUCKET_SLOTS && !mine; ++slot) {
-            S = B + slot * (8 * W);
-            uint32_t cur = __hip_atomic_load(S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (!(cur & SK_VALID)) {
-                const uint32_t seen = atomicCAS(S, cur, cur | SK_VALID);
-                if (seen == cur) {
-                    mine = true;
-                    break;
-                }
-                cur = seen;
-            }
-        }
-        if (!mine) {
-            atomicOr(B, SK_GO_ON << choice);
-            unplaced = choice + 1 == SK_CHOICES;
-        } else {
-            placed[r] = 1;
-            const uint32_t size = run_sizes[r];
+    bool heavy = false;
+    uint32_t size = 0;
+    if (r < num_keys) {
+        size = run_sizes[r];
+        heavy = size > SK_INLINE_MAX;
+        if (heavy) {
             const uint64_t begin = run_begins[r];
-            uint32_t meta, d1;
-            uint64_t w1;
-            uint64_t body[2 * W];
-            for (int i = 0; i < 2 * W; ++i) body[i] = 0;
-            if (size == 1) {
-                const uint64_t v = occ[begin];
-                const uint64_t p = v >> 1;
-                const uint32_t km = d.k - d.m;
-                const uint32_t sid = read_window<W>(d.granules, p, 1).string_id;
-                const uint64_t s_begin = d.endpoints[sid], s_end = d.endpoints[sid + 1];
-                const uint64_t left = p - s_begin < km ? p - s_begin : km;
-                const uint64_t right = s_end - (p + d.m) < km ? s_end - (p + d.m) : km;
-                meta = (uint32_t(v & 1) ? SK_STRAND : 0u) | (uint32_t(left) << SK_LEFT_SHIFT) | (uint32_t(right) << SK_RIGHT_SHIFT);
-                d1 = sid;
-                w1 = p | (uint64_t(h.fingerprint) << 40);
-                read_bases<W>(d.granules, int64_t(p) - int64_t(km), body);
-                is_inline = true;
-            } else {
-                meta = SK_LIST;
-                too_long = size > SK_LIST_MAX;
-                d1 = too_long ? 0u : size;
-                w1 = begin | (uint64_t(h.fingerprint) << 40);
-                body[0] = size <= 2 ? occ[begin] : 0;
-                body[1] = size == 2 ? occ[begin + 1] : 0;
-            }
-            S[1] = d1;
-            reinterpret_cast<uint64_t*>(S)[1] = w1;
-            for (int i = 0; i < 2 * W; ++i) reinterpret_cast<uint64_t*>(S)[2 + i] = body[i];
-            if (meta) atomicOr(S, meta);
+            flags[begin] = SK_ITEM_MARKER;
+            for (uint32_t t = 1; t < size; ++t) flags[begin + t] = SK_ITEM_NONE;
         }
     }
-    /* statistics: one atomic per wave and counter, not per key */
-    const uint64_t b0 = __ballot(is_inline), b1 = __ballot(too_long), b2 = __ballot(unplaced);
+    const uint64_t b = __ballot(heavy);
+    uint64_t occs = heavy ? size : 0;
+    for (int o = 32; o > 0; o >>= 1) occs += __shfl_down(occs, o, 64);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && b) {
+        atomicAdd(stats + 4, (unsigned long long)__popcll(b));  // heavy keys
+        atomicAdd(stats + 5, (unsigned long long)occs);         // their occurrences
+    }
+}
+
+/* One lane per (occurrence of a heavy key, alignment a): the k-mer starting km - a bases before the occurrence, if it
+   lies inside its string and elects this very occurrence as its key, becomes an item keyed by sk_kmer_key. EMIT off:
+   count only. */
+template <int W, bool EMIT>
+__global__ void __launch_bounds__(256)
+sk_heavy_kmers_kernel(const dict_view d, const uint64_t first_tuple, const uint64_t num_tuples, const uint8_t* __restrict__ flags,
+                      const uint64_t* __restrict__ occ, unsigned long long* __restrict__ cursor, uint64_t* __restrict__ item_keys,
+                      uint64_t* __restrict__ item_vals) {
+    const uint32_t km = d.k - d.m, per = km + 1;
+    const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t t = first_tuple + g / per;
+    const uint32_t a = uint32_t(g % per);
+    bool mine = false;
+    uint64_t key = 0, v = 0;
+    if (t < num_tuples && flags[t] != SK_ITEM_INLINE) {
+        v = occ[t];
+        const uint64_t p = v >> 1;
+        if (p + a >= km && p + a - km + d.k <= d.num_bases) {
+            const window_t<W> w = read_window<W>(d.granules, p + a - km, d.k);
+            if (!w.crosses) {
+                const kmer_w<W> x = w.kmer, x_rc = kmer_revcomp<W>(x, d.k);
+                const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
+                if (sk_usable(d, kk)) {
+                    const uint64_t q = (p + a - km) + (kk.rc ? km - kk.pos : kk.pos);  // where this k-mer's key occurrence lies
+                    mine = q == p && (kk.rc ? 1u : 0u) == uint32_t(v & 1);
+                    key = sk_kmer_key<W>(x, x_rc);
+                }
+            }
+        }
+    }
+    const uint64_t ballot = __ballot(mine);
+    if (ballot == 0) return;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t leader = uint32_t(__ffsll((unsigned long long)ballot)) - 1u;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(ballot));
+    base = __shfl(base, int(leader), 64);
+    if constexpr (EMIT) {
+        if (mine) {
+            const uint64_t at = base + uint64_t(__popcll(ballot & ((uint64_t(1) << lane) - 1)));
+            item_keys[at] = key;
+            item_vals[at] = v;
+        }
+    }
+}
+
+/* One lane per item, one launch per bucket choice: claim the first free slot of the item's bucket of this choice and
+   fill it; an item that finds the bucket full sets the bucket's go-on flag and waits for the next round (after the
+   last one: it is left to the complete path). flags == nullptr: every item is an inline slot (the heavy keys' k-mers). */
+template <int W>
+__global__ void __launch_bounds__(256)
+sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_items, const uint64_t* __restrict__ item_keys,
+                const uint64_t* __restrict__ item_vals, const uint8_t* __restrict__ flags, uint32_t* __restrict__ slots,
+                const uint32_t num_buckets, uint8_t* __restrict__ placed, unsigned long long* __restrict__ stats) {
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    bool unplaced = false, used = false;
+    if (t < num_items && !placed[t]) {
+        const uint8_t kind = flags ? flags[t] : SK_ITEM_INLINE;
+        if (kind == SK_ITEM_NONE) {
+            placed[t] = 1;
+        } else {
+            const sk_hash_t h = sk_hash(item_keys[t], num_buckets);
+            uint32_t* B = slots + (SK_BUCKET_SLOTS * 8 * W) * uint64_t(h.bucket[choice]);  // slot 0 of the bucket: carries the flags
+            /* claim the first free slot of the bucket: set its valid bit unless somebody holds it (other lanes may be
+               OR-ing flags into slot 0's word) */
+            uint32_t* S = nullptr;
+            for (uint32_t slot = 0; slot < SK_BUCKET_SLOTS && !S; ++slot) {
+                uint32_t* T = B + slot * (8 * W);
+                uint32_t cur = __hip_atomic_load(T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (!(cur & SK_VALID)) {
+                    const uint32_t seen = atomicCAS(T, cur, cur | SK_VALID);
+                    if (seen == cur) {
+                        S = T;
+                        break;
+                    }
+                    cur = seen;
+                }
+            }
+            if (!S) {
+                atomicOr(B, SK_GO_ON << choice);  // this item lives further along -- or, after the last choice, nowhere
+                unplaced = choice + 1 == SK_CHOICES;
+            } else {
+                placed[t] = 1;
+                used = true;
+                uint32_t meta, d1;
+                uint64_t w1;
+                uint64_t body[2 * W];
+                for (int i = 0; i < 2 * W; ++i) body[i] = 0;
+                const uint64_t v = item_vals[t];
+                const uint64_t p = v >> 1;
+                if (kind == SK_ITEM_INLINE) {
+                    const uint32_t km = d.k - d.m;
+                    const uint32_t sid = read_window<W>(d.granules, p, 1).string_id;
+                    const uint64_t s_begin = d.endpoints[sid], s_end = d.endpoints[sid + 1];
+                    const uint64_t left = p - s_begin < km ? p - s_begin : km;
+                    const uint64_t right = s_end - (p + d.m) < km ? s_end - (p + d.m) : km;
+                    meta = (uint32_t(v & 1) ? SK_STRAND : 0u) | (uint32_t(left) << SK_LEFT_SHIFT) | (uint32_t(right) << SK_RIGHT_SHIFT);
+                    d1 = sid;
+                    w1 = p | (uint64_t(h.fingerprint) << 40);
+                    read_bases<W>(d.granules, int64_t(p) - int64_t(km), body);
+                } else {
+                    meta = SK_MARKER;
+                    d1 = 0;
+                    w1 = uint64_t(h.fingerprint) << 40;
+                }
+                S[1] = d1;
+                reinterpret_cast<uint64_t*>(S)[1] = w1;
+                for (int i = 0; i < 2 * W; ++i) reinterpret_cast<uint64_t*>(S)[2 + i] = body[i];
+                if (meta) atomicOr(S, meta);
+            }
+        }
+    }
+    /* statistics: one atomic per wave and counter, not per item */
+    const uint64_t b2 = __ballot(unplaced), b3 = __ballot(used);
     if ((threadIdx.x & (WAVE - 1)) == 0) {
-        if (b0) atomicAdd(stats + 0, (unsigned long long)__popcll(b0));
-        if (b1) atomicAdd(stats + 1, (unsigned long long)__popcll(b1));
         if (b2) atomicAdd(stats + 2, (unsigned long long)__popcll(b2));
+        if (b3) atomicAdd(stats + 3, (unsigned long long)__popcll(b3));
     }
 }
 
@@ -207,7 +284,6 @@ struct temp_buffers {  // freed on every exit path
 void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_shards, uint32_t table_shard_id) {
     dict_view& v = rep.view;
     v.sk.slots = nullptr;
-    v.sk.occ = nullptr;
     v.sk.num_buckets = 0;
     v.sk.enabled = 0;
     v.sk.num_shards = table_shards;  // read by the scan kernel's filter
@@ -221,7 +297,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     const uint64_t num_waves = (positions + 1 + NEW_PER_WAVE - 1) / NEW_PER_WAVE;
     const uint64_t threads = num_waves * WAVE;
     const dim3 block(256), grid(uint32_t((threads + 255) / 256));
-    if ((threads + 255) / 256 >= (uint64_t(1) << 31) || num_waves >= (uint64_t(1) << 31)) return;  // hipCUB item counts are int
+    if (threads >= (uint64_t(1) << 32) || num_waves >= (uint64_t(1) << 31)) return;  // one launch, and hipCUB item counts are int
 
     temp_buffers tmp;
     uint32_t* counts = tmp.alloc<uint32_t>(num_waves);
@@ -277,7 +353,6 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
         HIP_CHECK(hipDeviceSynchronize());
         tmp.release(scratch);
     }
-    tmp.release(keys_sorted);
     uint64_t K = 0;
     HIP_CHECK(hipMemcpy(&K, d_num_runs, 8, hipMemcpyDeviceToHost));
     double slots_per_key = SK_SLOTS_PER_KEY;
@@ -285,15 +360,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
         const double want = std::atof(e);
         if (want >= 1.2 && want <= 16.0) slots_per_key = want;
     }
-    const uint64_t num_buckets = uint64_t(double(K) * slots_per_key / SK_BUCKET_SLOTS) + 8;
-    const uint64_t num_slots = num_buckets * SK_BUCKET_SLOTS;
-    const uint64_t slot_bytes = wide ? 64 : 32;
-    if (K == 0 || num_buckets >= (uint64_t(1) << 32)) return;
-    {
-        size_t free_bytes = 0, total_bytes = 0;
-        HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
-        if (num_slots * slot_bytes + K * 8 > free_bytes / 2) return;  // leave HBM for the caller's batches
-    }
+    if (K == 0) return;
     uint32_t* run_begins = tmp.alloc<uint32_t>(K);
     {
         size_t bytes = 0;
@@ -302,36 +369,85 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
         HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scratch, bytes, run_sizes, run_begins, int(K)));
         tmp.release(scratch);
     }
+    /* stats: 2 unplaced items, 3 slots used, 4 heavy keys, 5 their occurrences, 6 / 7 cursors of the heavy k-mer passes */
+    unsigned long long* stats = tmp.alloc<unsigned long long>(8);
+    HIP_CHECK(hipMemset(stats, 0, 64));
+    uint8_t* flags = tmp.alloc<uint8_t>(T);
+    HIP_CHECK(hipMemset(flags, SK_ITEM_INLINE, T));
+    hipLaunchKernelGGL(sk_classify_kernel, dim3(uint32_t((K + 255) / 256)), block, 0, 0, K, run_sizes, run_begins, flags, stats);
+    HIP_CHECK(hipGetLastError());
+    tmp.release(run_begins);
+    tmp.release(run_sizes);
+    tmp.release(keys);
+    /* the k-mers of the heavy keys, keyed one by one: count, then emit. A launch of 2^32 threads or more is not carried
+       out (and reports no error), so the tuples are walked in pieces. */
+    const uint64_t per = idx.k - idx.m + 1;
+    const uint64_t tuples_per_launch = (uint64_t(1) << 30) / per;
+    auto heavy_pass = [&](bool emit, unsigned long long* cursor, uint64_t* item_keys, uint64_t* item_vals) {
+        for (uint64_t first = 0; first < T; first += tuples_per_launch) {
+            const uint64_t count = std::min(tuples_per_launch, T - first);
+            const dim3 pair_grid(uint32_t((count * per + 255) / 256));
+            if (wide && emit) hipLaunchKernelGGL((sk_heavy_kmers_kernel<2, true>), pair_grid, block, 0, 0, v, first, first + count, flags, occ, cursor, item_keys, item_vals);
+            else if (wide) hipLaunchKernelGGL((sk_heavy_kmers_kernel<2, false>), pair_grid, block, 0, 0, v, first, first + count, flags, occ, cursor, item_keys, item_vals);
+            else if (emit) hipLaunchKernelGGL((sk_heavy_kmers_kernel<1, true>), pair_grid, block, 0, 0, v, first, first + count, flags, occ, cursor, item_keys, item_vals);
+            else hipLaunchKernelGGL((sk_heavy_kmers_kernel<1, false>), pair_grid, block, 0, 0, v, first, first + count, flags, occ, cursor, item_keys, item_vals);
+            HIP_CHECK(hipGetLastError());
+        }
+    };
+    heavy_pass(false, stats + 6, nullptr, nullptr);
+    unsigned long long h_stats[8];
+    HIP_CHECK(hipMemcpy(h_stats, stats, 64, hipMemcpyDeviceToHost));
+    const uint64_t heavy_keys = h_stats[4], heavy_occurrences = h_stats[5], heavy_kmers = h_stats[6];
+    if (heavy_kmers >= (uint64_t(1) << 31)) return;
+    uint64_t* kmer_keys = tmp.alloc<uint64_t>(heavy_kmers);
+    uint64_t* kmer_vals = tmp.alloc<uint64_t>(heavy_kmers);
+    if (heavy_kmers) {
+        heavy_pass(true, stats + 7, kmer_keys, kmer_vals);
+        HIP_CHECK(hipMemcpy(h_stats, stats, 64, hipMemcpyDeviceToHost));
+        if (h_stats[7] != heavy_kmers) throw error(error_kind::hip, "super-k-mer table: the two passes over the heavy keys disagree");
+    }
+    /* slots asked for: one per occurrence of a light key, one marker per heavy key, one per k-mer of a heavy key */
+    const uint64_t wanted = (T - heavy_occurrences) + heavy_keys + heavy_kmers;
+    const uint64_t num_buckets = uint64_t(double(wanted) * slots_per_key / SK_BUCKET_SLOTS) + 8;
+    const uint64_t num_slots = num_buckets * SK_BUCKET_SLOTS;
+    const uint64_t slot_bytes = wide ? 64 : 32;
+    if (num_buckets >= (uint64_t(1) << 32)) return;
+    {
+        size_t free_bytes = 0, total_bytes = 0;
+        HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
+        if (num_slots * slot_bytes > free_bytes / 2) return;  // leave HBM for the caller's batches
+    }
     uint32_t* slots = tmp.alloc<uint32_t>(num_slots * slot_bytes / 4);
-    uint8_t* placed = tmp.alloc<uint8_t>(K);
-    unsigned long long* stats = tmp.alloc<unsigned long long>(4);
+    uint8_t* placed = tmp.alloc<uint8_t>(T + heavy_kmers);
     HIP_CHECK(hipMemset(slots, 0, num_slots * slot_bytes));
-    HIP_CHECK(hipMemset(placed, 0, K));
-    HIP_CHECK(hipMemset(stats, 0, 32));
+    HIP_CHECK(hipMemset(placed, 0, T + heavy_kmers));
     for (uint32_t choice = 0; choice < SK_CHOICES; ++choice) {
-        if (wide)
-            hipLaunchKernelGGL(sk_place_kernel<2>, dim3(uint32_t((K + 255) / 256)), block, 0, 0, v, choice, K, keys, run_sizes,
-                               run_begins, occ, slots, uint32_t(num_buckets), placed, stats);
-        else
-            hipLaunchKernelGGL(sk_place_kernel<1>, dim3(uint32_t((K + 255) / 256)), block, 0, 0, v, choice, K, keys, run_sizes,
-                               run_begins, occ, slots, uint32_t(num_buckets), placed, stats);
+        const dim3 g1(uint32_t((T + 255) / 256)), g2(uint32_t((heavy_kmers + 255) / 256));
+        if (wide) {
+            hipLaunchKernelGGL(sk_place_kernel<2>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(num_buckets), placed, stats);
+            if (heavy_kmers)
+                hipLaunchKernelGGL(sk_place_kernel<2>, g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, slots,
+                                   uint32_t(num_buckets), placed + T, stats);
+        } else {
+            hipLaunchKernelGGL(sk_place_kernel<1>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(num_buckets), placed, stats);
+            if (heavy_kmers)
+                hipLaunchKernelGGL(sk_place_kernel<1>, g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, slots,
+                                   uint32_t(num_buckets), placed + T, stats);
+        }
         HIP_CHECK(hipGetLastError());
     }
-    unsigned long long h_stats[4];
-    HIP_CHECK(hipMemcpy(h_stats, stats, 32, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(h_stats, stats, 64, hipMemcpyDeviceToHost));
     HIP_CHECK(hipDeviceSynchronize());
 
     tmp.keep(slots);
-    tmp.keep(occ);
     rep.allocations.push_back(slots);
-    rep.allocations.push_back(occ);
-    rep.bytes += num_slots * slot_bytes + T * 8;
+    rep.bytes += num_slots * slot_bytes;
     rep.sk_keys = K;
-    rep.sk_inline_keys = h_stats[0];
-    rep.sk_long_lists = h_stats[1];
+    rep.sk_heavy_keys = heavy_keys;
+    rep.sk_heavy_kmers = heavy_kmers;
     rep.sk_unplaced = h_stats[2];
+    rep.sk_slots_used = h_stats[3];
     v.sk.slots = slots;
-    v.sk.occ = occ;
     v.sk.num_buckets = uint32_t(num_buckets);
     v.sk.enabled = 1;
 }

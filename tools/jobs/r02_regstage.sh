@@ -1,0 +1,21 @@
+#!/bin/bash
+set -u
+cd "$(dirname "$0")/../.."
+OUT=gpurun_out/${1:-r02_regstage}
+mkdir -p $OUT
+export TMPDIR=/tmp
+for i in 1 2 3; do timeout 1500 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -3; done
+timeout 900 python tools/debug/table_mismatch.py 2>&1 | tail -4
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o c2 -- python bench.py --workload c2 --no-cpu-baseline --no-extra-mixes > $OUT/prof_c2.log 2>&1
+python3 - $OUT <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + '/prof/**/c2_kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'lookup' in r['Name']: print(r['Name'][:100], r['Calls'], r['AverageNs'])
+PY
+grep '"metric"' $OUT/prof_c2.log | cut -c1-250
+timeout 1500 python bench.py --no-cpu-baseline > $OUT/bench_c3.jsonl 2> $OUT/bench_c3.err; tail -3 $OUT/bench_c3.err | cut -c1-600; python3 - $OUT <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1] + '/bench_c3.jsonl').read().strip().splitlines()[-1])
+print('C3', r['value'], r['ms_per_step'], r['roofline']['frac'], r['config']['device_bytes_per_kmer'], json.dumps(r['other_mixes']))
+PY
