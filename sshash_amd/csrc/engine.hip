@@ -531,6 +531,19 @@ static result_view advance(result_view v, uint64_t at) {
     return v;
 }
 
+/* queries per launch sequence (first, resume, deferred): at most 2^27 (queue entries carry 27-bit indices) */
+static uint64_t launch_piece_queries() {
+    static const uint64_t piece = [] {
+        uint64_t v = uint64_t(1) << 27;
+        if (const char* e = std::getenv("SSHASH_AMD_PIECE")) {  // measurement knob
+            const uint64_t want = std::strtoull(e, nullptr, 10);
+            if (want >= 4096 && want <= (uint64_t(1) << 27)) v = want;
+        }
+        return v;
+    }();
+    return piece;
+}
+
 template <int W, bool CANON, int MODE, bool ASCII>
 static void launch(device_replica const* rep, void const* q, uint64_t n, bool check_rc,
                    result_view const& out, uint8_t* member, hipStream_t stream) {
@@ -544,7 +557,8 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
         if ((d.directory.enabled || d.sk.enabled) && !(MODE == int(out_mode::full) && out.minimizer_found)) {
             /* multi-pass: at most 2^27 queries per launch sequence (queue entries are 32-bit; the scratch
                queues stay below 1.3 GiB (2.1 for 128-bit k-mers)) */
-            const uint64_t pieces = (n + (uint64_t(1) << 27) - 1) >> 27;
+            const uint64_t piece_max = launch_piece_queries();
+            const uint64_t pieces = (n + piece_max - 1) / piece_max;
             const uint64_t piece = ((n + pieces - 1) / pieces + block - 1) / block * block;  // equal pieces, whole workgroups
             const size_t qbytes = size_t(W) * 8, kbytes = d.k;
             for (uint64_t at = 0; at < n; at += piece) {
