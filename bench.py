@@ -272,12 +272,11 @@ def main():
                     "algorithmic_bytes_rule": "SURVEY 8(d): 8 B per distinct 64-bit index word the REFERENCE algorithm dereferences "
                                               "+ query in + id out, counted by the instrumented oracle on this batch",
                     "avg_kernel_ms": round(avg_kernel_ms, 3)}
-        own = d.read_counts_device(local_rank, dq.data_ptr(), min(n, 10_000_000)) if hasattr(d, "read_counts_device") else None
-        if own:
-            own_bytes = own["bytes_per_lookup"]
-            roofline["own_useful_bytes_per_lookup"] = round(own_bytes, 2)
-            roofline["frac_own_useful_bytes"] = round(own_bytes * n / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-            roofline["own_reads_per_lookup"] = own["reads_per_lookup"]
+        if traffic:
+            # the kernels' own bytes: what the PMC passes of this very workload saw moving between L2 and HBM per step
+            # (64 B per bucket line -- both slots of a line are compared --, the query and id streams, the pass queues)
+            roofline["frac_hbm_traffic"] = round(traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            roofline["hbm_traffic_bytes_per_lookup"] = round(traffic / n, 2)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cores = effective_cores()

@@ -78,3 +78,44 @@ def test_effective_cores_is_positive():
     import bench
 
     assert bench.effective_cores() >= 1
+
+
+SPAWNED = textwrap.dedent(
+    """
+    import os, sys
+    import torch, torch.distributed as dist
+    dist.init_process_group(backend="gloo")   # RANK / WORLD_SIZE / MASTER_* come from torch.distributed.run
+    t = torch.tensor([dist.get_rank() + 1])
+    dist.all_reduce(t)
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1"
+    open(os.path.join(sys.argv[1], f"rank{dist.get_rank()}.{int(t)}.{' '.join(sys.argv[2:])}"), "w").close()
+    dist.destroy_process_group()
+    """
+)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` outside torch.distributed.run spawns the N ranks itself (bench.spawn_ranks): same
+    launcher, a stand-in script (no GPU here)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    script = tmp_path / "spawned.py"
+    script.write_text(SPAWNED)
+    env_before = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE")}
+    assert env_before == {"RANK": None, "WORLD_SIZE": None}
+    rc = bench.spawn_ranks(2, str(script), [str(tmp_path), "--gpus", "2"])
+    assert rc == 0
+    made = sorted(f for f in os.listdir(tmp_path) if f.startswith("rank"))
+    assert made == ["rank0.3.--gpus 2", "rank1.3.--gpus 2"]
+
+
+def test_strong_scaling_shares_cover_the_batch():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for total, world in ((1_000_000_000, 8), (100_000_007, 3), (5, 8)):
+        shares = [bench.split_batch(total, world, r) for r in range(world)]
+        assert shares[0][0] == 0 and shares[-1][1] == total
+        assert all(shares[r][1] == shares[r + 1][0] for r in range(world - 1))
+        assert max(hi - lo for lo, hi in shares) - min(hi - lo for lo, hi in shares) <= 1
