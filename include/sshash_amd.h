@@ -190,6 +190,21 @@ sshash_status sshash_streaming_query_device(const sshash_dict* d, int device, co
                                             const uint64_t* read_offsets, uint64_t num_reads, uint64_t* report,
                                             void* hip_stream);
 
+/* ---- streaming_query<Dict,canonical>::lookup for EVERY k-mer of every read (include/streaming_query.hpp:56-109),
+ *      batched: what the reference returns k-mer by k-mer while it streams a read. Every non-NULL array of `out` has one
+ *      entry per BASE of `bases` (total_bases = read_offsets[num_reads] entries): entry read_offsets[r] + j is the result
+ *      of the k-mer starting at base j of read r; entries of places where no k-mer starts (the last k-1 bases of a
+ *      read, reads shorter than k) are left untouched. A k-mer holding a character other than ACGTacgt gets the
+ *      default result the reference returns after its reset() (every u64 field SSHASH_INVALID_U64, orientation +1).
+ *      Results equal the point lookups' (the reference asserts exactly that, :107); minimizer_found is not produced
+ *      (SSHASH_ERR_ARGUMENT if asked for). `report` (may be NULL; device variant: 6 uint64 counters, accumulated into)
+ *      receives the same counters as sshash_streaming_query. ---- */
+sshash_status sshash_streaming_lookup_device(const sshash_dict* d, int device, const char* bases, const uint64_t* read_offsets,
+                                             uint64_t num_reads, uint64_t total_bases, const sshash_results* out, uint64_t* report,
+                                             void* hip_stream);
+sshash_status sshash_streaming_lookup(const sshash_dict* d, const char* bases, const uint64_t* read_offsets, uint64_t num_reads,
+                                      const sshash_results* out, sshash_streaming_report* report);
+
 /* ---- routing for a minimizer-sharded index: owner shard of the forward
  *      minimizer and of the reverse-complement minimizer of every query (equal for canonical
  *      dictionaries: the smaller-valued minimizer decides). Device pointers, asynchronous. ----------- */

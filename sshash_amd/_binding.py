@@ -138,6 +138,8 @@ def _load() -> C.CDLL:
         "sshash_to_device_table_shard": (C.c_int, [P, C.c_int, C.c_uint32, C.c_uint32]),
         "sshash_device_bytes": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64)]),
         "sshash_device_stats": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64 * 8)]),
+        "sshash_streaming_lookup_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, C.c_uint64, C.POINTER(_Results), P, P]),
+        "sshash_streaming_lookup": (C.c_int, [P, P, P, C.c_uint64, C.POINTER(_Results), C.POINTER(_Report)]),
         "sshash_lookup_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
         "sshash_lookup_ascii_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
         "sshash_lookup_packed": (C.c_int, [P, P, C.c_uint64, C.c_int, C.POINTER(_Results)]),
@@ -178,6 +180,7 @@ C_ABI_SYMBOLS = (
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
     "sshash_access_packed_device sshash_weight sshash_weight_device "
     "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device "
+    "sshash_streaming_lookup sshash_streaming_lookup_device "
     "sshash_route_packed_device sshash_route_bucket_device sshash_route_bucket_by_key_device sshash_route_combine_device"
 ).split()
 
@@ -522,6 +525,42 @@ class Dictionary:
         r = _Report()
         _check(_load().sshash_streaming_query(self._h, bases.ctypes.data, offsets.ctypes.data, len(chunks), C.byref(r)))
         return self._report(r)
+
+    def streaming_lookup(self, reads: Sequence[Union[str, bytes]], full: bool = False):
+        """streaming_query::lookup for every k-mer of every read (reference include/streaming_query.hpp:56-109), batched.
+        -> (list of LookupResult, one per read, len(read) - k + 1 entries each; StreamingQueryReport)."""
+        chunks = [s.encode("ascii", "replace") if isinstance(s, str) else bytes(s) for s in reads]
+        offsets = np.zeros(len(chunks) + 1, dtype=np.uint64)
+        if chunks:
+            offsets[1:] = np.cumsum([len(c) for c in chunks], dtype=np.uint64)
+        bases = np.frombuffer(b"".join(chunks) or b"\0", dtype=np.uint8)
+        total = max(int(offsets[-1]), 1)
+        arrays = {"kmer_id": np.full(total, INVALID_U64, dtype=np.uint64)}
+        if full:
+            for name in ("kmer_id_in_string", "kmer_offset", "string_id", "string_begin", "string_end"):
+                arrays[name] = np.full(total, INVALID_U64, dtype=np.uint64)
+            arrays["kmer_orientation"] = np.ones(total, dtype=np.int8)
+        r = _Results()
+        for name, a in arrays.items():
+            setattr(r, name, a.ctypes.data)
+        rep = _Report()
+        _check(_load().sshash_streaming_lookup(self._h, bases.ctypes.data, offsets.ctypes.data, len(chunks), C.byref(r), C.byref(rep)))
+        per_read = []
+        k = self.k()
+        for i, c in enumerate(chunks):
+            lo = int(offsets[i])
+            n = max(0, len(c) - k + 1)
+            per_read.append(LookupResult(**{name: a[lo:lo + n] for name, a in arrays.items()}))
+        return per_read, self._report(rep)
+
+    def streaming_lookup_device(self, device: int, d_bases: int, d_read_offsets: int, num_reads: int, total_bases: int,
+                                d_kmer_id: int, d_report: int = 0, stream: int = 0, **optional_outputs: int) -> None:
+        r = _Results()
+        r.kmer_id = d_kmer_id
+        for name, ptr in optional_outputs.items():
+            setattr(r, name, ptr)
+        _check(_load().sshash_streaming_lookup_device(self._h, int(device), C.c_void_p(d_bases), C.c_void_p(d_read_offsets),
+                                                      int(num_reads), int(total_bases), C.byref(r), C.c_void_p(d_report), C.c_void_p(stream)))
 
     def streaming_query_device(self, device: int, d_bases: int, d_read_offsets: int, num_reads: int, d_report: int,
                                stream: int = 0) -> None:

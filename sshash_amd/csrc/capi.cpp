@@ -351,6 +351,32 @@ sshash_status sshash_streaming_query_device(const sshash_dict* d, int device, co
     return guarded([&] { d->eng->streaming_query_device(device, bases, read_offsets, num_reads, 0, report, hip_stream); });
 }
 
+static void fill_report(sshash_streaming_report* report, streaming_report const& r) {
+    report->num_kmers = r.num_kmers;
+    report->num_positive_kmers = r.num_positive_kmers;
+    report->num_negative_kmers = r.num_negative_kmers;
+    report->num_invalid_kmers = r.num_invalid_kmers;
+    report->num_searches = r.num_searches;
+    report->num_extensions = r.num_extensions;
+}
+
+sshash_status sshash_streaming_lookup_device(const sshash_dict* d, int device, const char* bases, const uint64_t* read_offsets,
+                                             uint64_t num_reads, uint64_t total_bases, const sshash_results* out, uint64_t* report,
+                                             void* hip_stream) {
+    if (!d || !out || (num_reads && (!bases || !read_offsets))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->streaming_lookup_device(device, bases, read_offsets, num_reads, total_bases, to_view(out), report, hip_stream); });
+}
+
+sshash_status sshash_streaming_lookup(const sshash_dict* d, const char* bases, const uint64_t* read_offsets, uint64_t num_reads,
+                                      const sshash_results* out, sshash_streaming_report* report) {
+    if (!d || !out || (num_reads && (!bases || !read_offsets))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    if (report) std::memset(report, 0, sizeof(*report));
+    return guarded([&] {
+        const streaming_report r = d->eng->streaming_lookup_host(bases, read_offsets, num_reads, to_view(out));
+        if (report) fill_report(report, r);
+    });
+}
+
 sshash_status sshash_route_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
                                          uint32_t num_shards, uint32_t* owner_forward, uint32_t* owner_reverse,
                                          void* hip_stream) {

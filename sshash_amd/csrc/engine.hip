@@ -314,9 +314,11 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
 template <int W, bool CANON, int MODE, bool ASCII>
 __global__ void __launch_bounds__(256)
 lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const void* __restrict__ queries,
-              const uint64_t n, const bool check_rc, const result_view out, uint8_t* __restrict__ member) {
+              const uint64_t n, const bool check_rc, const result_view out, uint8_t* __restrict__ member,
+              const uint8_t* __restrict__ lane_valid) {
     const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
     for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (lane_valid && !(lane_valid[i] & 1)) continue;  // no query in this place (streaming lookup)
         kmer_w<W> x;
         if constexpr (ASCII) {
             x = kmer_from_ascii<W>(static_cast<const char*>(queries) + i * d.k, d.k);
@@ -372,13 +374,14 @@ __device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries
 template <int W, bool CANON, int MODE, bool ASCII, bool SK>
 __global__ void __launch_bounds__(256)
 fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const uint64_t n, const bool check_rc,
-                   const result_view out, uint8_t* __restrict__ member, const pass_queues q) {
+                   const result_view out, uint8_t* __restrict__ member, const pass_queues q,
+                   const uint8_t* __restrict__ lane_valid /* null, or bit 0 of entry i: place i holds a query */) {
     /* LDS: the ASCII tile (256 * k characters) and, afterwards, the staged bucket lines (64 * W bytes per lane) */
     constexpr uint32_t TILE_WORDS = ASCII ? 64 * (W == 1 ? 31 : 63) + 8 : 0;
     constexpr uint32_t STAGE_WORDS = SK ? 256 * 16 * W : 0;
     __shared__ uint4 lds[(TILE_WORDS > STAGE_WORDS ? TILE_WORDS : STAGE_WORDS) / 4 + 1];
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    const bool active = i < n;
+    const bool active = i < n && (!lane_valid || (lane_valid[i] & 1));
     kmer_w<W> x = kmer_zero<W>();
     if constexpr (ASCII) {
         /* util::string_to_uint_kmer (include/util.hpp:207-213) for a whole workgroup: the 256*k
@@ -546,7 +549,7 @@ static uint64_t launch_piece_queries() {
 
 template <int W, bool CANON, int MODE, bool ASCII>
 static void launch(device_replica const* rep, void const* q, uint64_t n, bool check_rc,
-                   result_view const& out, uint8_t* member, hipStream_t stream) {
+                   result_view const& out, uint8_t* member, hipStream_t stream, uint8_t const* lane_valid) {
     dict_view const& d = rep->view;
     skew_part_dev const* skew = rep->d_skew;
     const uint32_t block = 256;
@@ -582,12 +585,12 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 uint8_t* mem = member ? member + at : nullptr;
                 if (d.sk.enabled) {
                     hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII, true>), dim3(nblocks), dim3(block), 0, stream, d, qa,
-                                       m, check_rc, ids, mem, pq);
+                                       m, check_rc, ids, mem, pq, lane_valid ? lane_valid + at : nullptr);
                     hipLaunchKernelGGL((resume_lookup_kernel<W, CANON, MODE>), dim3(DEFER_SHARDS * RESUME_PARTS), dim3(block), 0, stream, d,
                                        check_rc, ids, mem, pq);
                 } else {
                     hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII, false>), dim3(nblocks), dim3(block), 0, stream, d, qa,
-                                       m, check_rc, ids, mem, pq);
+                                       m, check_rc, ids, mem, pq, lane_valid ? lane_valid + at : nullptr);
                 }
                 hipLaunchKernelGGL((deferred_lookup_kernel<W, CANON, MODE, ASCII>), dim3(DEFER_SHARDS * DEFER_BLOCKS_PER_SHARD), dim3(block), 0, stream, d,
                                    skew, qa, check_rc, ids, mem, pq);
@@ -599,30 +602,31 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
     uint64_t blocks = (n + block - 1) / block;
     if (blocks > (uint64_t(1) << 22)) blocks = uint64_t(1) << 22;  // grid-stride beyond 2^30 queries
     hipLaunchKernelGGL((lookup_kernel<W, CANON, MODE, ASCII>), dim3(uint32_t(blocks)), dim3(block), 0, stream, d, skew,
-                       q, n, check_rc, out, member);
+                       q, n, check_rc, out, member, lane_valid);
     HIP_CHECK(hipGetLastError());
 }
 
 template <int W, bool CANON, bool ASCII>
 static void launch_mode(out_mode mode, device_replica const* rep, void const* q, uint64_t n,
-                        bool check_rc, result_view const& out, uint8_t* member, hipStream_t s) {
+                        bool check_rc, result_view const& out, uint8_t* member, hipStream_t s, uint8_t const* lane_valid) {
     switch (mode) {
-        case out_mode::ids: launch<W, CANON, 0, ASCII>(rep, q, n, check_rc, out, member, s); break;
-        case out_mode::full: launch<W, CANON, 1, ASCII>(rep, q, n, check_rc, out, member, s); break;
-        case out_mode::member: launch<W, CANON, 2, ASCII>(rep, q, n, check_rc, out, member, s); break;
+        case out_mode::ids: launch<W, CANON, 0, ASCII>(rep, q, n, check_rc, out, member, s, lane_valid); break;
+        case out_mode::full: launch<W, CANON, 1, ASCII>(rep, q, n, check_rc, out, member, s, lane_valid); break;
+        case out_mode::member: launch<W, CANON, 2, ASCII>(rep, q, n, check_rc, out, member, s, lane_valid); break;
     }
 }
 
 template <bool ASCII>
 static void launch_any(out_mode mode, device_replica const* rep, void const* q, uint64_t n,
-                       bool check_rc, result_view const& out, uint8_t* member, hipStream_t s) {
+                       bool check_rc, result_view const& out, uint8_t* member, hipStream_t s, uint8_t const* lane_valid = nullptr) {
     dict_view const& d = rep->view;
     const bool wide = d.k > 31;
-    if (!wide && !d.canonical) launch_mode<1, false, ASCII>(mode, rep, q, n, check_rc, out, member, s);
-    else if (!wide && d.canonical) launch_mode<1, true, ASCII>(mode, rep, q, n, check_rc, out, member, s);
-    else if (wide && !d.canonical) launch_mode<2, false, ASCII>(mode, rep, q, n, check_rc, out, member, s);
-    else launch_mode<2, true, ASCII>(mode, rep, q, n, check_rc, out, member, s);
+    if (!wide && !d.canonical) launch_mode<1, false, ASCII>(mode, rep, q, n, check_rc, out, member, s, lane_valid);
+    else if (!wide && d.canonical) launch_mode<1, true, ASCII>(mode, rep, q, n, check_rc, out, member, s, lane_valid);
+    else if (wide && !d.canonical) launch_mode<2, false, ASCII>(mode, rep, q, n, check_rc, out, member, s, lane_valid);
+    else launch_mode<2, true, ASCII>(mode, rep, q, n, check_rc, out, member, s, lane_valid);
 }
+
 
 static void check_outputs(out_mode mode, result_view const& out, uint8_t* member) {
     if (mode == out_mode::member) {
@@ -630,6 +634,15 @@ static void check_outputs(out_mode mode, result_view const& out, uint8_t* member
     } else if (!out.kmer_id) {
         throw error(error_kind::argument, "kmer_id output pointer is null");
     }
+}
+
+void engine::lookup_packed_masked_device(int device, uint64_t const* d_kmers, uint8_t const* d_lane_valid, uint64_t n, bool check_rc,
+                                         out_mode mode, result_view const& d_out, void* stream) const {
+    device_replica const* rep = replica(device);
+    check_outputs(mode, d_out, nullptr);
+    if (n == 0) return;
+    device_guard guard(device);
+    launch_any<false>(mode, rep, d_kmers, n, check_rc, d_out, nullptr, hipStream_t(stream), d_lane_valid);
 }
 
 void engine::lookup_packed_device(int device, uint64_t const* d_kmers, uint64_t n, bool check_rc, out_mode mode,

@@ -74,6 +74,11 @@ public:
     void route_combine_device(int device, uint64_t const* d_replies, uint32_t const* d_slots, uint64_t m, uint64_t* d_out,
                               void* stream) const;
 
+    /* lookup_packed_device over the places i with bit 0 of d_lane_valid[i] set; the outputs of the other places are
+       left untouched (the position-parallel streaming lookup, streaming.hip) */
+    void lookup_packed_masked_device(int device, uint64_t const* d_kmers, uint8_t const* d_lane_valid, uint64_t n, bool check_rc,
+                                     out_mode mode, result_view const& d_out, void* stream) const;
+
     /* Host-buffer entry points: shard the batch over every replica, stream chunks through
        pinned staging buffers, results land in the caller's arrays. */
     void lookup_packed_host(uint64_t const* h_kmers, uint64_t n, bool check_rc, out_mode mode,
@@ -87,6 +92,15 @@ public:
     /* Device buffers, asynchronous; `d_report` receives 6 u64 counters (accumulated). */
     void streaming_query_device(int device, char const* d_bases, uint64_t const* d_read_offsets, uint64_t n_reads,
                                 uint64_t total_bases, uint64_t* d_report, void* stream) const;
+
+    /* Per-k-mer results of the streaming query (streaming_query::lookup for every k-mer of every read,
+       include/streaming_query.hpp:56-109): entry read_offsets[r] + j of every non-null array of `d_out` = the k-mer
+       starting at base j of read r; places where no k-mer starts are left untouched. `d_report` (nullable): the six
+       counters, accumulated. Device buffers, asynchronous. */
+    void streaming_lookup_device(int device, char const* d_bases, uint64_t const* d_read_offsets, uint64_t n_reads,
+                                 uint64_t total_bases, result_view const& d_out, uint64_t* d_report, void* stream) const;
+    streaming_report streaming_lookup_host(char const* bases, uint64_t const* read_offsets, uint64_t n_reads,
+                                           result_view const& h_out) const;
 
     /* the replica resident on `device` (throws when there is none); internal to the .hip files */
     device_replica const* replica(int device) const;

@@ -202,6 +202,300 @@ void engine::streaming_query_device(int device, char const* d_bases, uint64_t co
     if (prev != device) HIP_CHECK(hipSetDevice(prev));
 }
 
+/* ---- per-k-mer results: the streaming query as a position-parallel pipeline -----------------------------------
+   The reference asserts, for every k-mer, that its streaming result equals the point lookup
+   (include/streaming_query.hpp:107); what the state machine adds is bookkeeping: a k-mer is invalid iff one of its k
+   characters is (:59-65: an invalid one resets to full validation), a positive k-mer is an *extension* iff the
+   previous k-mer of the read was positive, in the same string, and the id moved by that k-mer's orientation (:86-100;
+   `remaining_string_bases > 0` is "same string"), otherwise a *search*; everything else is negative. So:
+     1. encode    one lane per base of the reads: which read it lies in (a tile of 256 positions resolves its reads
+                  through LDS), whether a k-mer starts there, its validity, the packed k-mer (characters staged in
+                  LDS, four packed at a time);
+     2. lookup    the batched lookup over all places holding a valid k-mer (engine.hip: first / resume / deferred
+                  passes) -- every k-mer at full lookup speed, no serial chain along a read, long reads cost nothing
+                  special;
+     3. classify  one lane per k-mer: counters, and the default result for invalid k-mers. */
+constexpr uint8_t SQ_VALID = 1, SQ_INVALID = 2, SQ_FIRST = 4;  // flags of a place; 0 = no k-mer starts here
+
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t v) {  // 0x80 in every byte of v that is not zero
+    return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256)
+stream_encode_kernel(const char* __restrict__ bases, const uint64_t* __restrict__ offsets, const uint64_t n_reads,
+                     const uint64_t total_bases, const uint64_t first, const uint64_t count, const uint32_t k,
+                     uint64_t* __restrict__ kmers /* relative to `first` */, uint8_t* __restrict__ flags /* absolute */) {
+    constexpr uint32_t TILE = 256, SPAN = TILE + 64;
+    __shared__ uint32_t chars[SPAN / 4 + 2];
+    __shared__ uint64_t ends[TILE + 2];  // offsets[r0 + 1 ...]: the read boundaries that may fall into the tile
+    __shared__ uint64_t r0_shared;
+    const uint64_t g0 = first + uint64_t(blockIdx.x) * TILE;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {  // the read holding the tile's first base: largest r with offsets[r] <= g0
+        uint64_t lo = 0, hi = n_reads - 1;
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo + 1) / 2;
+            if (offsets[mid] <= g0) lo = mid;
+            else hi = mid - 1;
+        }
+        r0_shared = lo;
+    }
+    /* the characters of the tile and the k - 1 after it */
+    for (uint32_t c = tid; c < SPAN / 4 + 2; c += TILE) {
+        const uint64_t at = g0 + 4 * uint64_t(c);
+        uint32_t v = 0;
+        if (at + 4 <= total_bases && ((reinterpret_cast<uintptr_t>(bases) + at) & 3) == 0) v = *reinterpret_cast<const uint32_t*>(bases + at);
+        else
+            for (uint32_t b = 0; b < 4; ++b)
+                if (at + b < total_bases) v |= uint32_t(uint8_t(bases[at + b])) << (8 * b);
+        chars[c] = v;
+    }
+    __syncthreads();
+    const uint64_t r0 = r0_shared;
+    for (uint32_t c = tid; c < TILE + 2; c += TILE) ends[c] = r0 + 1 + c <= n_reads ? offsets[r0 + 1 + c] : ~uint64_t(0);
+    __syncthreads();
+    const uint64_t p = g0 + tid;
+    if (tid >= count - uint64_t(blockIdx.x) * TILE || p >= total_bases) return;
+    /* my read: r0 + the number of boundaries ends[.] <= p */
+    uint32_t lo = 0, hi = TILE + 1;  // first index with ends[index] > p
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (ends[mid] <= p) lo = mid + 1;
+        else hi = mid;
+    }
+    uint64_t begin, end;
+    if (lo <= TILE) {
+        end = ends[lo];
+        begin = lo ? ends[lo - 1] : offsets[r0];
+    } else {  // more than TILE reads begin inside the tile (empty reads): resolve this place on its own
+        uint64_t a = r0, b = n_reads - 1;
+        while (a < b) {
+            const uint64_t mid = a + (b - a + 1) / 2;
+            if (offsets[mid] <= p) a = mid;
+            else b = mid - 1;
+        }
+        begin = offsets[a];
+        end = offsets[a + 1];
+    }
+    uint8_t f = 0;
+    kmer_w<W> x = kmer_zero<W>();
+    if (p + k <= end) {
+        bool valid = true;
+        const uint32_t w0 = tid >> 2, sh = tid & 3;
+        for (uint32_t j = 0; 4 * j < k; ++j) {
+            const uint32_t four = __builtin_amdgcn_alignbyte(chars[w0 + j + 1], chars[w0 + j], sh);
+            const uint32_t rem = k - 4 * j;
+            /* A C G T a c g t only (include/kmer.hpp:209-219): fold the case, every byte must be one of the four */
+            const uint32_t u = four & 0xDFDFDFDFu;
+            uint32_t bad = nonzero_bytes(u ^ 0x41414141u) & nonzero_bytes(u ^ 0x43434343u) & nonzero_bytes(u ^ 0x47474747u) &
+                           nonzero_bytes(u ^ 0x54545454u);
+            if (rem < 4) bad &= (1u << (8 * rem)) - 1;
+            valid = valid && bad == 0;
+            uint32_t c = (four >> 1) & 0x03030303u;  // (c >> 1) & 3 for four characters at once
+            c = (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xFFu;
+            if (rem < 4) c &= (1u << (2 * rem)) - 1;
+            if (8 * j < 64) x.w[0] |= uint64_t(c) << (8 * j);
+            else if constexpr (W == 2) x.w[1] |= uint64_t(c) << (8 * j - 64);
+        }
+        f = (valid ? SQ_VALID : SQ_INVALID) | (p == begin ? SQ_FIRST : 0);
+    }
+    flags[p] = f;
+    for (int j = 0; j < W; ++j) kmers[(p - first) * W + j] = x.w[j];
+}
+
+__global__ void __launch_bounds__(256)
+stream_classify_kernel(const uint8_t* __restrict__ flags, const uint64_t total_bases, const result_view out,
+                       const uint64_t* __restrict__ string_id, const int8_t* __restrict__ orientation, uint64_t* __restrict__ report) {
+    const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    uint64_t c_kmer = 0, c_invalid = 0, c_negative = 0, c_search = 0, c_extension = 0;
+    const uint8_t f = p < total_bases ? flags[p] : 0;
+    if (f & SQ_INVALID) {
+        /* what streaming_query::lookup returns after its reset(): a default lookup_result (include/util.hpp:38-62) */
+        c_kmer = c_invalid = 1;
+        out.kmer_id[p] = INVALID_U64;
+        if (out.kmer_id_in_string) out.kmer_id_in_string[p] = INVALID_U64;
+        if (out.kmer_offset) out.kmer_offset[p] = INVALID_U64;
+        if (out.string_id) out.string_id[p] = INVALID_U64;
+        if (out.string_begin) out.string_begin[p] = INVALID_U64;
+        if (out.string_end) out.string_end[p] = INVALID_U64;
+        if (out.kmer_orientation) out.kmer_orientation[p] = 1;
+    } else if (f & SQ_VALID) {
+        c_kmer = 1;
+        const uint64_t id = out.kmer_id[p];
+        if (id == INVALID_U64) {
+            c_negative = 1;
+        } else {
+            bool extension = false;
+            if (!(f & SQ_FIRST) && (flags[p - 1] & SQ_VALID)) {
+                const uint64_t before = out.kmer_id[p - 1];
+                extension = before != INVALID_U64 && string_id[p - 1] == string_id[p] &&
+                            id == before + uint64_t(int64_t(orientation[p - 1]));
+            }
+            c_extension = extension;
+            c_search = !extension;
+        }
+    }
+    if (!report) return;
+    c_kmer = wave_sum(c_kmer);
+    c_invalid = wave_sum(c_invalid);
+    c_negative = wave_sum(c_negative);
+    c_search = wave_sum(c_search);
+    c_extension = wave_sum(c_extension);
+    if ((threadIdx.x & 63) == 0 && c_kmer) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 0), (unsigned long long)c_kmer);
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 1), (unsigned long long)(c_search + c_extension));
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 2), (unsigned long long)c_negative);
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 3), (unsigned long long)c_invalid);
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 4), (unsigned long long)c_search);
+        atomicAdd(reinterpret_cast<unsigned long long*>(report + 5), (unsigned long long)c_extension);
+    }
+}
+
+void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t const* d_read_offsets, uint64_t n_reads,
+                                     uint64_t total_bases, result_view const& d_out, uint64_t* d_report, void* stream) const {
+    device_replica const* rep = replica(device);
+    if (!d_out.kmer_id) throw error(error_kind::argument, "kmer_id output pointer is null");
+    if (d_out.minimizer_found) throw error(error_kind::argument, "the streaming lookup does not report minimizer_found");
+    if (n_reads == 0 || total_bases == 0) return;
+    device_guard guard(device);
+    hipStream_t s = hipStream_t(stream);
+    dict_view const& d = rep->view;
+    const uint32_t W = d.k <= 31 ? 1 : 2;
+    const uint64_t chunk = std::min<uint64_t>(total_bases, uint64_t(1) << 27);
+    uint8_t* flags = nullptr;
+    uint64_t* kmers = nullptr;
+    uint64_t* sid = d_out.string_id;
+    int8_t* ori = d_out.kmer_orientation;
+    HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&flags), total_bases, s));
+    HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&kmers), chunk * W * sizeof(uint64_t), s));
+    if (!sid) HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&sid), total_bases * sizeof(uint64_t), s));
+    if (!ori) HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&ori), total_bases, s));
+    result_view all = d_out;
+    all.string_id = sid;
+    all.kmer_orientation = ori;
+    for (uint64_t first = 0; first < total_bases; first += chunk) {
+        const uint64_t count = std::min(chunk, total_bases - first);
+        const dim3 grid(uint32_t((count + 255) / 256)), block(256);
+        if (W == 1) hipLaunchKernelGGL(stream_encode_kernel<1>, grid, block, 0, s, d_bases, d_read_offsets, n_reads, total_bases, first, count, d.k, kmers, flags);
+        else hipLaunchKernelGGL(stream_encode_kernel<2>, grid, block, 0, s, d_bases, d_read_offsets, n_reads, total_bases, first, count, d.k, kmers, flags);
+        HIP_CHECK(hipGetLastError());
+        result_view part = all;
+        part.kmer_id += first;
+        if (part.kmer_id_in_string) part.kmer_id_in_string += first;
+        if (part.kmer_offset) part.kmer_offset += first;
+        part.string_id += first;
+        if (part.string_begin) part.string_begin += first;
+        if (part.string_end) part.string_end += first;
+        part.kmer_orientation += first;
+        lookup_packed_masked_device(device, kmers, flags + first, count, true, out_mode::full, part, s);
+    }
+    for (uint64_t first = 0; first < total_bases; first += uint64_t(1) << 30) {
+        const uint64_t count = std::min<uint64_t>(uint64_t(1) << 30, total_bases - first);
+        result_view part = d_out;
+        part.kmer_id += first;
+        if (part.kmer_id_in_string) part.kmer_id_in_string += first;
+        if (part.kmer_offset) part.kmer_offset += first;
+        if (part.string_id) part.string_id += first;
+        if (part.string_begin) part.string_begin += first;
+        if (part.string_end) part.string_end += first;
+        if (part.kmer_orientation) part.kmer_orientation += first;
+        hipLaunchKernelGGL(stream_classify_kernel, dim3(uint32_t((count + 255) / 256)), dim3(256), 0, s, flags + first, count, part,
+                           sid + first, ori + first, d_report);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (!d_out.kmer_orientation) HIP_CHECK(hipFreeAsync(ori, s));
+    if (!d_out.string_id) HIP_CHECK(hipFreeAsync(sid, s));
+    HIP_CHECK(hipFreeAsync(kmers, s));
+    HIP_CHECK(hipFreeAsync(flags, s));
+}
+
+/* Host buffers: pieces of whole reads (at most ~64 MiB of bases each) go through one stream: H2D, the device pipeline
+   above, D2H of the arrays the caller asked for. */
+streaming_report engine::streaming_lookup_host(char const* bases, uint64_t const* read_offsets, uint64_t n_reads,
+                                               result_view const& h_out) const {
+    streaming_report total;
+    if (n_reads == 0) return total;
+    if (!h_out.kmer_id) throw error(error_kind::argument, "kmer_id output pointer is null");
+    const std::vector<int> devs = devices();
+    if (devs.empty()) throw error(error_kind::no_device, "dictionary is not resident on any device (call sshash_to_device first)");
+    const int device = devs[0];
+    device_guard guard(device);
+    const uint64_t piece_bases = uint64_t(64) << 20;
+    hipStream_t s = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct buffers {
+        std::vector<void*> dev;
+        hipStream_t s;
+        ~buffers() {
+            for (void* p : dev) (void)hipFree(p);
+            (void)hipStreamDestroy(s);
+        }
+    } own{{}, s};
+    auto dmalloc = [&](uint64_t bytes) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, std::max<uint64_t>(bytes, 8)));
+        own.dev.push_back(p);
+        return p;
+    };
+    uint64_t max_bases = 0, max_reads = 0;
+    std::vector<uint64_t> cuts{0};
+    for (uint64_t at = 0; at < n_reads;) {
+        uint64_t end = at + 1;
+        while (end < n_reads && read_offsets[end + 1] - read_offsets[at] <= piece_bases) ++end;
+        max_bases = std::max(max_bases, read_offsets[end] - read_offsets[at]);
+        max_reads = std::max(max_reads, end - at);
+        cuts.push_back(end);
+        at = end;
+    }
+    char* d_bases = static_cast<char*>(dmalloc(max_bases + 8));
+    uint64_t* d_offsets = static_cast<uint64_t*>(dmalloc((max_reads + 1) * 8));
+    uint64_t* d_report = static_cast<uint64_t*>(dmalloc(6 * 8));
+    HIP_CHECK(hipMemsetAsync(d_report, 0, 48, s));
+    result_view d_out{};
+    d_out.kmer_id = static_cast<uint64_t*>(dmalloc(max_bases * 8));
+    if (h_out.kmer_id_in_string) d_out.kmer_id_in_string = static_cast<uint64_t*>(dmalloc(max_bases * 8));
+    if (h_out.kmer_offset) d_out.kmer_offset = static_cast<uint64_t*>(dmalloc(max_bases * 8));
+    if (h_out.string_id) d_out.string_id = static_cast<uint64_t*>(dmalloc(max_bases * 8));
+    if (h_out.string_begin) d_out.string_begin = static_cast<uint64_t*>(dmalloc(max_bases * 8));
+    if (h_out.string_end) d_out.string_end = static_cast<uint64_t*>(dmalloc(max_bases * 8));
+    if (h_out.kmer_orientation) d_out.kmer_orientation = static_cast<int8_t*>(dmalloc(max_bases));
+    if (h_out.minimizer_found) throw error(error_kind::argument, "the streaming lookup does not report minimizer_found");
+    std::vector<uint64_t> rel(max_reads + 1);
+    for (size_t piece = 0; piece + 1 < cuts.size(); ++piece) {
+        const uint64_t first = cuts[piece], last = cuts[piece + 1];
+        const uint64_t b0 = read_offsets[first], nb = read_offsets[last] - b0;
+        if (nb == 0) continue;
+        for (uint64_t i = first; i <= last; ++i) rel[i - first] = read_offsets[i] - b0;
+        HIP_CHECK(hipMemcpyAsync(d_offsets, rel.data(), (last - first + 1) * 8, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(d_bases, bases + b0, nb, hipMemcpyHostToDevice, s));
+        /* places without a k-mer keep what the caller's arrays hold: seed the device arrays with it */
+        HIP_CHECK(hipMemcpyAsync(d_out.kmer_id, h_out.kmer_id + b0, nb * 8, hipMemcpyHostToDevice, s));
+        streaming_lookup_device(device, d_bases, d_offsets, last - first, nb, d_out, d_report, s);
+        HIP_CHECK(hipMemcpyAsync(h_out.kmer_id + b0, d_out.kmer_id, nb * 8, hipMemcpyDeviceToHost, s));
+        auto back = [&](auto* h, auto* dptr, uint64_t width) {
+            if (h) HIP_CHECK(hipMemcpyAsync(h + b0, dptr, nb * width, hipMemcpyDeviceToHost, s));
+        };
+        back(h_out.kmer_id_in_string, d_out.kmer_id_in_string, 8);
+        back(h_out.kmer_offset, d_out.kmer_offset, 8);
+        back(h_out.string_id, d_out.string_id, 8);
+        back(h_out.string_begin, d_out.string_begin, 8);
+        back(h_out.string_end, d_out.string_end, 8);
+        back(h_out.kmer_orientation, d_out.kmer_orientation, 1);
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+    uint64_t h[6];
+    HIP_CHECK(hipMemcpyAsync(h, d_report, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    total.num_kmers = h[0];
+    total.num_positive_kmers = h[1];
+    total.num_negative_kmers = h[2];
+    total.num_invalid_kmers = h[3];
+    total.num_searches = h[4];
+    total.num_extensions = h[5];
+    return total;
+}
+
 /* Host buffers: the reads are cut into pieces of at most ~32 MiB of bases; per replica up to eight lanes (the
    pooled pinned pipelines of the lookup host path, replica.hpp) pull pieces from a shared counter and run
    copy-in -> H2D -> kernel, accumulating the six counters in device memory; one read-back per lane. */

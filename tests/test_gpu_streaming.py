@@ -110,3 +110,63 @@ def test_multiline_fasta_and_unsupported_extension(case_skew_regular, tmp_path):
     q.write_text("ACGT\n")
     rep = _as_dict(d.streaming_query_from_file(str(q)))
     assert rep == {k: 0 for k in rep}  # "unsupported query file format": empty report (src/query.cpp:169-171)
+
+
+# ---- per-k-mer results: streaming_query::lookup for every k-mer (include/streaming_query.hpp:56-109) ----------------
+
+FIELDS = ("kmer_id", "kmer_id_in_string", "string_id", "string_begin", "string_end", "kmer_orientation")  # what
+# equal_lookup_result compares (include/util.hpp:107-141)
+
+
+@pytest.mark.parametrize("case_name", ["case_se_regular", "case_se_canonical", "case_skew_regular", "case_skew_canonical",
+                                       "case_k63_canonical", "case_k63_regular", "case_small_k"])
+def test_streaming_lookup_returns_what_the_reference_returns_kmer_by_kmer(case_name, request):
+    """Every k-mer of every read: the result streaming_query::lookup hands back (oracle_streaming_read: the restated state
+    machine), the counters of the report, and -- the reference's own assertion, :107 -- the point lookup."""
+    case = request.getfixturevalue(case_name)
+    d = case.dict.to_device(0)
+    reads = _synthetic_reads(case, 400, seed=23)
+    # a long read: several strings back to back with junk in between (one lane per read would crawl along it)
+    rng = np.random.default_rng(5)
+    reads.append("NN".join(case.sequences[i] for i in rng.integers(0, len(case.sequences), 40)))
+    per_read, report = d.streaming_lookup(reads, full=True)
+    assert _as_dict(report) == case.oracle.streaming_query(reads) == _as_dict(d.streaming_query(reads))
+    assert len(per_read) == len(reads)
+    for r, got in zip(reads, per_read):
+        want = case.oracle.streaming_read(r)
+        assert got.kmer_id.size == want.size == max(0, len(r) - case.k + 1)
+        found = want["kmer_id"] != np.uint64(0xFFFFFFFFFFFFFFFF)
+        for f in FIELDS:
+            g = getattr(got, f)
+            if f == "kmer_orientation":  # compared for found k-mers only (include/util.hpp:122-127)
+                assert (g[found] == want[f][found]).all(), f
+            else:
+                assert (g == want[f]).all(), f
+
+
+def test_streaming_lookup_device_leaves_other_places_untouched(case_se_regular):
+    import torch
+
+    case = case_se_regular
+    d = case.dict.to_device(0)
+    k = case.k
+    reads = [case.sequences[0][:200], "ACGT", case.sequences[1][:k], case.sequences[2][:k + 7].lower()]
+    blob = "".join(reads).encode()
+    offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(r) for r in reads])
+    dev = torch.device("cuda", 0)
+    d_bases = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    ids = torch.full((len(blob),), 12345, dtype=torch.int64, device=dev)
+    rep = torch.zeros(6, dtype=torch.int64, device=dev)
+    d.streaming_lookup_device(0, d_bases.data_ptr(), d_off.data_ptr(), len(reads), len(blob), ids.data_ptr(), d_report=rep.data_ptr())
+    torch.cuda.synchronize()
+    got = ids.cpu().numpy()
+    expect_kmers = 0
+    for i, r in enumerate(reads):
+        lo, n = int(offsets[i]), max(0, len(r) - k + 1)
+        expect_kmers += n
+        want = case.oracle.streaming_read(r)["kmer_id"].view(np.int64)
+        assert (got[lo:lo + n] == want).all()
+        assert (got[lo + n:int(offsets[i + 1])] == 12345).all()  # no k-mer starts there
+    assert int(rep[0].item()) == expect_kmers and int(rep[1].item()) == expect_kmers  # all positive
