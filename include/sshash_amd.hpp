@@ -5,9 +5,12 @@
 // include/util.hpp:191-195, src/query.cpp:128), "not found" == constants::invalid_uint64.
 //
 // Additions over the reference interface are the batched overloads (the GPU engine wants
-// batches) and `to_device`. Everything else is a one-element batch.
+// batches) and `to_device`. Everything else is a one-element batch. `streaming_query` below mirrors
+// reference include/streaming_query.hpp (one k-mer per call, the reference's shape) and adds the batched
+// lookup_read().
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -43,6 +46,16 @@ struct build_configuration {  // reference include/util.hpp:143-159
     uint64_t k = 31, m = 20, seed = 1, num_threads = 1;
     double lambda = 5.0;
     bool canonical = false, verbose = false;
+};
+
+/* the `Kmer` of the reference's typed overloads lookup(Kmer, bool) / is_member(Kmer, bool) (include/dictionary.hpp:42,76):
+   a 2-bit packed k-mer, first base in the least-significant bits (include/kmer.hpp:80,194) -- one word for k <= 31,
+   two for k <= 63 (the reference's uint64_t / __uint128_t kmer_t) */
+struct uint_kmer_t {
+    uint64_t bits[2] = {0, 0};
+    uint_kmer_t() = default;
+    uint_kmer_t(uint64_t lo) : bits{lo, 0} {}
+    uint_kmer_t(unsigned __int128 v) : bits{uint64_t(v), uint64_t(v >> 64)} {}
 };
 
 /* struct-of-arrays batch result */
@@ -109,6 +122,9 @@ public:
     /* Lookup queries -- include/dictionary.hpp:40-42 */
     lookup_result lookup(char const* string_kmer, bool check_reverse_complement = true) const {
         return lookup_batch(string_kmer, 1, check_reverse_complement)[0];
+    }
+    lookup_result lookup(uint_kmer_t uint_kmer, bool check_reverse_complement = true) const {
+        return lookup_batch(uint_kmer.bits, 1, check_reverse_complement)[0];
     }
     lookup_result lookup_packed(uint64_t const* uint_kmer_words, bool check_reverse_complement = true) const {
         return lookup_batch(uint_kmer_words, 1, check_reverse_complement)[0];
@@ -178,6 +194,11 @@ public:
         check(sshash_is_member_ascii(m_h, string_kmer, 1, check_reverse_complement, &out));
         return out != 0;
     }
+    bool is_member(uint_kmer_t uint_kmer, bool check_reverse_complement = true) const {
+        uint8_t out = 0;
+        check(sshash_is_member_packed(m_h, uint_kmer.bits, 1, check_reverse_complement, &out));
+        return out != 0;
+    }
     std::vector<uint8_t> is_member_batch(char const* kmers, uint64_t n, bool check_reverse_complement = true) const {
         std::vector<uint8_t> out(n);
         check(sshash_is_member_ascii(m_h, kmers, n, check_reverse_complement, out.data()));
@@ -191,6 +212,34 @@ public:
     streaming_query_report streaming_query_from_file(std::string const& filename, bool multiline) const {
         sshash_streaming_report s;
         check(sshash_streaming_query_from_file(m_h, filename.c_str(), multiline, &s));
+        return to_report(s);
+    }
+
+    /* streaming_query::lookup for every k-mer of every read, batched (sshash_streaming_lookup): `r` gets one entry per
+       base of `bases` -- entry read_offsets[i] + j = the k-mer starting at base j of read i; places where no k-mer starts
+       keep a default (not found) result. */
+    streaming_query_report streaming_lookup(char const* bases, uint64_t const* read_offsets, uint64_t num_reads, lookup_results& r) const {
+        const uint64_t total = num_reads ? read_offsets[num_reads] : 0;
+        sshash_results out = bind(r, total);
+        out.minimizer_found = nullptr;  // not part of what streaming results are compared on (include/util.hpp:107-141)
+        std::fill(r.kmer_id.begin(), r.kmer_id.end(), constants::invalid_uint64);
+        std::fill(r.kmer_id_in_string.begin(), r.kmer_id_in_string.end(), constants::invalid_uint64);
+        std::fill(r.kmer_offset.begin(), r.kmer_offset.end(), constants::invalid_uint64);
+        std::fill(r.string_id.begin(), r.string_id.end(), constants::invalid_uint64);
+        std::fill(r.string_begin.begin(), r.string_begin.end(), constants::invalid_uint64);
+        std::fill(r.string_end.begin(), r.string_end.end(), constants::invalid_uint64);
+        std::fill(r.kmer_orientation.begin(), r.kmer_orientation.end(), int8_t(constants::forward_orientation));
+        std::fill(r.minimizer_found.begin(), r.minimizer_found.end(), uint8_t(1));
+        sshash_streaming_report s;
+        check(sshash_streaming_lookup(m_h, bases, read_offsets, num_reads, &out, &s));
+        return to_report(s);
+    }
+
+    sshash_dict* handle() const { return m_h; }
+    uint32_t words_per_kmer() const { return m_info.words_per_kmer; }
+
+private:
+    static streaming_query_report to_report(sshash_streaming_report const& s) {
         streaming_query_report r;
         r.num_kmers = s.num_kmers;
         r.num_positive_kmers = s.num_positive_kmers;
@@ -200,11 +249,6 @@ public:
         r.num_extensions = s.num_extensions;
         return r;
     }
-
-    sshash_dict* handle() const { return m_h; }
-    uint32_t words_per_kmer() const { return m_info.words_per_kmer; }
-
-private:
     static void check(sshash_status s) {
         if (s != SSHASH_OK) throw std::runtime_error(sshash_last_error());
     }
@@ -234,6 +278,97 @@ private:
     }
     sshash_dict* m_h = nullptr;
     sshash_info m_info{};
+};
+
+/* streaming_query<Dict, canonical> -- reference include/streaming_query.hpp:9-198: a stateful cursor over the k-mers of
+   a read. lookup(kmer) takes a pointer to k characters, the k-mer following the previous call's; reset() starts a new
+   read. Same counters, same error (canonical mismatch -> std::runtime_error, :40-45), non-owning pointer to the
+   dictionary (:118). The reference asserts that what lookup returns equals the point lookup (:107): here it IS the
+   point lookup, with the reference's bookkeeping around it -- a k-mer with an invalid character resets the state
+   (:59-65); a positive k-mer is an extension when the previous one was positive in the same string and the id moved by
+   the orientation carried along (:86-100), else a search (:144-197). One call = one device round trip: this class is
+   the reference's shape; lookup_read() is the form meant for the GPU (one batched call per read). */
+template <bool canonical>
+struct streaming_query {
+    explicit streaming_query(dictionary const* dict) : m_dict(dict), m_k(dict->k()) {
+        if (canonical != dict->canonical())
+            throw std::runtime_error(std::string("dict.canonical() = ") + (dict->canonical() ? "true" : "false") + " but required " +
+                                     (canonical ? "true" : "false"));
+        reset();
+    }
+
+    void reset() {
+        m_res = lookup_result();
+        m_positive = false;
+    }
+
+    lookup_result lookup(char const* kmer) {
+        for (uint64_t i = 0; i != m_k; ++i) {
+            if (!is_valid(kmer[i])) {
+                m_num_invalid += 1;
+                reset();
+                return m_res;
+            }
+        }
+        account(m_dict->lookup(kmer));
+        return m_res;
+    }
+
+    /* every k-mer of `read` (reset() first, as src/query.cpp:78-108 does per read): one batched call */
+    std::vector<lookup_result> lookup_read(char const* read, uint64_t length) {
+        reset();
+        std::vector<lookup_result> out;
+        if (length < m_k) return out;
+        const uint64_t offsets[2] = {0, length};
+        lookup_results r;
+        const streaming_query_report rep = m_dict->streaming_lookup(read, offsets, 1, r);
+        m_num_searches += rep.num_searches;
+        m_num_extensions += rep.num_extensions;
+        m_num_negative += rep.num_negative_kmers;
+        m_num_invalid += rep.num_invalid_kmers;
+        out.reserve(length - m_k + 1);
+        for (uint64_t i = 0; i + m_k <= length; ++i) out.push_back(r[i]);
+        return out;
+    }
+
+    uint64_t num_searches() const { return m_num_searches; }
+    uint64_t num_extensions() const { return m_num_extensions; }
+    uint64_t num_positive_lookups() const { return num_searches() + num_extensions(); }
+    uint64_t num_negative_lookups() const { return m_num_negative; }
+    uint64_t num_invalid_lookups() const { return m_num_invalid; }
+
+private:
+    static bool is_valid(char c) {  // include/kmer.hpp:209-219,253-255
+        switch (c) {
+            case 'A': case 'C': case 'G': case 'T': case 'a': case 'c': case 'g': case 't': return true;
+            default: return false;
+        }
+    }
+    void account(lookup_result const& now) {
+        if (now.kmer_id == constants::invalid_uint64) {
+            m_num_negative += 1;
+            m_res = now;
+            m_positive = false;
+            return;
+        }
+        const bool extension = m_positive && now.string_id == m_res.string_id &&
+                               now.kmer_id == m_res.kmer_id + uint64_t(m_res.kmer_orientation);
+        const int64_t carried = m_res.kmer_orientation;
+        m_res = now;
+        if (extension) {
+            m_num_extensions += 1;
+            m_res.kmer_orientation = carried;  // :94-95
+        } else {
+            m_num_searches += 1;
+        }
+        m_positive = true;
+    }
+
+    dictionary const* m_dict;
+    uint64_t m_k;
+    lookup_result m_res;
+    bool m_positive = false;
+    uint64_t m_num_searches = 0, m_num_extensions = 0, m_num_invalid = 0, m_num_negative = 0;
 };
 
 }  // namespace sshash_amd

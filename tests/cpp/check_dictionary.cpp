@@ -191,6 +191,65 @@ static bool check_navigational(dictionary const& dict, std::vector<std::string> 
     return true;
 }
 
+/* include/streaming_query.hpp: the class, one k-mer per call (the reference's shape), must agree with the point lookup
+   on what equal_lookup_result compares (include/util.hpp:107-141; the reference asserts it, :107), with the batched
+   lookup_read() of the same read, and the two must count alike; the typed overloads lookup(Kmer) / is_member(Kmer)
+   (include/dictionary.hpp:42,76) must agree with the string ones. */
+template <bool canonical>
+static bool check_streaming_query(dictionary const& dict, std::vector<std::string> const& seqs) {
+    std::cout << "checking correctness of streaming_query and of the typed lookups..." << std::endl;
+    const uint64_t k = dict.k();
+    auto same = [](lookup_result const& a, lookup_result const& b) {
+        return a.kmer_id == b.kmer_id && a.kmer_id_in_string == b.kmer_id_in_string && a.string_id == b.string_id &&
+               a.string_begin == b.string_begin && a.string_end == b.string_end &&
+               (b.kmer_id == constants::invalid_uint64 || a.kmer_orientation == b.kmer_orientation);
+    };
+    /* a read: a stretch of one string, a mutation, an N, a stretch of another string reverse-complemented, junk */
+    std::string read = seqs[0].substr(0, std::min<size_t>(seqs[0].size(), k + 20));
+    read[read.size() / 2] = read[read.size() / 2] == 'A' ? 'C' : 'A';
+    read += "N";
+    read += reverse_complement(seqs[1 % seqs.size()].substr(0, std::min<size_t>(seqs[1 % seqs.size()].size(), k + 12)));
+    read += "ACGTTGCAACGTACGTAGCTAGCTAGCATCGATCGATCAGCTAGCTAGCATCGATCAGCTACGAT";
+    streaming_query<canonical> one_by_one(&dict), batched(&dict);
+    one_by_one.reset();
+    std::vector<lookup_result> all = batched.lookup_read(read.data(), read.size());
+    if (all.size() != read.size() - k + 1) FAIL("lookup_read returned " << all.size() << " results");
+    for (uint64_t i = 0; i + k <= read.size(); ++i) {
+        const lookup_result got = one_by_one.lookup(read.data() + i);
+        bool valid = true;
+        for (uint64_t j = 0; j < k; ++j) valid = valid && std::string("ACGTacgt").find(read[i + j]) != std::string::npos;
+        lookup_result point = valid ? dict.lookup(read.data() + i) : lookup_result();
+        if (!same(got, point)) FAIL("streaming_query::lookup differs from the point lookup at k-mer " << i);
+        if (!same(all[i], point)) FAIL("lookup_read differs from the point lookup at k-mer " << i);
+        if (valid) {
+            /* typed overloads: the same k-mer, packed */
+            uint_kmer_t x;
+            for (uint64_t j = 0; j < k; ++j) x.bits[(2 * j) / 64] |= ((uint64_t(uint8_t(read[i + j])) >> 1) & 3) << ((2 * j) % 64);
+            lookup_result typed = dict.lookup(x);
+            if (typed.kmer_id != point.kmer_id || (typed.kmer_id != constants::invalid_uint64 && typed.kmer_orientation != point.kmer_orientation))
+                FAIL("lookup(Kmer) differs from lookup(char const*) at k-mer " << i);
+            if (dict.is_member(x) != (point.kmer_id != constants::invalid_uint64)) FAIL("is_member(Kmer) at k-mer " << i);
+            if (dict.is_member(read.data() + i) != dict.is_member(x)) FAIL("is_member(char const*) at k-mer " << i);
+        }
+    }
+    if (one_by_one.num_searches() != batched.num_searches() || one_by_one.num_extensions() != batched.num_extensions() ||
+        one_by_one.num_negative_lookups() != batched.num_negative_lookups() || one_by_one.num_invalid_lookups() != batched.num_invalid_lookups())
+        FAIL("counters of the two forms differ: searches " << one_by_one.num_searches() << "/" << batched.num_searches() << " extensions "
+                                                          << one_by_one.num_extensions() << "/" << batched.num_extensions());
+    if (one_by_one.num_extensions() == 0 || one_by_one.num_invalid_lookups() == 0 || one_by_one.num_negative_lookups() == 0)
+        FAIL("the read was meant to exercise extensions, invalid and negative k-mers");
+    if (one_by_one.num_positive_lookups() + one_by_one.num_negative_lookups() + one_by_one.num_invalid_lookups() != read.size() - k + 1)
+        FAIL("counters do not add up (src/query.cpp:44-45)");
+    /* canonical mismatch -> std::runtime_error (include/streaming_query.hpp:40-45) */
+    try {
+        streaming_query<!canonical> wrong(&dict);
+        FAIL("a streaming_query of the other flavour was accepted");
+    } catch (std::runtime_error const& e) {
+        if (std::string(e.what()).find("but required") == std::string::npos) FAIL("unexpected message: " << e.what());
+    }
+    return true;
+}
+
 int main(int argc, char** argv) {
     if (argc < 4) {
         std::cerr << "Usage: " << argv[0] << " <input.fa[.gz]> <k> <m> [--canonical]" << std::endl;
@@ -210,6 +269,7 @@ int main(int argc, char** argv) {
         if (!check_every_id(dict)) return 1;
         if (!check_negative(dict)) return 1;
         if (!check_navigational(dict, seqs)) return 1;
+        if (!(cfg.canonical ? check_streaming_query<true>(dict, seqs) : check_streaming_query<false>(dict, seqs))) return 1;
         /* error channel: exceptions with the reference's wording */
         try {
             dictionary other;
