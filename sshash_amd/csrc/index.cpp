@@ -255,10 +255,12 @@ void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, st
     idx.num_bases = idx.endpoints.back();
     idx.num_kmers = 0;
     for (uint64_t s = 0; s < idx.num_strings; ++s) {
+        if (idx.endpoints[s + 1] < idx.endpoints[s]) throw error(error_kind::build, "endpoints must not decrease");
         const uint64_t len = idx.endpoints[s + 1] - idx.endpoints[s];
         if (len < opt.k) throw error(error_kind::build, "input string shorter than k");
         idx.num_kmers += len - opt.k + 1;
     }
+    if (packed_bases.size() < (2 * idx.num_bases + 63) / 64) throw error(error_kind::build, "fewer packed words than the endpoints announce");
     const uint32_t W = idx.words_per_kmer();
     idx.strings = std::move(packed_bases);
     /* zero sentinel of one k-mer word-width (src/builder/encode_strings.cpp:183-188) + slack
@@ -658,8 +660,10 @@ struct writer {
 };
 struct reader {
     FILE* f;
+    uint64_t left;  // bytes of the file not read yet: a length field can never ask for more
     void raw(void* p, size_t n) {
-        if (n && fread(p, 1, n, f) != n) throw error(error_kind::format, "index file truncated");
+        if (n > left || (n && fread(p, 1, n, f) != n)) throw error(error_kind::format, "index file truncated");
+        left -= n;
     }
     uint64_t u64() {
         uint64_t v;
@@ -669,7 +673,7 @@ struct reader {
     template <typename T>
     void vec(std::vector<T>& v) {
         const uint64_t n = u64();
-        if (n > (uint64_t(1) << 40)) throw error(error_kind::format, "index file corrupt");
+        if (n > left / sizeof(T)) throw error(error_kind::format, "index file corrupt (a vector longer than the file)");
         v.resize(n);
         raw(v.data(), n * sizeof(T));
         const size_t pad = (8 - (n * sizeof(T)) % 8) % 8;
@@ -680,7 +684,7 @@ struct reader {
         p.size = u64();
         p.width = uint32_t(u64());
         vec(p.words);
-        if (p.width < 1 || p.width > 64 || p.words.size() < (p.size * p.width + 63) / 64 + 1)
+        if (p.width < 1 || p.width > 64 || p.size > (uint64_t(1) << 56) || p.words.size() < (p.size * p.width + 63) / 64 + 1)
             throw error(error_kind::format, "index file corrupt (packed vector)");
     }
     void mphf(mphf_host& m) {
@@ -732,11 +736,101 @@ void save_index(host_index const& idx, std::string const& filename) {
     fclose(f);
 }
 
+/* Everything the device upload and the kernels rely on without checking again: a file that passes may hold a wrong
+   dictionary, but not one that makes the engine read or write out of bounds (make_granules indexes by
+   endpoint, the kernels index by codeword, offset and MPHF geometry). */
+static void validate_mphf(mphf_host const& f, char const* what) {
+    auto bad = [&](char const* why) { throw error(error_kind::format, std::string("index file corrupt (") + what + ": " + why + ")"); };
+    if (f.pilot_width < 1 || f.pilot_width > 32) bad("pilot width");
+    if (f.num_keys == 0) {
+        if (!f.parts.empty()) bad("partitions of an empty function");
+        return;
+    }
+    if (f.parts.empty()) bad("no partition");
+    uint64_t keys = 0, pilots = 0, frees = 0;
+    for (mphf_partition const& p : f.parts) {
+        if (p.key_offset != keys || p.pilot_base != pilots || p.free_base != frees) bad("partition offsets");
+        if (p.num_keys == 0 || p.table_size < p.num_keys) bad("table size");
+        if (p.dense_buckets == 0 || p.sparse_buckets == 0) bad("bucket counts");
+        keys += p.num_keys;
+        pilots += uint64_t(p.dense_buckets) + p.sparse_buckets;
+        frees += p.table_size - p.num_keys;
+    }
+    if (keys != f.num_keys) bad("key count");
+    if (f.pilots.size() < (pilots * f.pilot_width + 63) / 64 + 1) bad("pilot vector");
+    if (f.free_slots.size() < frees) bad("free slots");
+    for (mphf_partition const& p : f.parts)
+        for (uint64_t i = 0; i < uint64_t(p.table_size - p.num_keys); ++i)
+            if (f.free_slots[p.free_base + i] >= p.num_keys) bad("free slot value");
+}
+
+static void validate_packed(packed_vec const& v, char const* what) {
+    if (v.width < 1 || v.width > 64 || v.words.size() < (v.size * v.width + 63) / 64 + 1)
+        throw error(error_kind::format, std::string("index file corrupt (") + what + ")");
+}
+
+static void validate_index(host_index const& idx) {
+    auto bad = [](char const* why) { throw error(error_kind::format, std::string("index file corrupt (") + why + ")"); };
+    if (idx.endpoints.size() != idx.num_strings + 1 || idx.endpoints.empty() || idx.endpoints.front() != 0 || idx.endpoints.back() != idx.num_bases)
+        bad("endpoints");
+    uint64_t kmers = 0;
+    for (uint64_t s = 0; s < idx.num_strings; ++s) {
+        if (idx.endpoints[s + 1] < idx.endpoints[s] || idx.endpoints[s + 1] - idx.endpoints[s] < idx.k) bad("string shorter than k");
+        kmers += idx.endpoints[s + 1] - idx.endpoints[s] - idx.k + 1;
+    }
+    if (kmers != idx.num_kmers) bad("num_kmers");
+    const uint64_t W = idx.words_per_kmer();
+    if (idx.strings.size() < (2 * idx.num_bases + 63) / 64 + W + 2 || idx.strings_num_bits != 2 * idx.num_bases + 64 * W) bad("strings");
+    if (idx.begin_buckets_of_size.size() != MAX_BUCKET_SMALL + 1) bad("bucket table");
+    validate_mphf(idx.minimizers_mphf, "minimizers");
+    validate_packed(idx.control_codewords, "control codewords");
+    validate_packed(idx.mid_load_buckets, "mid-load buckets");
+    validate_packed(idx.heavy_load_buckets, "heavy-load buckets");
+    if (idx.control_codewords.size != idx.minimizers_mphf.num_keys) bad("one control codeword per minimizer");
+    if (idx.heavy_load_buckets.size && idx.mid_load_buckets.size && idx.mid_load_buckets.width != idx.heavy_load_buckets.width)
+        bad("offset widths");  // the device reads both lists with one width
+    for (uint64_t i = 0; i < idx.mid_load_buckets.size; ++i)
+        if (idx.mid_load_buckets.get(i) >= idx.num_bases) bad("mid-load offset");
+    for (uint64_t i = 0; i < idx.heavy_load_buckets.size; ++i)
+        if (idx.heavy_load_buckets.get(i) >= idx.num_bases) bad("heavy-load offset");
+    uint64_t heavy_positions = 0;
+    for (uint32_t p = 0; p < idx.skew_num_partitions; ++p) {
+        validate_mphf(idx.skew_mphfs[p], "skew index");
+        validate_packed(idx.skew_positions[p], "skew positions");
+        if (idx.skew_positions[p].size != idx.skew_mphfs[p].num_keys) bad("one skew position per k-mer");
+        heavy_positions += idx.skew_positions[p].size;
+    }
+    /* control codewords (src/builder/build_sparse_and_skew_index.cpp:110-124,204-235): every one must point inside
+       the structure its two low bits select */
+    for (uint64_t i = 0; i < idx.control_codewords.size; ++i) {
+        const uint64_t code = idx.control_codewords.get(i);
+        if ((code & 1) == 0) {
+            if ((code >> 1) >= idx.num_bases) bad("singleton offset");
+        } else if ((code & 3) == 1) {
+            const uint64_t size = ((code >> 2) & (MAX_BUCKET_SMALL - 1)) + 2;
+            if (size > MAX_BUCKET_SMALL) bad("mid-load bucket size");
+            const uint64_t begin = uint64_t(idx.begin_buckets_of_size[size]) + (code >> (2 + MIN_L)) * size;
+            if (begin + size > idx.mid_load_buckets.size) bad("mid-load bucket");
+        } else {
+            if (((code >> 2) & 7) >= idx.skew_num_partitions || (code >> 5) >= std::max<uint64_t>(idx.heavy_load_buckets.size, 1)) bad("heavy-load bucket");
+        }
+    }
+    if (idx.weight_starts.size() != idx.weight_values.size() || (!idx.weight_starts.empty() && idx.weight_starts[0] != 0)) bad("weights");
+    for (size_t i = 1; i < idx.weight_starts.size(); ++i)
+        if (idx.weight_starts[i] <= idx.weight_starts[i - 1] || idx.weight_starts[i] >= idx.num_kmers) bad("weight intervals");
+}
+
 void load_index(host_index& idx, std::string const& filename) {
     FILE* f = fopen(filename.c_str(), "rb");
     if (!f) throw error(error_kind::io, "error in opening the file '" + filename + "'");
     try {
-        reader r{f};
+        uint64_t file_bytes = 0;
+        if (fseek(f, 0, SEEK_END) == 0) {
+            const long at = ftell(f);
+            if (at > 0) file_bytes = uint64_t(at);
+        }
+        rewind(f);
+        reader r{f, file_bytes};
         idx = host_index();
         char magic[8];
         r.raw(magic, 8);
@@ -781,11 +875,9 @@ void load_index(host_index& idx, std::string const& filename) {
         r.packed(idx.heavy_load_buckets);
         r.vec(idx.weight_starts);
         r.vec(idx.weight_values);
-        if (idx.endpoints.size() != idx.num_strings + 1 || idx.begin_buckets_of_size.size() != MAX_BUCKET_SMALL + 1 ||
-            idx.weight_starts.size() != idx.weight_values.size() || (!idx.weight_starts.empty() && idx.weight_starts[0] != 0))
-            throw error(error_kind::format, "index file corrupt (sizes)");
         char extra;
         if (fread(&extra, 1, 1, f) != 0) throw error(error_kind::format, "index file has trailing bytes");
+        validate_index(idx);
     } catch (...) {
         fclose(f);
         throw;

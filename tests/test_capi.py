@@ -185,3 +185,56 @@ def test_cuttlefish_segment_input(case_skew_regular, tmp_path):
         assert (d.access_packed(ids) == case.dict.access_packed(ids)).all()
     with pytest.raises(sshash_amd.SSHashError):
         sshash_amd.Dictionary.build(str(plain), k=case.k, m=case.m, weighted=True)
+
+
+def test_corrupt_index_files_are_rejected_not_trusted(tmp_path):
+    """a damaged or hostile index file must come back as SSHASH_ERR_FORMAT -- not as an out-of-bounds
+    write while the device layout is made, nor as a kernel reading outside its arrays. Every 8-byte word of a small
+    index file is overwritten in turn (with a huge and with a small value), and the file is truncated at several
+    places: each variant either loads into a dictionary that passes the same structural checks, or raises."""
+    import sshash_amd
+    from conftest import random_dna
+
+    rng = np.random.default_rng(3)
+    seqs = [random_dna(rng, int(rng.integers(31, 90))) for _ in range(40)]
+    fa = tmp_path / "small.fa"
+    fa.write_text("".join(f">\n{s}\n" for s in seqs))
+    d = sshash_amd.Dictionary.build(str(fa), k=31, m=11)
+    good = tmp_path / "good.sshash"
+    d.save(str(good))
+    blob = bytearray(good.read_bytes())
+    assert sshash_amd.Dictionary.load(str(good)).num_kmers() == d.num_kmers()
+    rejected = accepted = 0
+    bad = tmp_path / "bad.sshash"
+    step = max(8, (len(blob) // 8 // 400) * 8)  # ~400 positions spread over the file, all of the header
+    positions = list(range(0, min(len(blob), 256), 8)) + list(range(256, len(blob) - 8, step))
+    for at in positions:
+        for value in (0xFFFFFFFFFFFFFFF0, 0x0000000000000003):
+            variant = bytearray(blob)
+            variant[at:at + 8] = int(value).to_bytes(8, "little")
+            bad.write_bytes(variant)
+            try:
+                other = sshash_amd.Dictionary.load(str(bad))
+                accepted += 1  # a word of payload (bases, pilots ...) changed: structurally still a dictionary
+                assert other.num_strings() == d.num_strings()
+                other.close()
+            except sshash_amd.SSHashError as e:
+                rejected += 1
+                assert e.status != 0
+    for cut in (7, 40, 100, len(blob) // 2, len(blob) - 1):
+        bad.write_bytes(blob[:cut])
+        with pytest.raises(sshash_amd.SSHashError):
+            sshash_amd.Dictionary.load(str(bad))
+    bad.write_bytes(blob + b"x")
+    with pytest.raises(sshash_amd.SSHashError):
+        sshash_amd.Dictionary.load(str(bad))
+    assert rejected > 50 and accepted > 0
+
+
+def test_build_from_packed_rejects_bad_endpoints():
+    import sshash_amd
+
+    words = np.zeros(8, dtype=np.uint64)
+    for endpoints in ([0, 40, 35, 100], [0, 40, 100000], [5, 40, 80], [0, 20, 60]):
+        with pytest.raises((sshash_amd.SSHashError, ValueError)):
+            sshash_amd.Dictionary.build_from_packed(words, np.array(endpoints, dtype=np.uint64), k=31, m=11)
