@@ -231,6 +231,31 @@ sshash_status sshash_route_bucket_by_key_device(const sshash_dict* d, int device
 sshash_status sshash_route_combine_device(const sshash_dict* d, int device, const uint64_t* replies, const uint32_t* slots,
                                           uint64_t m, uint64_t* out, void* hip_stream);
 
+/* ---- the whole sharded lookup as ONE call (BASELINE.json configs[4]): route -> exchange -> lookup
+ *      -> return -> combine against a dictionary partitioned over `num_ranks` GPUs -- minimizer shards
+ *      (sshash_build_config.num_shards / shard_id; by_table_key = 0) or table shards (sshash_to_device_table_shard;
+ *      by_table_key = 1). Collective: every rank calls it with its own local batch of n packed k-mers (n may be 0) and
+ *      receives the n ids, identical to the unpartitioned dictionary's. The one step that needs communication is handed
+ *      in as two callbacks (return 0 on success):
+ *        counts  all-to-all of ONE uint64 per peer: send[p] goes to rank p, recv[p] comes from rank p (host arrays of
+ *                num_ranks entries);
+ *        data    all-to-all-v of DEVICE buffers: the block for rank p starts after the blocks of the ranks before it,
+ *                send_counts[p] / recv_counts[p] elements of elem_bytes each (host arrays); it must be complete, or ordered
+ *                on hip_stream, when it returns.
+ *      sshash_sharded_lookup_rccl supplies them over an RCCL communicator (grouped ncclSend/ncclRecv: the all-to-all
+ *      over xGMI); `nccl_comm` is an ncclComm_t whose rank r holds shard r. RCCL is resolved when first used. ---- */
+typedef struct sshash_exchange {
+    void* ctx;
+    int (*counts)(void* ctx, const uint64_t* send, uint64_t* recv);
+    int (*data)(void* ctx, const void* send, const uint64_t* send_counts, void* recv, const uint64_t* recv_counts,
+                uint32_t elem_bytes, void* hip_stream);
+} sshash_exchange;
+sshash_status sshash_sharded_lookup_device(const sshash_dict* d, int device, uint32_t num_ranks, int by_table_key,
+                                           const uint64_t* kmers, uint64_t n, int check_reverse_complement, uint64_t* kmer_ids,
+                                           const sshash_exchange* exchange, void* hip_stream);
+sshash_status sshash_sharded_lookup_rccl(const sshash_dict* d, int device, void* nccl_comm, int by_table_key, const uint64_t* kmers,
+                                         uint64_t n, int check_reverse_complement, uint64_t* kmer_ids, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,14 @@ class _Results(C.Structure):
     ]
 
 
+EXCHANGE_COUNTS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+EXCHANGE_DATA = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p)
+
+
+class _Exchange(C.Structure):  # sshash_exchange
+    _fields_ = [("ctx", C.c_void_p), ("counts", EXCHANGE_COUNTS), ("data", EXCHANGE_DATA)]
+
+
 class _Report(C.Structure):
     _fields_ = [
         ("num_kmers", C.c_uint64),
@@ -138,6 +146,8 @@ def _load() -> C.CDLL:
         "sshash_to_device_table_shard": (C.c_int, [P, C.c_int, C.c_uint32, C.c_uint32]),
         "sshash_device_bytes": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64)]),
         "sshash_device_stats": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64 * 8)]),
+        "sshash_sharded_lookup_device": (C.c_int, [P, C.c_int, C.c_uint32, C.c_int, P, C.c_uint64, C.c_int, P, C.POINTER(_Exchange), P]),
+        "sshash_sharded_lookup_rccl": (C.c_int, [P, C.c_int, P, C.c_int, P, C.c_uint64, C.c_int, P, P]),
         "sshash_streaming_lookup_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, C.c_uint64, C.POINTER(_Results), P, P]),
         "sshash_streaming_lookup": (C.c_int, [P, P, P, C.c_uint64, C.POINTER(_Results), C.POINTER(_Report)]),
         "sshash_lookup_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, C.POINTER(_Results), P]),
@@ -180,7 +190,7 @@ C_ABI_SYMBOLS = (
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
     "sshash_access_packed_device sshash_weight sshash_weight_device "
     "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device "
-    "sshash_streaming_lookup sshash_streaming_lookup_device "
+    "sshash_streaming_lookup sshash_streaming_lookup_device sshash_sharded_lookup_device sshash_sharded_lookup_rccl "
     "sshash_route_packed_device sshash_route_bucket_device sshash_route_bucket_by_key_device sshash_route_combine_device"
 ).split()
 
@@ -492,6 +502,40 @@ class Dictionary:
     def route_combine_device(self, device: int, d_replies: int, d_slots: int, m: int, d_out: int, stream: int = 0) -> None:
         _check(_load().sshash_route_combine_device(self._h, int(device), C.c_void_p(d_replies), C.c_void_p(d_slots), int(m),
                                                    C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def sharded_lookup_device(self, device: int, num_ranks: int, by_table_key: bool, d_kmers: int, n: int, d_kmer_id: int,
+                              counts_fn, data_fn, check_reverse_complement: bool = True, stream: int = 0) -> None:
+        """sshash_sharded_lookup_device: route -> exchange -> lookup -> return -> combine in one call; the exchange is
+        `counts_fn(send: list[int]) -> list[int]` and `data_fn(send_ptr, send_counts, recv_ptr, recv_counts, elem_bytes,
+        stream) -> None` (device pointers)."""
+        errors = []
+
+        def counts(_ctx, send, recv):
+            try:
+                got = counts_fn([int(send[p]) for p in range(num_ranks)])
+                for p in range(num_ranks):
+                    recv[p] = int(got[p])
+                return 0
+            except Exception as e:  # noqa: BLE001 -- must not unwind through the C frames
+                errors.append(e)
+                return 1
+
+        def data(_ctx, send, send_counts, recv, recv_counts, elem_bytes, hip_stream):
+            try:
+                data_fn(int(send or 0), [int(send_counts[p]) for p in range(num_ranks)], int(recv or 0),
+                        [int(recv_counts[p]) for p in range(num_ranks)], int(elem_bytes), int(hip_stream or 0))
+                return 0
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+                return 1
+
+        x = _Exchange(None, EXCHANGE_COUNTS(counts), EXCHANGE_DATA(data))
+        status = _load().sshash_sharded_lookup_device(self._h, int(device), int(num_ranks), 1 if by_table_key else 0, C.c_void_p(d_kmers),
+                                                      int(n), 1 if check_reverse_complement else 0, C.c_void_p(d_kmer_id), C.byref(x),
+                                                      C.c_void_p(stream))
+        if errors:
+            raise errors[0]
+        _check(status)
 
     def route_device(self, device: int, d_kmers: int, n: int, num_shards: int, d_owner_fwd: int, d_owner_rc: int,
                      stream: int = 0) -> None:

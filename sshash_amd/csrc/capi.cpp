@@ -409,4 +409,20 @@ sshash_status sshash_route_combine_device(const sshash_dict* d, int device, cons
     return guarded([&] { d->eng->route_combine_device(device, replies, slots, m, out, hip_stream); });
 }
 
+sshash_status sshash_sharded_lookup_device(const sshash_dict* d, int device, uint32_t num_ranks, int by_table_key,
+                                           const uint64_t* kmers, uint64_t n, int check_rc, uint64_t* kmer_ids,
+                                           const sshash_exchange* exchange, void* hip_stream) {
+    if (!d || !exchange || (n && (!kmers || !kmer_ids))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        exchange_ops x{exchange->ctx, exchange->counts, exchange->data};
+        d->eng->sharded_lookup_device(device, num_ranks, by_table_key != 0, kmers, n, check_rc != 0, kmer_ids, x, hip_stream);
+    });
+}
+
+sshash_status sshash_sharded_lookup_rccl(const sshash_dict* d, int device, void* nccl_comm, int by_table_key, const uint64_t* kmers,
+                                         uint64_t n, int check_rc, uint64_t* kmer_ids, void* hip_stream) {
+    if (!d || !nccl_comm || (n && (!kmers || !kmer_ids))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->sharded_lookup_rccl(device, nccl_comm, by_table_key != 0, kmers, n, check_rc != 0, kmer_ids, hip_stream); });
+}
+
 }  // extern "C"

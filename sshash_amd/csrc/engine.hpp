@@ -14,6 +14,14 @@ struct device_replica;  // defined in engine.hip
 
 enum class out_mode : int { ids = 0, full = 1, member = 2 };
 
+/* the one collective step of the sharded lookup, supplied by the caller (sshash_exchange in include/sshash_amd.h) */
+struct exchange_ops {
+    void* ctx;
+    int (*counts)(void* ctx, const uint64_t* send, uint64_t* recv);
+    int (*data)(void* ctx, const void* send, const uint64_t* send_counts, void* recv, const uint64_t* recv_counts, uint32_t elem_bytes,
+                void* hip_stream);
+};
+
 struct streaming_report {  // streaming_query_report, include/util.hpp:21-36
     uint64_t num_kmers = 0, num_positive_kmers = 0, num_negative_kmers = 0, num_invalid_kmers = 0,
              num_searches = 0, num_extensions = 0;
@@ -101,6 +109,14 @@ public:
                                  uint64_t total_bases, result_view const& d_out, uint64_t* d_report, void* stream) const;
     streaming_report streaming_lookup_host(char const* bases, uint64_t const* read_offsets, uint64_t n_reads,
                                            result_view const& h_out) const;
+
+    /* Lookup against a dictionary partitioned over `num_ranks` GPUs (minimizer shards, or table shards with
+       by_table_key): route -> exchange -> lookup -> return -> combine (sharded.cpp). Collective: every rank calls it, with
+       its own local batch (n may be 0). d_out: n ids. */
+    void sharded_lookup_device(int device, uint32_t num_ranks, bool by_table_key, uint64_t const* d_kmers, uint64_t n, bool check_rc,
+                               uint64_t* d_out, exchange_ops const& x, void* stream) const;
+    void sharded_lookup_rccl(int device, void* nccl_comm, bool by_table_key, uint64_t const* d_kmers, uint64_t n, bool check_rc,
+                             uint64_t* d_out, void* stream) const;
 
     /* the replica resident on `device` (throws when there is none); internal to the .hip files */
     device_replica const* replica(int device) const;

@@ -25,9 +25,10 @@ Results are identical to the unsharded dictionary: ids derive from string offset
 A second partitioning, by = "table": every rank keeps the complete reference structures and strings but only its
 share of the super-k-mer table (about three quarters of a replica's HBM); queries are routed by their table key,
 which is strand-symmetric, so a query has ONE owner and the exchange carries one message per query.
-torch is used for device memory and ``torch.distributed``; routing, bucketing, lookup and combine are HIP
-kernels behind the C ABI. With a ``gloo`` group (tests) the payloads are
-staged through host memory.
+The five steps are ONE call of the C ABI, ``sshash_sharded_lookup_device`` (sshash_amd/csrc/sharded.cpp), which takes
+the exchange as two callbacks; this module supplies them from ``torch.distributed`` (``all_to_all_single`` over
+RCCL; a ``gloo`` group -- the tests -- stages the payloads through host memory). A C++ host hands its own
+exchange, or an ``ncclComm_t`` to ``sshash_sharded_lookup_rccl``, and needs nothing of this file.
 """
 from __future__ import annotations
 
@@ -77,27 +78,19 @@ class ShardedDictionary:
                                  **build_kwargs)
         return cls(shard, device, group)
 
-    def _route(self, d_kmers, n, cursors, send, slots, check_rc, stream):
-        if self.by == "table":
-            self.shard.route_bucket_by_key_device(self.device, d_kmers, n, self.world, cursors, send, slots, stream=stream)
-        else:
-            self.shard.route_bucket_device(self.device, d_kmers, n, self.world, cursors, send, slots,
-                                           check_reverse_complement=check_rc, stream=stream)
+    # -- the exchange: torch.distributed behind the two callbacks of sshash_sharded_lookup_device ------------------
+    class _DevicePointer:
+        """A raw device pointer as something torch.as_tensor accepts (the CUDA array interface)."""
 
-    # -- collectives -----------------------------------------------------------------------------
-    def _all_to_all(self, send, send_counts, recv_counts):
+        def __init__(self, ptr: int, nbytes: int):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    def _tensor(self, ptr: int, nbytes: int):
         import torch
-        import torch.distributed as dist
 
-        width = send.shape[1:]
-        if self._on_host:
-            s = send.cpu().contiguous()
-            r = torch.empty((int(sum(recv_counts)),) + tuple(width), dtype=send.dtype)
-            dist.all_to_all_single(r, s, list(recv_counts), list(send_counts), group=self.group)
-            return r.to(self._dev)
-        r = torch.empty((int(sum(recv_counts)),) + tuple(width), dtype=send.dtype, device=self._dev)
-        dist.all_to_all_single(r, send.contiguous(), list(recv_counts), list(send_counts), group=self.group)
-        return r
+        if nbytes == 0:
+            return torch.empty(0, dtype=torch.uint8, device=self._dev)
+        return torch.as_tensor(self._DevicePointer(ptr, nbytes), device=self._dev)
 
     def _exchange_counts(self, send_counts):
         import torch
@@ -108,41 +101,40 @@ class ShardedDictionary:
         dist.all_to_all_single(r, s, group=self.group)
         return [int(x) for x in r.tolist()]
 
+    def _exchange_data(self, send_ptr, send_counts, recv_ptr, recv_counts, elem_bytes, stream):
+        """all-to-all-v of device buffers: all_to_all_single over RCCL (xGMI); a gloo group (tests) stages through host
+        memory. The library's launches are on `stream`, which is torch's current stream (lookup_device passes it)."""
+        import torch
+        import torch.distributed as dist
+
+        send = self._tensor(send_ptr, sum(send_counts) * elem_bytes)
+        recv = self._tensor(recv_ptr, sum(recv_counts) * elem_bytes)
+        s_split = [c * elem_bytes for c in send_counts]
+        r_split = [c * elem_bytes for c in recv_counts]
+        if self._on_host:
+            r = torch.empty(recv.numel(), dtype=torch.uint8)
+            dist.all_to_all_single(r, send.cpu(), r_split, s_split, group=self.group)
+            recv.copy_(r)
+        else:
+            dist.all_to_all_single(recv, send, r_split, s_split, group=self.group)
+
     # -- lookup ----------------------------------------------------------------------------------------
     def lookup_device(self, d_kmers, check_reverse_complement: bool = True):
         """d_kmers: int64 CUDA tensor of n*W packed words on this rank's device -> int64 CUDA tensor of n ids
-        (bit pattern of the uint64 ids; INVALID_U64 == -1)."""
+        (bit pattern of the uint64 ids; INVALID_U64 == -1). Collective: every rank of the group calls it (an empty
+        local batch still takes part in the exchange). Route, lookup, return and combine run inside
+        sshash_sharded_lookup_device (sshash_amd/csrc/sharded.cpp); only the exchange comes from here."""
         import torch
 
         W = self.shard.words_per_kmer()
         n = d_kmers.numel() // W
         stream = torch.cuda.current_stream(self._dev).cuda_stream
-        # 1. count the messages per owner, then scatter them into per-owner regions (HIP kernels behind the C ABI)
-        counts = torch.zeros(self.world, dtype=torch.int64, device=self._dev)
-        if n:
-            self._route(d_kmers.data_ptr(), n, counts.data_ptr(), 0, 0, check_reverse_complement, stream)
-        send_counts = [int(c) for c in counts.tolist()]
-        total = sum(send_counts)
-        cursors = torch.cumsum(counts, 0) - counts                                  # first message of every region
-        send = torch.empty((max(total, 1), W), dtype=torch.int64, device=self._dev)
-        slots = torch.empty(max(total, 1), dtype=torch.int32, device=self._dev)     # which local query a message is about
-        if n:
-            self._route(d_kmers.data_ptr(), n, cursors.data_ptr(), send.data_ptr(), slots.data_ptr(), check_reverse_complement, stream)
-        # 2. exchange, 3. lookup what arrived, 4. return the ids
-        recv_counts = self._exchange_counts(send_counts)
-        received = self._all_to_all(send[:total], send_counts, recv_counts)           # (m, W) packed k-mers to look up here
-        m = received.shape[0]
-        ids = torch.full((max(m, 1),), -1, dtype=torch.int64, device=self._dev)
-        if m:
-            received = received.contiguous()
-            self.shard.lookup_device(self.device, received.data_ptr(), m, ids.data_ptr(),
-                                     check_reverse_complement=check_reverse_complement, stream=stream)
-        replies = self._all_to_all(ids[:m].view(m, 1), recv_counts, send_counts).view(-1).contiguous()  # aligned with `slots`
-        # 5. combine: a reply that found the k-mer settles its query
-        out = torch.full((n,), -1, dtype=torch.int64, device=self._dev)
-        if total:
-            self.shard.route_combine_device(self.device, replies.data_ptr(), slots.data_ptr(), total, out.data_ptr(), stream=stream)
-        return out
+        out = torch.empty(max(n, 1), dtype=torch.int64, device=self._dev)
+        d_kmers = d_kmers.contiguous()
+        self.shard.sharded_lookup_device(self.device, self.world, self.by == "table", d_kmers.data_ptr() if n else 0, n,
+                                         out.data_ptr(), self._exchange_counts, self._exchange_data,
+                                         check_reverse_complement=check_reverse_complement, stream=stream)
+        return out[:n]
 
     def lookup(self, kmers: np.ndarray, check_reverse_complement: bool = True) -> np.ndarray:
         """Host convenience wrapper: packed uint64 words in, uint64 ids out."""

@@ -136,3 +136,64 @@ def test_a_table_shard_answers_every_query_on_its_own(case_name, request):
     reads = ["".join(case.sequences[i]) for i in range(0, len(case.sequences), 5)]
     got, ref = d.streaming_query(reads), case.oracle.streaming_query(reads)
     assert [getattr(got, f) for f in ref] == list(ref.values())
+
+
+@pytest.mark.gpu
+def test_sharded_lookup_from_cpp_with_callbacks_and_over_rccl():
+    """tests/cpp/check_sharded.cpp: two ranks as host threads over sshash_sharded_lookup_device with their own exchange
+    callbacks (minimizer shards, then table shards), and sshash_sharded_lookup_rccl over a real RCCL communicator."""
+    binary = os.path.join(ROOT, "tests", "cpp", "check_sharded")
+    if not os.path.exists(binary):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "sshash_amd", "csrc"), "tools"])
+    p = subprocess.run([binary, SE_FASTA, "31", "13"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "EVERYTHING OK!" in p.stdout
+
+
+NCCL_WORKER = textwrap.dedent(
+    """
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, sys.argv[1])
+    import torch, torch.distributed as dist
+    import sshash_amd
+    from sshash_amd.sharded import ShardedDictionary
+    from oracle.ground_truth import _revcomp_u64
+
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))  # RCCL
+    whole = sshash_amd.Dictionary.build(sys.argv[2], k=31, m=13, num_threads=4).to_device(local)
+    for by in ("minimizer", "table"):
+        sd = ShardedDictionary.build(sys.argv[2], device=local, by=by, k=31, m=13, num_threads=4)
+        rng = np.random.default_rng(5 + rank)
+        ids = rng.integers(0, whole.num_kmers(), 20000, dtype=np.uint64)
+        pos = whole.access_packed(ids)
+        pos[::2] = _revcomp_u64(pos[::2], 31)
+        q = np.concatenate([pos, rng.integers(0, 1 << 62, 20000, dtype=np.uint64)])
+        got = sd.lookup(q)
+        assert (got == whole.lookup(q).kmer_id).all(), by
+        assert sd.lookup(np.zeros(0, dtype=np.uint64)).size == 0
+    if rank == 0:
+        print("NCCL SHARDED OK", world, flush=True)
+    dist.barrier(); dist.destroy_process_group()
+    """
+)
+
+
+@pytest.mark.gpu
+def test_sharded_lookup_over_the_nccl_backend(tmp_path):
+    """The RCCL branch of sshash_amd/sharded.py (all_to_all_single on device tensors) under torch.distributed.run: as many
+    ranks as there are GPUs (one on the single-GPU test box -- the exchange with oneself still goes through RCCL)."""
+    import torch
+
+    n = max(1, min(torch.cuda.device_count(), 8))
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                        "--master-port", "29577", str(script), ROOT, SE_FASTA], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert f"NCCL SHARDED OK {n}" in p.stdout
