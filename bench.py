@@ -152,6 +152,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-mixes", action="store_true", help="skip the untimed-region side measurements (other query mixes)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="queries per CPU-baseline pass")
+    ap.add_argument("--sharded", choices=["table", "minimizer"], default=None,
+                    help="NOT the headline mode: partition the dictionary over the GPUs instead of replicating it (BASELINE.json "
+                         "configs[4]) -- 'table': the super-k-mer table by key, 'minimizer': the minimizer-side structures -- and "
+                         "route every query to its owner with an all-to-all over RCCL (sshash_sharded_lookup_device)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
     bases, mean_len, queries, what = WORKLOADS[args.workload]
@@ -165,6 +169,11 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
 
+    # stdout carries the ONE JSON line and nothing else: whatever the libraries write to file descriptor 1 meanwhile
+    # (RCCL prints its version banner and its warnings there) is sent to stderr until the line is due
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -193,7 +202,30 @@ def main():
 
     d, index_path = get_index(args, rank, world, barrier)
     t0 = time.time()
-    d.to_device(local_rank)
+    sharded = None
+    if args.sharded:
+        if not use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
+            use_dist = True
+        from sshash_amd.sharded import ShardedDictionary
+
+        if args.sharded == "table":
+            sharded = ShardedDictionary(d, local_rank, by="table")
+        else:
+            # rank r keeps the buckets of its own minimizers only: rebuilt from the cached dictionary's strings
+            import sshash_amd
+            from sshash_amd.synthetic import make_spss
+
+            words, endpoints = make_spss(args.bases, k=args.k, m=args.m, seed=args.seed, mean_len=args.mean_len)
+            shard = sshash_amd.Dictionary.build_from_packed(words, endpoints, k=args.k, m=args.m, canonical=args.canonical, num_threads=0,
+                                                            num_shards=world, shard_id=rank)
+            del words
+            sharded = ShardedDictionary(shard, local_rank, by="minimizer")
+            d.to_device(local_rank)  # (the complete dictionary: used to draw the queries)
+    else:
+        d.to_device(local_rank)
     stats = d.device_stats(local_rank)
     if rank == 0:
         log(f"replica in HBM: {d.device_bytes(local_rank) / 1e6:.0f} MB (upload {time.time() - t0:.1f}s); {stats}")
@@ -211,7 +243,10 @@ def main():
     stream = torch.cuda.current_stream()
 
     def step(q=dq, o=out, count=n):
-        d.lookup_device(local_rank, q.data_ptr(), count, o.data_ptr(), check_reverse_complement=True, stream=stream.cuda_stream)
+        if sharded is not None:
+            o[:count] = sharded.lookup_device(q[: count * W])
+        else:
+            d.lookup_device(local_rank, q.data_ptr(), count, o.data_ptr(), check_reverse_complement=True, stream=stream.cuda_stream)
 
     for _ in range(args.warmup):
         step()
@@ -341,7 +376,7 @@ def main():
                                    f"({args.positive:.0%} positive, half of them reverse-complemented; negatives: {args.negatives}) "
                                    f"split over {world} GPU(s)",
                        "queries_per_step": args.queries, "queries_per_gpu": n, "num_kmers": d.num_kmers(), "k": d.k(), "m": d.m(),
-                       "canonical": d.canonical(), "index_replicated_per_gpu": True,
+                       "canonical": d.canonical(), "index_replicated_per_gpu": sharded is None, "sharded": args.sharded,
                        "positive_fraction_found": round(found, 4), "device_index_bytes": d.device_bytes(local_rank),
                        "device_bytes_per_kmer": round(d.device_bytes(local_rank) / d.num_kmers(), 2),
                        "device_stats": stats},
@@ -353,6 +388,14 @@ def main():
     barrier()
     if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)  # the C library's own buffer of stdout (RCCL's banner sits there until exit)
+    except Exception:
+        pass
+    os.dup2(json_fd, 1)
     if rank == 0:
         print(json.dumps(result), flush=True)
 
