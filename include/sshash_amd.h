@@ -116,9 +116,15 @@ sshash_status sshash_to_device(sshash_dict* d, int device);
  * of another shard takes the complete path). Everything else is resident in full. */
 sshash_status sshash_to_device_table_shard(sshash_dict* d, int device, uint32_t num_table_shards, uint32_t table_shard_id);
 sshash_status sshash_device_bytes(const sshash_dict* d, int device, uint64_t* bytes);
-/* out = {bytes in HBM, minimizer-directory sectors (0 = disabled), sectors flagged overflow, keys in the directory,
- *        super-k-mer table slots (0 = disabled), its keys, keys held inline, keys left to the complete path} */
-sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out[8]);
+/* out = { [0] bytes in HBM, [1] minimizer-directory sectors (0 = disabled), [2] sectors flagged overflow, [3] keys in the
+ *         directory, [4] super-k-mer table slots (0 = no table), [5] its keys, [6] keys held inline (<= 4 occurrences),
+ *         [7] items left to the complete path (no free slot in any of their buckets), [8] slots in use (load factor =
+ *         [8] / [4]), [9] heavy keys (a marker + one slot per k-mer), [10] k-mers entered one by one, [11] why there is no
+ *         table: 0 = there is one, 1 = disabled (SSHASH_AMD_SKTABLE=0), 2 = minimizer shard (keeps the directory path),
+ *         3 = more than 2^39 bases, 4 = more items than one build pass holds (2^31 super-k-mers), 5 = not enough free HBM
+ *         -- in all these cases lookups take the directory / MPHF path, about half as fast --, [12] bytes of the table,
+ *         [13..15] reserved } */
+sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out[16]);
 
 /* ---- dictionary::lookup(Kmer, bool) / lookup(char const*, bool): include/dictionary.hpp:41-42,
  *      src/dictionary.cpp:58-78. Batched. ------------------------------------------------------

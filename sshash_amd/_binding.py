@@ -145,7 +145,7 @@ def _load() -> C.CDLL:
         "sshash_to_device": (C.c_int, [P, C.c_int]),
         "sshash_to_device_table_shard": (C.c_int, [P, C.c_int, C.c_uint32, C.c_uint32]),
         "sshash_device_bytes": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64)]),
-        "sshash_device_stats": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64 * 8)]),
+        "sshash_device_stats": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64 * 16)]),
         "sshash_sharded_lookup_device": (C.c_int, [P, C.c_int, C.c_uint32, C.c_int, P, C.c_uint64, C.c_int, P, C.POINTER(_Exchange), P]),
         "sshash_sharded_lookup_rccl": (C.c_int, [P, C.c_int, P, C.c_int, P, C.c_uint64, C.c_int, P, P]),
         "sshash_streaming_lookup_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, C.c_uint64, C.POINTER(_Results), P, P]),
@@ -345,13 +345,16 @@ class Dictionary:
         return int(out.value)
 
     def device_stats(self, device: int = 0) -> dict:
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         _check(_load().sshash_device_stats(self._h, int(device), C.byref(out)))
+        reasons = {0: None, 1: "disabled", 2: "minimizer shard", 3: "more than 2^39 bases", 4: "too many items for one build pass",
+                   5: "not enough free HBM"}
         return {"bytes": int(out[0]), "directory_sectors": int(out[1]), "directory_overflow_sectors": int(out[2]),
                 "directory_keys": int(out[3]), "sk_slots": int(out[4]), "sk_keys": int(out[5]), "sk_inline_keys": int(out[6]),
-                "sk_deferred_keys": int(out[7])}
+                "sk_deferred_keys": int(out[7]), "sk_slots_used": int(out[8]), "sk_heavy_keys": int(out[9]),
+                "sk_heavy_kmers": int(out[10]), "sk_absent_reason": reasons.get(int(out[11]), str(int(out[11]))),
+                "sk_bytes": int(out[12]), "sk_load_factor": round(int(out[8]) / int(out[4]), 4) if int(out[4]) else 0.0}
 
-    # ---- lookups ---------------------------------------------------------------------------
     def _as_batch(self, kmers: KmerBatch):
         """-> (is_ascii, contiguous ndarray, n)"""
         if isinstance(kmers, (str, bytes)):

@@ -174,7 +174,7 @@ sshash_status sshash_device_bytes(const sshash_dict* d, int device, uint64_t* by
     return guarded([&] { *bytes = d->eng->device_bytes(device); });
 }
 
-sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out[8]) {
+sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out[16]) {
     if (!d || !out) return fail(SSHASH_ERR_ARGUMENT, "null argument");
     return guarded([&] { d->eng->device_stats(device, out); });
 }
@@ -292,13 +292,10 @@ sshash_status sshash_access_packed(const sshash_dict* d, const uint64_t* kmer_id
     return guarded([&] {
         const uint32_t W = d->idx->words_per_kmer();
         const uint32_t nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-        std::string err;
+        /* an id >= num_kmers throws inside a worker: parallel_ranges hands the first exception back to this thread */
         detail::parallel_ranges(n, n >= 4096 ? nt : 1, [&](uint64_t b, uint64_t e, uint32_t) {
-            try {
-                for (uint64_t i = b; i < e; ++i) access_kmer_packed(*d->idx, kmer_ids[i], out_words + i * W);
-            } catch (std::exception const& ex) { err = ex.what(); }
+            for (uint64_t i = b; i < e; ++i) access_kmer_packed(*d->idx, kmer_ids[i], out_words + i * W);
         });
-        if (!err.empty()) throw error(error_kind::argument, err);
     });
 }
 

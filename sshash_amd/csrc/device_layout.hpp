@@ -167,6 +167,9 @@ static_assert(SK_CHOICES == 4, "sk_hash and sk_choice spell out four choices");
 constexpr uint32_t SK_INLINE_MAX = 4;         // a key with up to this many occurrences holds one inline slot per occurrence;
                                               // a heavier key holds a marker and its k-mers are keyed one by one
 constexpr double SK_SLOTS_PER_KEY = 2.0;
+/* why a replica was given no table (sshash_device_stats) */
+constexpr uint32_t SK_ABSENT_DISABLED = 1, SK_ABSENT_MINIMIZER_SHARD = 2, SK_ABSENT_TOO_MANY_BASES = 3, SK_ABSENT_TOO_MANY_ITEMS = 4,
+                   SK_ABSENT_NO_MEMORY = 5;
 
 struct sk_view {
     void const* slots;    // num_buckets x 2 slots of 32 bytes (k <= 31) or of 64 bytes (k <= 63)

@@ -150,6 +150,7 @@ engine::engine(std::shared_ptr<host_index> idx) : m_idx(std::move(idx)) {}
 engine::~engine() = default;
 
 bool engine::on_device(int device) const {
+    std::shared_lock<std::shared_mutex> lock(m_replicas_mutex);
     for (auto const& r : m_replicas)
         if (r->device == device) return true;
     return false;
@@ -157,13 +158,14 @@ bool engine::on_device(int device) const {
 
 std::vector<int> engine::devices() const {
     std::vector<int> d;
+    std::shared_lock<std::shared_mutex> lock(m_replicas_mutex);
     for (auto const& r : m_replicas) d.push_back(r->device);
     return d;
 }
 
 uint64_t engine::device_bytes(int device) const { return replica(device)->bytes; }
 
-void engine::device_stats(int device, uint64_t out[8]) const {
+void engine::device_stats(int device, uint64_t out[16]) const {
     device_replica const* r = replica(device);
     out[0] = r->bytes;
     out[1] = r->view.directory.enabled ? r->view.directory.num_buckets : 0;
@@ -173,9 +175,16 @@ void engine::device_stats(int device, uint64_t out[8]) const {
     out[5] = r->sk_keys;
     out[6] = r->sk_keys - r->sk_heavy_keys;
     out[7] = r->sk_unplaced;
+    out[8] = r->sk_slots_used;
+    out[9] = r->sk_heavy_keys;
+    out[10] = r->sk_heavy_kmers;
+    out[11] = r->view.sk.enabled ? 0 : r->sk_absent_reason;
+    out[12] = r->sk_bytes;
+    out[13] = out[14] = out[15] = 0;
 }
 
 device_replica const* engine::replica(int device) const {
+    std::shared_lock<std::shared_mutex> lock(m_replicas_mutex);
     for (auto const& r : m_replicas)
         if (r->device == device) return r.get();
     throw error(error_kind::no_device, "dictionary is not resident on device " + std::to_string(device) +
@@ -183,8 +192,19 @@ device_replica const* engine::replica(int device) const {
 }
 
 void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_id) {
-    if (on_device(device)) return;
     if (table_shards == 0 || table_shard_id >= table_shards) throw error(error_kind::argument, "table shard id must be < number of table shards");
+    std::lock_guard<std::mutex> one_upload_at_a_time(m_upload_mutex);
+    {
+        std::shared_lock<std::shared_mutex> lock(m_replicas_mutex);
+        for (auto const& r : m_replicas) {
+            if (r->device != device) continue;
+            if (r->view.sk.num_shards != table_shards || r->view.sk.shard_id != table_shard_id)
+                throw error(error_kind::argument, "the dictionary is already resident on device " + std::to_string(device) +
+                                                      " with another table sharding (" + std::to_string(r->view.sk.shard_id) + " of " +
+                                                      std::to_string(r->view.sk.num_shards) + ")");
+            return;
+        }
+    }
     const int count = visible_device_count();
     if (count == 0) throw error(error_kind::no_device, "no HIP device visible: the lookup path requires an MI355X (no CPU fallback)");
     if (device < 0 || device >= count) throw error(error_kind::no_device, "invalid device ordinal " + std::to_string(device));
@@ -306,6 +326,7 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
         v.weight_values = rep->put(idx.weight_values);
     }
     build_sk_table(*rep, idx, table_shards, table_shard_id);
+    std::unique_lock<std::shared_mutex> lock(m_replicas_mutex);
     m_replicas.push_back(std::move(rep));
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 
 #include <memory>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -42,7 +44,7 @@ public:
     uint64_t device_bytes(int device) const;
     /* {bytes in HBM, directory sectors, directory sectors flagged overflow, keys held by the directory,
         super-k-mer table slots (0 = disabled), its keys, its inline keys, its keys left to the complete path} */
-    void device_stats(int device, uint64_t out[8]) const;
+    void device_stats(int device, uint64_t out[16]) const;
 
     /* Device-pointer entry points: queries and outputs already live in the HBM of `device`;
        the launch is asynchronous on `stream` (a hipStream_t, may be null = default stream).
@@ -123,6 +125,9 @@ public:
 
 private:
     std::shared_ptr<host_index> m_idx;
+    /* to_device may run while other host threads query: readers share, the upload's final push_back is exclusive */
+    mutable std::shared_mutex m_replicas_mutex;
+    std::mutex m_upload_mutex;
     std::vector<std::unique_ptr<device_replica>> m_replicas;
 };
 

@@ -10,6 +10,8 @@
 #include <atomic>
 #include <cstring>
 #include <stdexcept>
+#include <mutex>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -180,6 +182,8 @@ inline part_build_result build_partition(std::vector<hash128> const& hashes,
     return res;
 }
 
+/* Workers are raw std::threads: an exception leaving one would terminate the process. The first one thrown is
+   kept and rethrown on the calling thread once all workers have joined; the others stop at their next item. */
 template <typename Fn>
 inline void parallel_for(uint64_t n, uint32_t num_threads, Fn&& fn) {
     if (num_threads <= 1 || n <= 1) {
@@ -187,18 +191,28 @@ inline void parallel_for(uint64_t n, uint32_t num_threads, Fn&& fn) {
         return;
     }
     std::atomic<uint64_t> next{0};
+    std::atomic<bool> failed{false};
+    std::exception_ptr first;
+    std::mutex guard;
     std::vector<std::thread> pool;
     const uint32_t nt = uint32_t(std::min<uint64_t>(num_threads, n));
     for (uint32_t t = 0; t < nt; ++t) {
         pool.emplace_back([&] {
-            for (;;) {
-                const uint64_t i = next.fetch_add(1);
-                if (i >= n) break;
-                fn(i);
+            try {
+                for (;;) {
+                    const uint64_t i = next.fetch_add(1);
+                    if (i >= n || failed.load(std::memory_order_relaxed)) break;
+                    fn(i);
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> lock(guard);
+                if (!first) first = std::current_exception();
+                failed = true;
             }
         });
     }
     for (auto& th : pool) th.join();
+    if (first) std::rethrow_exception(first);
 }
 
 /* [begin,end) ranges, one per thread */
@@ -210,12 +224,19 @@ inline void parallel_ranges(uint64_t n, uint32_t num_threads, Fn&& fn) {
         return;
     }
     std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> thrown(nt);
     const uint64_t chunk = (n + nt - 1) / nt;
     for (uint32_t t = 0; t < nt; ++t) {
         const uint64_t b = std::min(n, t * chunk), e = std::min(n, b + chunk);
-        pool.emplace_back([=, &fn] { fn(b, e, t); });
+        pool.emplace_back([=, &fn, &thrown] {
+            try {
+                fn(b, e, t);
+            } catch (...) { thrown[t] = std::current_exception(); }
+        });
     }
     for (auto& th : pool) th.join();
+    for (auto const& e : thrown)
+        if (e) std::rethrow_exception(e);
 }
 
 }  // namespace detail

@@ -46,7 +46,8 @@ struct device_replica {
     skew_part_dev* d_skew = nullptr;
     uint64_t directory_overflowed = 0;  // sectors carrying the overflow flag
     uint64_t directory_entries = 0;     // keys resident in the directory
-    uint64_t sk_keys = 0, sk_heavy_keys = 0, sk_heavy_kmers = 0, sk_unplaced = 0, sk_slots_used = 0;  // super-k-mer table
+    uint64_t sk_keys = 0, sk_heavy_keys = 0, sk_heavy_kmers = 0, sk_unplaced = 0, sk_slots_used = 0, sk_bytes = 0;  // super-k-mer table
+    uint32_t sk_absent_reason = 1;  // SK_ABSENT_* (0 = the table is there)
     std::vector<void*> allocations;
 
     /* Per-stream scratch for the deferred-query queue of the two-phase lookup. Work on one stream is

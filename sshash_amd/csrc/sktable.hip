@@ -19,6 +19,7 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "replica.hpp"
@@ -281,6 +282,13 @@ struct temp_buffers {  // freed on every exit path
 
 }  // namespace
 
+/* why a replica has no table (device_stats; sshash_device_stats out[11]): lookups then take the directory / MPHF path,
+   about half as fast -- never silently: the caller can see it */
+static void absent(device_replica& rep, uint32_t reason) {
+    rep.sk_absent_reason = reason;
+    if (std::getenv("SSHASH_AMD_VERBOSE")) fprintf(stderr, "[sshash_amd] device %d: no super-k-mer table (reason %u, sshash_amd.h)\n", rep.device, reason);
+}
+
 void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_shards, uint32_t table_shard_id) {
     dict_view& v = rep.view;
     v.sk.slots = nullptr;
@@ -289,15 +297,15 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     v.sk.num_shards = table_shards;  // read by the scan kernel's filter
     v.sk.shard_id = table_shard_id;
     const char* env = std::getenv("SSHASH_AMD_SKTABLE");
-    if (env && env[0] == '0') return;
-    if (idx.num_shards > 1 || idx.num_kmers == 0) return;  // a shard holds only its own minimizers' buckets: keep its path
-    if (idx.num_bases >= (uint64_t(1) << 39)) return;                       // positions are stored in 40 bits with a strand bit
+    if (env && env[0] == '0') return absent(rep, SK_ABSENT_DISABLED);
+    if (idx.num_shards > 1 || idx.num_kmers == 0) return absent(rep, SK_ABSENT_MINIMIZER_SHARD);  // a shard holds only its own minimizers' buckets: keep its path
+    if (idx.num_bases >= (uint64_t(1) << 39)) return absent(rep, SK_ABSENT_TOO_MANY_BASES);  // positions are stored in 40 bits with a strand bit
 
     const uint64_t positions = idx.num_bases - idx.k + 1;
     const uint64_t num_waves = (positions + 1 + NEW_PER_WAVE - 1) / NEW_PER_WAVE;
     const uint64_t threads = num_waves * WAVE;
     const dim3 block(256), grid(uint32_t((threads + 255) / 256));
-    if (threads >= (uint64_t(1) << 32) || num_waves >= (uint64_t(1) << 31)) return;  // one launch, and hipCUB item counts are int
+    if (threads >= (uint64_t(1) << 32) || num_waves >= (uint64_t(1) << 31)) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);  // one launch, and hipCUB item counts are int
 
     temp_buffers tmp;
     uint32_t* counts = tmp.alloc<uint32_t>(num_waves);
@@ -320,7 +328,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     HIP_CHECK(hipMemcpy(&last_offset, offsets + (num_waves - 1), 8, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(&last_count, counts + (num_waves - 1), 4, hipMemcpyDeviceToHost));
     const uint64_t T = last_offset + last_count;  // super-k-mers
-    if (T == 0 || T >= (uint64_t(1) << 31)) return;
+    if (T == 0 || T >= (uint64_t(1) << 31)) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);
 
     uint64_t* keys = tmp.alloc<uint64_t>(T);
     uint64_t* vals = tmp.alloc<uint64_t>(T);
@@ -360,7 +368,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
         const double want = std::atof(e);
         if (want >= 1.2 && want <= 16.0) slots_per_key = want;
     }
-    if (K == 0) return;
+    if (K == 0) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);
     uint32_t* run_begins = tmp.alloc<uint32_t>(K);
     {
         size_t bytes = 0;
@@ -398,7 +406,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     unsigned long long h_stats[8];
     HIP_CHECK(hipMemcpy(h_stats, stats, 64, hipMemcpyDeviceToHost));
     const uint64_t heavy_keys = h_stats[4], heavy_occurrences = h_stats[5], heavy_kmers = h_stats[6];
-    if (heavy_kmers >= (uint64_t(1) << 31)) return;
+    if (heavy_kmers >= (uint64_t(1) << 31)) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);
     uint64_t* kmer_keys = tmp.alloc<uint64_t>(heavy_kmers);
     uint64_t* kmer_vals = tmp.alloc<uint64_t>(heavy_kmers);
     if (heavy_kmers) {
@@ -411,11 +419,11 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     const uint64_t num_buckets = uint64_t(double(wanted) * slots_per_key / SK_BUCKET_SLOTS) + 8;
     const uint64_t num_slots = num_buckets * SK_BUCKET_SLOTS;
     const uint64_t slot_bytes = wide ? 64 : 32;
-    if (num_buckets >= (uint64_t(1) << 32)) return;
+    if (num_buckets >= (uint64_t(1) << 32)) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);
     {
         size_t free_bytes = 0, total_bytes = 0;
         HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
-        if (num_slots * slot_bytes > free_bytes / 2) return;  // leave HBM for the caller's batches
+        if (num_slots * slot_bytes > free_bytes / 2) return absent(rep, SK_ABSENT_NO_MEMORY);  // leave HBM for the caller's batches
     }
     uint32_t* slots = tmp.alloc<uint32_t>(num_slots * slot_bytes / 4);
     uint8_t* placed = tmp.alloc<uint8_t>(T + heavy_kmers);
@@ -447,6 +455,8 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     rep.sk_heavy_kmers = heavy_kmers;
     rep.sk_unplaced = h_stats[2];
     rep.sk_slots_used = h_stats[3];
+    rep.sk_bytes = num_slots * slot_bytes;
+    rep.sk_absent_reason = 0;
     v.sk.slots = slots;
     v.sk.num_buckets = uint32_t(num_buckets);
     v.sk.enabled = 1;

@@ -355,7 +355,7 @@ stream_classify_kernel(const uint8_t* __restrict__ flags, const uint64_t total_b
 void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t const* d_read_offsets, uint64_t n_reads,
                                      uint64_t total_bases, result_view const& d_out, uint64_t* d_report, void* stream) const {
     device_replica const* rep = replica(device);
-    if (!d_out.kmer_id) throw error(error_kind::argument, "kmer_id output pointer is null");
+    if (!d_out.kmer_id && !d_report) throw error(error_kind::argument, "neither a kmer_id array nor a report to fill");
     if (d_out.minimizer_found) throw error(error_kind::argument, "the streaming lookup does not report minimizer_found");
     if (n_reads == 0 || total_bases == 0) return;
     device_guard guard(device);
@@ -367,11 +367,14 @@ void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t c
     uint64_t* kmers = nullptr;
     uint64_t* sid = d_out.string_id;
     int8_t* ori = d_out.kmer_orientation;
+    uint64_t* ids = d_out.kmer_id;  // null: counters only (streaming_query_host over reads too long for one lane each)
+    if (!ids) HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&ids), total_bases * sizeof(uint64_t), s));
     HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&flags), total_bases, s));
     HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&kmers), chunk * W * sizeof(uint64_t), s));
     if (!sid) HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&sid), total_bases * sizeof(uint64_t), s));
     if (!ori) HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&ori), total_bases, s));
     result_view all = d_out;
+    all.kmer_id = ids;
     all.string_id = sid;
     all.kmer_orientation = ori;
     for (uint64_t first = 0; first < total_bases; first += chunk) {
@@ -393,7 +396,7 @@ void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t c
     for (uint64_t first = 0; first < total_bases; first += uint64_t(1) << 30) {
         const uint64_t count = std::min<uint64_t>(uint64_t(1) << 30, total_bases - first);
         result_view part = d_out;
-        part.kmer_id += first;
+        part.kmer_id = ids + first;
         if (part.kmer_id_in_string) part.kmer_id_in_string += first;
         if (part.kmer_offset) part.kmer_offset += first;
         if (part.string_id) part.string_id += first;
@@ -404,6 +407,7 @@ void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t c
                            sid + first, ori + first, d_report);
         HIP_CHECK(hipGetLastError());
     }
+    if (!d_out.kmer_id) HIP_CHECK(hipFreeAsync(ids, s));
     if (!d_out.kmer_orientation) HIP_CHECK(hipFreeAsync(ori, s));
     if (!d_out.string_id) HIP_CHECK(hipFreeAsync(sid, s));
     HIP_CHECK(hipFreeAsync(kmers, s));
@@ -499,6 +503,8 @@ streaming_report engine::streaming_lookup_host(char const* bases, uint64_t const
 /* Host buffers: the reads are cut into pieces of at most ~32 MiB of bases; per replica up to eight lanes (the
    pooled pinned pipelines of the lookup host path, replica.hpp) pull pieces from a shared counter and run
    copy-in -> H2D -> kernel, accumulating the six counters in device memory; one read-back per lane. */
+constexpr uint64_t LONG_READ_BASES = uint64_t(1) << 16;
+
 streaming_report engine::streaming_query_host(char const* bases, uint64_t const* read_offsets, uint64_t n_reads) const {
     streaming_report total;
     if (n_reads == 0) return total;
@@ -556,7 +562,12 @@ streaming_report engine::streaming_query_host(char const* bases, uint64_t const*
                 std::memcpy(hp + bases_at, bases + read_offsets[first], nb);
                 HIP_CHECK(hipMemcpyAsync(dp, hp, (last - first + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
                 HIP_CHECK(hipMemcpyAsync(dp + bases_at, hp + bases_at, nb, hipMemcpyHostToDevice, s));
-                streaming_query_device(device, dp + bases_at, reinterpret_cast<uint64_t const*>(dp), last - first, nb, d_report, s);
+                /* one lane walks one read: a read of megabases (a contig, a multiline FASTA record) would keep a single
+                   lane busy for minutes; such pieces go through the position-parallel pipeline, which gives the same counters */
+                bool long_read = false;
+                for (uint64_t i = first; i < last && !long_read; ++i) long_read = read_offsets[i + 1] - read_offsets[i] > LONG_READ_BASES;
+                if (long_read) streaming_lookup_device(device, dp + bases_at, reinterpret_cast<uint64_t const*>(dp), last - first, nb, result_view{}, d_report, s);
+                else streaming_query_device(device, dp + bases_at, reinterpret_cast<uint64_t const*>(dp), last - first, nb, d_report, s);
                 HIP_CHECK(hipStreamSynchronize(s));  // the pinned block is reused by the next piece
             }
             uint64_t h[6];

@@ -170,3 +170,17 @@ def test_streaming_lookup_device_leaves_other_places_untouched(case_se_regular):
         assert (got[lo:lo + n] == want).all()
         assert (got[lo + n:int(offsets[i + 1])] == 12345).all()  # no k-mer starts there
     assert int(rep[0].item()) == expect_kmers and int(rep[1].item()) == expect_kmers  # all positive
+
+
+def test_counters_of_reads_too_long_for_one_lane(case_se_regular):
+    """a contig-sized read used to run on ONE lane (one dependent HBM read per k-mer, for minutes). Pieces
+    holding a read of more than 2^16 bases now go through the position-parallel pipeline: same six counters."""
+    case = case_se_regular
+    d = case.dict.to_device(0)
+    rng = np.random.default_rng(8)
+    contig = "N".join(case.sequences[i] for i in rng.integers(0, len(case.sequences), 60))  # ~450 kbases
+    assert len(contig) > (1 << 16)
+    reads = [contig, case.sequences[3][:100], random_dna(rng, 80), contig[1000:200000].lower()]
+    got = _as_dict(d.streaming_query(reads))
+    assert got == case.oracle.streaming_query(reads)
+    assert got["num_extensions"] > 100000 and got["num_invalid_kmers"] > 0
