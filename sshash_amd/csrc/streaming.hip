@@ -306,34 +306,39 @@ stream_encode_kernel(const char* __restrict__ bases, const uint64_t* __restrict_
 
 __global__ void __launch_bounds__(256)
 stream_classify_kernel(const uint8_t* __restrict__ flags, const uint64_t total_bases, const result_view out,
-                       const uint64_t* __restrict__ string_id, const int8_t* __restrict__ orientation, uint64_t* __restrict__ report) {
-    const uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+                       const uint64_t* string_id, const int8_t* orientation /* may be out's own arrays */, uint64_t* __restrict__ report) {
+    /* grid-stride: the six counters are accumulated in registers and reach `report` once per wave -- one hot set of
+       atomics per wave of 64 k-mers would serialise at ~90 atomics/us */
     uint64_t c_kmer = 0, c_invalid = 0, c_negative = 0, c_search = 0, c_extension = 0;
-    const uint8_t f = p < total_bases ? flags[p] : 0;
-    if (f & SQ_INVALID) {
-        /* what streaming_query::lookup returns after its reset(): a default lookup_result (include/util.hpp:38-62) */
-        c_kmer = c_invalid = 1;
-        out.kmer_id[p] = INVALID_U64;
-        if (out.kmer_id_in_string) out.kmer_id_in_string[p] = INVALID_U64;
-        if (out.kmer_offset) out.kmer_offset[p] = INVALID_U64;
-        if (out.string_id) out.string_id[p] = INVALID_U64;
-        if (out.string_begin) out.string_begin[p] = INVALID_U64;
-        if (out.string_end) out.string_end[p] = INVALID_U64;
-        if (out.kmer_orientation) out.kmer_orientation[p] = 1;
-    } else if (f & SQ_VALID) {
-        c_kmer = 1;
-        const uint64_t id = out.kmer_id[p];
-        if (id == INVALID_U64) {
-            c_negative = 1;
-        } else {
-            bool extension = false;
-            if (!(f & SQ_FIRST) && (flags[p - 1] & SQ_VALID)) {
-                const uint64_t before = out.kmer_id[p - 1];
-                extension = before != INVALID_U64 && string_id[p - 1] == string_id[p] &&
-                            id == before + uint64_t(int64_t(orientation[p - 1]));
+    const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
+    for (uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < total_bases; p += stride) {
+        const uint8_t f = flags[p];
+        if (f & SQ_INVALID) {
+            /* what streaming_query::lookup returns after its reset(): a default lookup_result (include/util.hpp:38-62) */
+            ++c_kmer;
+            ++c_invalid;
+            out.kmer_id[p] = INVALID_U64;
+            if (out.kmer_id_in_string) out.kmer_id_in_string[p] = INVALID_U64;
+            if (out.kmer_offset) out.kmer_offset[p] = INVALID_U64;
+            if (out.string_id) out.string_id[p] = INVALID_U64;
+            if (out.string_begin) out.string_begin[p] = INVALID_U64;
+            if (out.string_end) out.string_end[p] = INVALID_U64;
+            if (out.kmer_orientation) out.kmer_orientation[p] = 1;
+        } else if (f & SQ_VALID) {
+            ++c_kmer;
+            const uint64_t id = out.kmer_id[p];
+            if (id == INVALID_U64) {
+                ++c_negative;
+            } else {
+                bool extension = false;
+                if (!(f & SQ_FIRST) && (flags[p - 1] & SQ_VALID)) {
+                    const uint64_t before = out.kmer_id[p - 1];
+                    extension = before != INVALID_U64 && string_id[p - 1] == string_id[p] &&
+                                id == before + uint64_t(int64_t(orientation[p - 1]));
+                }
+                c_extension += extension;
+                c_search += !extension;
             }
-            c_extension = extension;
-            c_search = !extension;
         }
     }
     if (!report) return;
@@ -403,7 +408,7 @@ void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t c
         if (part.string_begin) part.string_begin += first;
         if (part.string_end) part.string_end += first;
         if (part.kmer_orientation) part.kmer_orientation += first;
-        hipLaunchKernelGGL(stream_classify_kernel, dim3(uint32_t((count + 255) / 256)), dim3(256), 0, s, flags + first, count, part,
+        hipLaunchKernelGGL(stream_classify_kernel, dim3(uint32_t(std::min<uint64_t>((count + 255) / 256, 8192))), dim3(256), 0, s, flags + first, count, part,
                            sid + first, ori + first, d_report);
         HIP_CHECK(hipGetLastError());
     }

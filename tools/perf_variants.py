@@ -150,6 +150,18 @@ def main():
             nk = R * (L - k + 1)
             names = ["num_kmers", "num_positive_kmers", "num_negative_kmers", "num_invalid_kmers", "num_searches", "num_extensions"]
             report(f"streaming_{name}", ms, units=nk, unit="k-mers/s", reads=R, read_len=L, **dict(zip(names, counters)))
+            # the same reads with per-k-mer results (ids) out of the position-parallel pipeline
+            ids = torch.empty(R * L, dtype=torch.int64, device=dev)
+            rep2 = torch.zeros(6, dtype=torch.int64, device=dev)
+
+            def run_lookup():
+                rep2.zero_()
+                d.streaming_lookup_device(0, d_bases.data_ptr(), d_off.data_ptr(), R, R * L, ids.data_ptr(), d_report=rep2.data_ptr(), stream=stream)
+
+            ms2 = timed(run_lookup, reps=2)
+            assert rep2.cpu().numpy().tolist() == counters, (rep2.cpu().numpy().tolist(), counters)
+            report(f"streaming_lookup_per_kmer_results_{name}", ms2, units=nk, unit="k-mers/s", reads=R, read_len=L)
+            del ids
             # parity of the counters on a sample of reads
             sample = [bytes(reads[i]) for i in range(0, R, max(1, R // 2000))]
             want = O.OracleIndex(path).streaming_query(sample)
