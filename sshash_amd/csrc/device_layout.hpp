@@ -61,7 +61,7 @@
 //               strands, whatever the dictionary's own minimizer flavour. Built and probed with the same
 //               function, the table need not follow the reference's minimizer hash: it uses a 32-bit one;
 //        bucket one 64-byte line = the unit the memory system fetches (TCC_EA0_RDREQ is always a 64-byte request,
-//               profiles/r02/tlb_probe_counters.txt) = TWO 32-byte slots. A key lives in one of SK_CHOICES = 4
+//               profiles/r02/tlb_probe_counters.txt) = TWO 32-byte slots. A key lives in one of SK_CHOICES = 5
 //               hashed buckets, in the first of them that had a free slot when it was placed; two slots per key
 //               (load factor 0.5). The four lanes of a quad fetch the line of one of them together -- 16 bytes each,
 //               ONE load instruction, transposed through LDS (lookup_device.hpp) -- so that the memory pipeline sees
@@ -70,8 +70,8 @@
 //               translation cache covers, and the translation-request rate (75 G/s chip-wide), not DRAM, is what
 //               capped round 1's table at 38 G reads/s;
 //        slot   32 bytes:
-//                 d0  bit0 valid | bit1 marker | bit2 strand | bits 3-6 go-on flags of the BUCKET, one per choice
-//                     (kept in slot 0 only) | bits 8-13 left | bits 14-19 right
+//                 d0  bit0 valid | bit1 marker | bit2 strand | bits 3-7 go-on flags of the BUCKET, one per choice
+//                     (kept in slot 0 only) | bits 8-13 left | bits 14-19 right | bit 20 (slot 0 only) slot 1 is in use
 //                 d1  string id (marker: number of occurrences of the key)
 //                 d2,d3  position of the key occurrence (40 bits) | fingerprint of the key << 40
 //                 d4-d7  the 64 bases starting k-m bases before the occurrence, i.e. every k-mer of the super-k-mer
@@ -159,11 +159,12 @@ SSH_HD uint64_t directory_entry(uint64_t code, uint32_t fp) { return code | (uin
 /* ---- super-k-mer table (5) ---- */
 constexpr uint32_t SK_VALID = 1u, SK_MARKER = 2u, SK_STRAND = 4u;
 constexpr uint32_t SK_GO_ON = 8u;             // << c: a key whose choice c is this bucket lives at a later choice ...
-constexpr uint32_t SK_CHOICES = 4;            // ... or, for the last choice, in no slot at all (flags: bits 3-6 of slot 0)
+constexpr uint32_t SK_CHOICES = 5;            // ... or, for the last choice, in no slot at all (flags: bits 3-7 of slot 0)
 constexpr uint32_t SK_BUCKET_SLOTS = 2;       // slots per bucket: one 64-byte line at k <= 31
 constexpr uint32_t SK_LEFT_SHIFT = 8, SK_RIGHT_SHIFT = 14;
+constexpr uint32_t SK_SECOND_USED = 1u << 20;  // in slot 0: slot 1 of the bucket is in use (k <= 63: worth fetching its line)
 static_assert((SK_GO_ON << (SK_CHOICES - 1)) < (1u << SK_LEFT_SHIFT), "go-on flags must stay below the extent fields");
-static_assert(SK_CHOICES == 4, "sk_hash and sk_choice spell out four choices");
+static_assert(SK_CHOICES == 5, "sk_hash and sk_choice spell out five choices");
 constexpr uint32_t SK_INLINE_MAX = 4;         // a key with up to this many occurrences holds one inline slot per occurrence;
                                               // a heavier key holds a marker and its k-mers are keyed one by one
 constexpr double SK_SLOTS_PER_KEY = 2.0;
@@ -205,6 +206,7 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_buckets) {
     h.bucket[2] = mulhi32(uint32_t(b), num_buckets);
     const uint64_t c = (a + b) * 0xD6E8FEB86659FD93ULL;
     h.bucket[3] = mulhi32(uint32_t(c), num_buckets);
+    h.bucket[4] = mulhi32(uint32_t((c ^ (c >> 31)) * 0x9E3779B1u + uint32_t(a)), num_buckets);
     h.fingerprint = uint32_t(c >> 40);
     return h;
 }
@@ -235,37 +237,62 @@ SSH_HD uint32_t sk_mmer_hash(uint64_t mmer) {
     return uint32_t(mmer) * 0x9E3779B1u + (uint32_t(mmer >> 32) * 0x85EBCA77u + 0x27D4EB2Fu);
 }
 
+/* low 32 bits of (hi:lo) >> s, s in 0..31: one v_alignbit_b32 on the device (a 64-bit shift costs five times as much) */
+SSH_HD uint32_t funnel32(uint32_t lo, uint32_t hi, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+    return uint32_t(((uint64_t(hi) << 32) | lo) >> s);
+#endif
+}
+
 template <int W>
 SSH_HD sk_key_t sk_key(kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m) {
-    const uint64_t mask = low_mask(2 * m);
+    /* the k-mer as 32-bit words (16 bases each), two zero words behind it: the m-mer starting at base i = 16 j + t is
+       the 2m low bits of words j, j+1, j+2 shifted right by 2 t -- two funnel shifts instead of 64-bit (or 128-bit) shifts */
+    constexpr int D = 2 * W;
+    uint32_t f[D + 2], r[D + 2];
+    for (int j = 0; j < W; ++j) {
+        f[2 * j] = uint32_t(x.w[j]);
+        f[2 * j + 1] = uint32_t(x.w[j] >> 32);
+        r[2 * j] = uint32_t(x_rc.w[j]);
+        r[2 * j + 1] = uint32_t(x_rc.w[j] >> 32);
+    }
+    f[D] = f[D + 1] = r[D] = r[D + 1] = 0;
+    const uint32_t mask_lo = m >= 16 ? 0xFFFFFFFFu : (1u << (2 * m)) - 1;
+    const uint32_t mask_hi = m > 16 ? uint32_t(low_mask(2 * m) >> 32) : 0u;
     uint32_t best_f = 0xFFFFFFFFu, best_r = 0xFFFFFFFFu, pos_f = 0, pos_r = 0;
-    kmer_w<W> f = x, r = x_rc;
     const uint32_t n = k - m + 1;
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t hf = sk_mmer_hash(f.w[0] & mask), hr = sk_mmer_hash(r.w[0] & mask);
-        if (hf < best_f) {
-            best_f = hf;
-            pos_f = i;
-        }
-        if (hr < best_r) {
-            best_r = hr;
-            pos_r = i;
-        }
-        if constexpr (W == 1) {
-            f.w[0] >>= 2;
-            r.w[0] >>= 2;
-        } else {
-            f.w[0] = (f.w[0] >> 2) | (f.w[1] << 62);
-            f.w[1] >>= 2;
-            r.w[0] = (r.w[0] >> 2) | (r.w[1] << 62);
-            r.w[1] >>= 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < D; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 4
+#endif
+        for (uint32_t t = 0; t < 16; ++t) {
+            const uint32_t i = 16 * uint32_t(j) + t;
+            if (i >= n) break;
+            const uint32_t s = 2 * t;
+            const uint32_t hf = (funnel32(f[j], f[j + 1], s) & mask_lo) * 0x9E3779B1u +
+                                ((funnel32(f[j + 1], f[j + 2], s) & mask_hi) * 0x85EBCA77u + 0x27D4EB2Fu);
+            const uint32_t hr = (funnel32(r[j], r[j + 1], s) & mask_lo) * 0x9E3779B1u +
+                                ((funnel32(r[j + 1], r[j + 2], s) & mask_hi) * 0x85EBCA77u + 0x27D4EB2Fu);
+            if (hf < best_f) {
+                best_f = hf;
+                pos_f = i;
+            }
+            if (hr < best_r) {
+                best_r = hr;
+                pos_r = i;
+            }
         }
     }
     sk_key_t out;
     out.rc = best_r < best_f;
     out.tie = best_r == best_f;
     out.pos = out.rc ? pos_r : pos_f;
-    out.key = kmer_shr_chars<W>(out.rc ? x_rc : x, out.pos).w[0] & mask;
+    out.key = kmer_shr_chars<W>(out.rc ? x_rc : x, out.pos).w[0] & low_mask(2 * m);
     return out;
 }
 

@@ -408,7 +408,7 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
                    const uint8_t* __restrict__ lane_valid /* null, or bit 0 of entry i: place i holds a query */) {
     /* LDS: the ASCII tile (256 * k characters) and, afterwards, the staged bucket lines (64 * W bytes per lane) */
     constexpr uint32_t TILE_WORDS = ASCII ? 64 * (W == 1 ? 31 : 63) + 8 : 0;
-    constexpr uint32_t STAGE_WORDS = SK ? 256 * 16 * W : 0;
+    constexpr uint32_t STAGE_WORDS = SK ? 256 * 16 : 0;
     __shared__ uint4 lds[(TILE_WORDS > STAGE_WORDS ? TILE_WORDS : STAGE_WORDS) / 4 + 1];
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = i < n && (!lane_valid || (lane_valid[i] & 1));
@@ -455,7 +455,7 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
                                                              // serialise at ~90 atomics/us
     if constexpr (SK) {
         r = sk_first_pass_wave<W>(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1),
-                                  lds + (threadIdx.x >> 6) * (64 * 4 * W));
+                                  lds + (threadIdx.x >> 6) * (64 * 4));
         /* whatever needs a second dependent read joins the compacted second pass, with its packed k-mer (no lane leaves
            before this: the queue places are handed out per wave) */
         bool resume = active && r.outcome == FAST_CONTINUE;
@@ -499,7 +499,7 @@ constexpr uint32_t RESUME_PARTS = 4;
 template <int W, bool CANON, int MODE>
 __global__ void __launch_bounds__(256)
 resume_lookup_kernel(const dict_view d, const bool check_rc, const result_view out, uint8_t* __restrict__ member, const pass_queues q) {
-    __shared__ uint4 lds[256 * 4 * W];
+    __shared__ uint4 lds[256 * 4];
     const uint32_t shard = blockIdx.x & (DEFER_SHARDS - 1), part = blockIdx.x / DEFER_SHARDS;
     const uint32_t pushed = q.resume_counts[shard];
     const uint32_t total = pushed < q.resume_capacity ? pushed : q.resume_capacity;
@@ -508,11 +508,11 @@ resume_lookup_kernel(const dict_view d, const bool check_rc, const result_view o
         const bool active = j < total;
         const uint64_t at = uint64_t(shard) * q.resume_capacity + (active ? j : 0u);
         const uint32_t entry = q.resume_index[at];
-        const uint64_t i = entry & ((1u << RESUME_CHOICE_SHIFT) - 1);
+        const uint64_t i = entry & ((1u << RESUME_CHOICE_SHIFT) - 1);  // < 2^27: launch_piece_queries()
         kmer_w<W> x;
         for (int t = 0; t < W; ++t) x.w[t] = q.resume_kmers[at * W + t];
         const fast_t r = sk_second_pass_wave<W>(d, x, active, entry, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1),
-                                                lds + (threadIdx.x >> 6) * (64 * 4 * W));
+                                                lds + (threadIdx.x >> 6) * (64 * 4));
         if (!active) continue;
         if (r.outcome == FAST_DEFER) {
             q.defer_index[uint64_t(shard) * q.defer_capacity + atomicAdd(q.defer_counts + shard, 1u)] = uint32_t(i);

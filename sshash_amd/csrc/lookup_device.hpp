@@ -465,16 +465,22 @@ __device__ __forceinline__ kmer_w<W> kmer_pick(bool first, kmer_w<W> const& a, k
 
 /* c-th bucket of a key */
 __device__ __forceinline__ uint32_t sk_choice(sk_hash_t const& h, uint32_t c) {
-    return c == 0 ? h.bucket[0] : c == 1 ? h.bucket[1] : c == 2 ? h.bucket[2] : h.bucket[3];
+    return c == 0 ? h.bucket[0] : c == 1 ? h.bucket[1] : c == 2 ? h.bucket[2] : c == 3 ? h.bucket[3] : h.bucket[4];
 }
 
-/* One bucket (choice c of the sequence being followed) against one query. `piece(slot, i)` yields the i-th 16-byte
-   piece of a slot of the bucket -- out of LDS, where the quad staged the line, or out of global memory. Both slots
-   are compared in straight-line code (selects, no branch). Out: r (a hit), `go_on` (the bucket's flag for choice c),
-   `marker` (a slot says that the key is heavy: its k-mers are entered under keys of their own), `key_seen`. */
-template <int W, class Piece>
-__device__ __forceinline__ void sk_examine_bucket(dict_view const& d, sk_query_t<W> const Q, uint32_t c, Piece piece, fast_t& r,
-                                                  bool& key_seen, uint32_t& go_on, bool& marker) {
+/* What slot 0 of a bucket says about the bucket as a whole. */
+struct sk_bucket_flags {
+    uint32_t go_on;      // the bucket's flag for the choice being examined
+    bool second_used;    // slot 1 holds something (k <= 63: it lives in the bucket's second line)
+};
+
+/* One SLOT against one query. `piece(i)` yields the i-th 16-byte piece of the slot -- out of LDS, where the quad
+   staged the line, or out of global memory. Straight-line code (selects, no branch). FIRST: the slot is slot 0 of
+   its bucket and carries the bucket's flags. Out: r (a hit), `marker` (the slot says that the key is heavy: its
+   k-mers are entered under keys of their own), `key_seen`. */
+template <int W, bool FIRST, class Piece>
+__device__ __forceinline__ void sk_examine_slot(dict_view const& d, sk_query_t<W> const Q, uint32_t c, Piece piece, fast_t& r,
+                                                bool& key_seen, bool& marker, sk_bucket_flags& flags) {
     const uint32_t km = d.k - d.m;
     const uint32_t j = Q.j;
     /* values, not references into Q: a select between two members of a by-reference struct is compiled into an
@@ -484,51 +490,48 @@ __device__ __forceinline__ void sk_examine_bucket(dict_view const& d, sk_query_t
         y.w[t] = Q.y.w[t];
         y_rc.w[t] = Q.y_rc.w[t];
     }
-    go_on = 0;
-    marker = false;
-#pragma unroll
-    for (uint32_t slot = 0; slot < SK_BUCKET_SLOTS; ++slot) {
-        const uint4 q0 = piece(slot, 0), q1 = piece(slot, 1);
-        uint4 q2 = q1;
-        if constexpr (W == 2) q2 = piece(slot, 2);
-        const uint32_t meta = q0.x;
-        if (slot == 0) {
-            /* decided now, in its own register: hipcc 7.2 has been seen recycling a slot word that is only
-               consumed much later */
-            go_on = meta & (SK_GO_ON << c);
-            asm volatile("" : "+v"(go_on));
-        }
-        const bool valid = (meta & SK_VALID) != 0, is_marker = (meta & SK_MARKER) != 0;
-        const bool same_fingerprint = valid && (q0.w >> 8) == Q.fingerprint;
-        key_seen = key_seen || same_fingerprint;
-        marker = marker || (same_fingerprint && is_marker);
-        /* inline super-k-mer: the strings read the key forward (strand 0: y aligns, key at km - a)
-           or reverse-complemented (strand 1: rc(y) aligns, its copy of the key sits at km - j).
-           No fingerprint test: the k-mer comparison is the test. */
-        const uint64_t at = uint64_t(q0.z) | (uint64_t(q0.w & 0xFFu) << 32);
-        const bool o = (meta & SK_STRAND) != 0;
-        const uint32_t a = o ? j : km - j;
-        const uint64_t w0 = uint64_t(q1.x) | (uint64_t(q1.y) << 32), w1 = uint64_t(q1.z) | (uint64_t(q1.w) << 32);
-        kmer_w<W> cand;
-        if constexpr (W == 1) {
-            cand.w[0] = funnel_shr(w0, w1, 2 * a);
-        } else {
-            const uint64_t w2 = uint64_t(q2.x) | (uint64_t(q2.y) << 32), w3 = uint64_t(q2.z) | (uint64_t(q2.w) << 32);
-            const bool up = 2 * a >= 64;  // a <= 62: the k-mer starts in word 0 or 1
-            const uint32_t sh = (2 * a) & 63u;
-            const uint64_t e0 = up ? w1 : w0, e1 = up ? w2 : w1, e2 = up ? w3 : w2;
-            cand.w[0] = funnel_shr(e0, e1, sh);
-            cand.w[1] = funnel_shr(e1, e2, sh);
-        }
-        cand = kmer_take_chars<W>(cand, d.k);
-        const uint32_t left = (meta >> SK_LEFT_SHIFT) & 63u, right = (meta >> SK_RIGHT_SHIFT) & 63u;
-        const bool hit = valid && !is_marker && kmer_eq<W>(cand, kmer_pick<W>(o, y_rc, y)) && a + left >= km && a <= right;
-        /* a k-mer occurs once in the strings: at most one slot hits */
-        r.kmer_offset = hit ? at + a - km : r.kmer_offset;
-        r.string_id = hit ? q0.y : r.string_id;
-        r.orientation = hit ? ((o != Q.s) ? int8_t(-1) : int8_t(1)) : r.orientation;
-        r.outcome = hit ? int(FAST_HIT) : r.outcome;
+    const uint4 q0 = piece(0), q1 = piece(1);
+    uint4 q2 = q1;
+    if constexpr (W == 2) q2 = piece(2);
+    const uint32_t meta = q0.x;
+    if constexpr (FIRST) {
+        /* decided now, in its own register: hipcc 7.2 has been seen recycling a slot word that is only
+           consumed much later */
+        uint32_t go_on = meta & (SK_GO_ON << c);
+        asm volatile("" : "+v"(go_on));
+        flags.go_on = go_on;
+        flags.second_used = (meta & SK_SECOND_USED) != 0;
     }
+    const bool valid = (meta & SK_VALID) != 0, is_marker = (meta & SK_MARKER) != 0;
+    const bool same_fingerprint = valid && (q0.w >> 8) == Q.fingerprint;
+    key_seen = key_seen || same_fingerprint;
+    marker = marker || (same_fingerprint && is_marker);
+    /* inline super-k-mer: the strings read the key forward (strand 0: y aligns, key at km - a)
+       or reverse-complemented (strand 1: rc(y) aligns, its copy of the key sits at km - j).
+       No fingerprint test: the k-mer comparison is the test. */
+    const uint64_t at = uint64_t(q0.z) | (uint64_t(q0.w & 0xFFu) << 32);
+    const bool o = (meta & SK_STRAND) != 0;
+    const uint32_t a = o ? j : km - j;
+    const uint64_t w0 = uint64_t(q1.x) | (uint64_t(q1.y) << 32), w1 = uint64_t(q1.z) | (uint64_t(q1.w) << 32);
+    kmer_w<W> cand;
+    if constexpr (W == 1) {
+        cand.w[0] = funnel_shr(w0, w1, 2 * a);
+    } else {
+        const uint64_t w2 = uint64_t(q2.x) | (uint64_t(q2.y) << 32), w3 = uint64_t(q2.z) | (uint64_t(q2.w) << 32);
+        const bool up = 2 * a >= 64;  // a <= 62: the k-mer starts in word 0 or 1
+        const uint32_t sh = (2 * a) & 63u;
+        const uint64_t e0 = up ? w1 : w0, e1 = up ? w2 : w1, e2 = up ? w3 : w2;
+        cand.w[0] = funnel_shr(e0, e1, sh);
+        cand.w[1] = funnel_shr(e1, e2, sh);
+    }
+    cand = kmer_take_chars<W>(cand, d.k);
+    const uint32_t left = (meta >> SK_LEFT_SHIFT) & 63u, right = (meta >> SK_RIGHT_SHIFT) & 63u;
+    const bool hit = valid && !is_marker && kmer_eq<W>(cand, kmer_pick<W>(o, y_rc, y)) && a + left >= km && a <= right;
+    /* a k-mer occurs once in the strings: at most one slot hits */
+    r.kmer_offset = hit ? at + a - km : r.kmer_offset;
+    r.string_id = hit ? q0.y : r.string_id;
+    r.orientation = hit ? ((o != Q.s) ? int8_t(-1) : int8_t(1)) : r.orientation;
+    r.outcome = hit ? int(FAST_HIT) : r.outcome;
 }
 
 /* Where a probe stands: the bucket sequence it follows (its key's, or -- once it has met its key's marker -- its
@@ -605,10 +608,13 @@ __device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& 
 #pragma unroll 1
     while (more) {
         const uint4* B = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(sk_choice(w.h, w.c));
-        uint32_t go_on;
-        bool marker, seen = false;
-        sk_examine_bucket<W>(d, Q, w.c, [B](uint32_t slot, uint32_t i) { return B[slot * (2 * W) + i]; }, r, seen, go_on, marker);
+        sk_bucket_flags flags;
+        bool marker = false, seen = false;
+        sk_examine_slot<W, true>(d, Q, w.c, [B](uint32_t i) { return B[i]; }, r, seen, marker, flags);
+        if (r.outcome == FAST_MISS && flags.second_used)
+            sk_examine_slot<W, false>(d, Q, w.c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags);
         key_seen = key_seen || (seen && !w.on_kmer_sequence);
+        const uint32_t go_on = flags.go_on;
         more = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
     }
     return r;
@@ -643,51 +649,82 @@ __device__ __forceinline__ uint32_t quad_broadcast(uint32_t v) {
    the wait before DS reads it believes unrelated (glds_check: 91 % stale reads) -- the explicit wait below covers that --
    and presumably takes further liberties of the same origin that were not pinned down. The register path uses nothing
    the compiler does not fully model; every parity test passes on it, three runs in a row, without any guard. */
-template <int W, int P>
-__device__ __forceinline__ void sk_stage_round_dma(char const* __restrict__ slots, uint32_t bucket_of_owner, uint32_t sub, uint4* wave_stage) {
-    constexpr int LINE = P >> 2;
-    __builtin_amdgcn_global_load_lds((sk_global_ptr)(slots + uint64_t(bucket_of_owner) * (64 * W) + 64 * LINE + 16 * sub),
-                                     (sk_lds_ptr)(wave_stage + P * 64), 16, 0, 0);
+template <int P>
+__device__ __forceinline__ void sk_stage_round_dma(char const* __restrict__ line_of_owner_base, uint64_t line_offset, uint32_t sub, uint4* wave_stage) {
+    __builtin_amdgcn_global_load_lds((sk_global_ptr)(line_of_owner_base + line_offset + 16 * sub), (sk_lds_ptr)(wave_stage + P * 64), 16, 0, 0);
 }
 
+/* LINE: which 64-byte line of the bucket (k <= 31: the bucket is one line holding both slots; k <= 63: line 0 = slot 0,
+   line 1 = slot 1, fetched only by the lanes that still need it) */
 template <int W>
-__device__ __forceinline__ void sk_stage_buckets(dict_view const& d, uint32_t bucket, bool need, uint4* wave_stage) {
+__device__ __forceinline__ void sk_stage_lines(dict_view const& d, uint32_t bucket, uint32_t line, bool need, uint4* wave_stage) {
     char const* slots = static_cast<char const*>(d.sk.slots);
     const uint32_t sub = threadIdx.x & 3u;
-    const uint32_t mine = need ? bucket : 0u;
+    /* a 32-bit line number would overflow at k <= 63 (2 lines per bucket, up to 2^32 buckets): keep bucket and line apart */
+    const uint32_t mine = need ? bucket : 0u, my_line = need ? line : 0u;
     const uint32_t b0 = quad_broadcast<0>(mine), b1 = quad_broadcast<1>(mine), b2 = quad_broadcast<2>(mine), b3 = quad_broadcast<3>(mine);
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    if constexpr (W == 2) {
+        l0 = quad_broadcast<0>(my_line);
+        l1 = quad_broadcast<1>(my_line);
+        l2 = quad_broadcast<2>(my_line);
+        l3 = quad_broadcast<3>(my_line);
+    }
+    const uint64_t a0 = uint64_t(b0) * (64 * W) + 64 * l0, a1 = uint64_t(b1) * (64 * W) + 64 * l1, a2 = uint64_t(b2) * (64 * W) + 64 * l2,
+                   a3 = uint64_t(b3) * (64 * W) + 64 * l3;
 #if !SSHASH_STAGE_WITH_LDS_DMA
     const uint32_t lane = threadIdx.x & 63u;
-    uint4 piece[4 * W];
-    const uint32_t owner_bucket[4] = {b0, b1, b2, b3};
-#pragma unroll
-    for (int p = 0; p < 4 * W; ++p)
-        piece[p] = *reinterpret_cast<const uint4*>(slots + uint64_t(owner_bucket[p & 3]) * (64 * W) + 64 * (p >> 2) + 16 * sub);
-#pragma unroll
-    for (int p = 0; p < 4 * W; ++p) wave_stage[p * 64 + lane] = piece[p];
+    const uint4 p0 = *reinterpret_cast<const uint4*>(slots + a0 + 16 * sub), p1 = *reinterpret_cast<const uint4*>(slots + a1 + 16 * sub),
+                p2 = *reinterpret_cast<const uint4*>(slots + a2 + 16 * sub), p3 = *reinterpret_cast<const uint4*>(slots + a3 + 16 * sub);
+    wave_stage[0 * 64 + lane] = p0;
+    wave_stage[1 * 64 + lane] = p1;
+    wave_stage[2 * 64 + lane] = p2;
+    wave_stage[3 * 64 + lane] = p3;
     /* other lanes of this wave read what this lane wrote: order the LDS accesses for the compiler (the hardware
        executes a wave's DS instructions in order) */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #else
-    sk_stage_round_dma<W, 0>(slots, b0, sub, wave_stage);
-    sk_stage_round_dma<W, 1>(slots, b1, sub, wave_stage);
-    sk_stage_round_dma<W, 2>(slots, b2, sub, wave_stage);
-    sk_stage_round_dma<W, 3>(slots, b3, sub, wave_stage);
-    if constexpr (W == 2) {
-        sk_stage_round_dma<W, 4>(slots, b0, sub, wave_stage);
-        sk_stage_round_dma<W, 5>(slots, b1, sub, wave_stage);
-        sk_stage_round_dma<W, 6>(slots, b2, sub, wave_stage);
-        sk_stage_round_dma<W, 7>(slots, b3, sub, wave_stage);
-    }
+    sk_stage_round_dma<0>(slots, a0, sub, wave_stage);
+    sk_stage_round_dma<1>(slots, a1, sub, wave_stage);
+    sk_stage_round_dma<2>(slots, a2, sub, wave_stage);
+    sk_stage_round_dma<3>(slots, a3, sub, wave_stage);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the lines must have landed before any DS read of the staging area
     __builtin_amdgcn_wave_barrier();
 #endif
 }
 
+/* One bucket for every lane with need = true: fetch (cooperatively) and examine. Called by all 64 lanes. k <= 31: one
+   line, both slots compared. k <= 63: slot 0's line; the lanes that neither hit nor can rule slot 1 out (its "in use" bit
+   sits in slot 0) fetch the second line in a second round -- 1.3 lines per probe instead of 2. */
+template <int W>
+__device__ __forceinline__ void sk_probe_bucket_wave(dict_view const& d, sk_query_t<W> const& Q, uint32_t bucket, uint32_t c, bool need,
+                                                     uint4* wave_stage, fast_t& r, bool& key_seen, bool& marker, uint32_t& go_on) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint4* mine = wave_stage + (lane & 3u) * 64 + (lane >> 2) * 4;  // region (lane & 3), line of quad (lane >> 2)
+    sk_bucket_flags flags;
+    flags.go_on = 0;
+    flags.second_used = false;
+    sk_stage_lines<W>(d, bucket, 0u, need, wave_stage);
+    if (need) {
+        sk_examine_slot<W, true>(d, Q, c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
+        if constexpr (W == 1) sk_examine_slot<W, false>(d, Q, c, [mine](uint32_t i) { return mine[2 + i]; }, r, key_seen, marker, flags);
+    }
+    if constexpr (W == 2) {
+        __builtin_amdgcn_wave_barrier();
+        const bool second = need && r.outcome == FAST_MISS && flags.second_used;
+        if (__ballot(second) != 0) {  // wave-uniform
+            sk_stage_lines<W>(d, bucket, 1u, second, wave_stage);
+            if (second) sk_examine_slot<W, false>(d, Q, c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
+        }
+    }
+    go_on = flags.go_on;
+    __builtin_amdgcn_wave_barrier();
+}
+
 /* what the first pass hands to the second in a queue entry, above the query's index */
-constexpr uint32_t RESUME_CHOICE_SHIFT = 28;  // bits 28-29: choice of the key's sequence the entry refers to
+constexpr uint32_t RESUME_CHOICE_SHIFT = 27;  // bits 27-29: choice of the key's sequence the entry refers to (the index: 27 bits)
 constexpr uint32_t RESUME_HEAVY = 1u << 30;   // the key's marker was met there: start on the k-mer's own sequence ...
 constexpr uint32_t RESUME_GO_ON = 1u << 31;   // ... and that bucket's go-on flag was set (the key's sequence continues)
 
@@ -704,16 +741,11 @@ __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<
     const bool usable = active && sk_usable(d, kk);  // else: no strand-symmetric key, or a key of another table shard
     const sk_hash_t h = sk_hash(kk.key, d.sk.num_buckets);
     const sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, h.fingerprint);
-    sk_stage_buckets<W>(d, usable ? h.bucket[0] : 0u, usable, wave_stage);
     fast_t r = fast_unsettled(active && !usable);
+    uint32_t go_on = 0;
+    bool marker = false, key_seen = false;
+    sk_probe_bucket_wave<W>(d, Q, usable ? h.bucket[0] : 0u, 0u, usable, wave_stage, r, key_seen, marker, go_on);
     if (usable) {
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint4* mine = wave_stage + (lane & 3u) * 64 + (lane >> 2) * 4;  // region (lane & 3), line of quad (lane >> 2)
-        uint32_t go_on;
-        bool marker, key_seen = false;
-        /* W = 1: the line holds both slots (pieces 0-1, 2-3); W = 2: slot 1 is the second line, four regions on */
-        sk_examine_bucket<W>(d, Q, 0u, [mine](uint32_t slot, uint32_t i) { return W == 1 ? mine[2 * slot + i] : mine[slot * 256 + i]; }, r,
-                             key_seen, go_on, marker);
         if (r.outcome == FAST_MISS) {
             if (marker) {
                 r.outcome = FAST_CONTINUE;
@@ -729,7 +761,6 @@ __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<
             r.orientation = miss_orientation;
         }
     }
-    __builtin_amdgcn_wave_barrier();
     return r;
 }
 
@@ -739,24 +770,17 @@ __device__ __forceinline__ fast_t sk_second_pass_wave(dict_view const& d, kmer_w
                                                       int8_t miss_orientation, uint4* wave_stage) {
     const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
     const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
-    sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), (entry >> RESUME_CHOICE_SHIFT) & 3u);
+    sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), (entry >> RESUME_CHOICE_SHIFT) & 7u);
     sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, w.h.fingerprint);
     if (entry & RESUME_HEAVY) sk_walk_to_kmer_sequence<W>(d, x, x_rc, w, Q, (entry & RESUME_GO_ON) != 0);
     fast_t r = fast_unsettled(false);
     bool need = active;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint4* mine = wave_stage + (lane & 3u) * 64 + (lane >> 2) * 4;
 #pragma unroll 1
     while (__ballot(need) != 0) {  // wave-uniform
-        sk_stage_buckets<W>(d, need ? sk_choice(w.h, w.c) : 0u, need, wave_stage);
-        if (need) {
-            uint32_t go_on;
-            bool marker, key_seen = false;
-            sk_examine_bucket<W>(d, Q, w.c, [mine](uint32_t slot, uint32_t i) { return W == 1 ? mine[2 * slot + i] : mine[slot * 256 + i]; }, r,
-                                 key_seen, go_on, marker);
-            need = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
-        }
-        __builtin_amdgcn_wave_barrier();
+        uint32_t go_on = 0;
+        bool marker = false, key_seen = false;
+        sk_probe_bucket_wave<W>(d, Q, need ? sk_choice(w.h, w.c) : 0u, w.c, need, wave_stage, r, key_seen, marker, go_on);
+        if (need) need = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
     }
     if (r.outcome == FAST_MISS || (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc)) {
         r = fast_unsettled(false);

@@ -217,6 +217,7 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
             } else {
                 placed[t] = 1;
                 used = true;
+                if (S != B) atomicOr(B, SK_SECOND_USED);
                 uint32_t meta, d1;
                 uint64_t w1;
                 uint64_t body[2 * W];
