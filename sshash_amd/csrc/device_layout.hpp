@@ -62,8 +62,8 @@
 //               function, the table need not follow the reference's minimizer hash: it uses a 32-bit one;
 //        bucket one 64-byte line = the unit the memory system fetches (TCC_EA0_RDREQ is always a 64-byte request,
 //               profiles/r02/tlb_probe_counters.txt) = TWO 32-byte slots. A key lives in one of SK_CHOICES = 5
-//               hashed buckets, in the first of them that had a free slot when it was placed; two slots per key
-//               (load factor 0.5). The four lanes of a quad fetch the line of one of them together -- 16 bytes each,
+//               hashed buckets, in the first of them that had a free slot when it was placed; 2.5 slots per item
+//               (load factor 0.4). The four lanes of a quad fetch the line of one of them together -- 16 bytes each,
 //               ONE load instruction, transposed through LDS (lookup_device.hpp) -- so that the memory pipeline sees
 //               one request and ONE address translation per lookup: with one lane issuing the 16-byte loads of its
 //               own slot every load is a separate UTCL1 miss once the table outgrows the ~2 GiB the per-CU
@@ -91,7 +91,7 @@
 //               and ties send the query to the complete path through (3)/(4).
 //      Ids are positions in the strings, so results are identical to the reference's; the table only
 //      changes how many reads it takes to find the position. SSHASH_AMD_SKTABLE=0 disables it.
-//      The table is the largest structure (~11 bytes per k-mer at k = 31, m = 21); with several GPUs it can be
+//      The table is the largest structure (~14 bytes per k-mer at k = 31, m = 21); with several GPUs it can be
 //      partitioned by key (sk_owner): each replica then builds the slots of its own keys only, queries are
 //      routed to the owner of their key (one message per query, sharded.py), and a replica that meets a key
 //      it does not own simply takes the complete path -- every replica stays correct on its own.
@@ -167,7 +167,7 @@ static_assert((SK_GO_ON << (SK_CHOICES - 1)) < (1u << SK_LEFT_SHIFT), "go-on fla
 static_assert(SK_CHOICES == 5, "sk_hash and sk_choice spell out five choices");
 constexpr uint32_t SK_INLINE_MAX = 4;         // a key with up to this many occurrences holds one inline slot per occurrence;
                                               // a heavier key holds a marker and its k-mers are keyed one by one
-constexpr double SK_SLOTS_PER_KEY = 2.0;
+constexpr double SK_SLOTS_PER_KEY = 2.5;  // slots per item: load factor 0.4 (1.6 ... 4.0 measured)
 /* why a replica was given no table (sshash_device_stats) */
 constexpr uint32_t SK_ABSENT_DISABLED = 1, SK_ABSENT_MINIMIZER_SHARD = 2, SK_ABSENT_TOO_MANY_BASES = 3, SK_ABSENT_TOO_MANY_ITEMS = 4,
                    SK_ABSENT_NO_MEMORY = 5;
