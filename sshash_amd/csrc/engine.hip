@@ -577,6 +577,16 @@ static uint64_t launch_piece_queries() {
     return piece;
 }
 
+/* the resume queue holds half a launch piece; a query that finds it full takes the complete path instead. The divisor
+   is a test knob: with 64 nearly every resumed query overflows (tests/test_gpu_parity.py) */
+static uint32_t resume_capacity_divisor() {
+    if (const char* e = std::getenv("SSHASH_AMD_RESUME_DIVISOR")) {
+        const unsigned long v = std::strtoul(e, nullptr, 10);
+        if (v >= 1 && v <= 4096) return uint32_t(v);
+    }
+    return 2;
+}
+
 template <int W, bool CANON, int MODE, bool ASCII>
 static void launch(device_replica const* rep, void const* q, uint64_t n, bool check_rc,
                    result_view const& out, uint8_t* member, hipStream_t stream, uint8_t const* lane_valid) {
@@ -599,7 +609,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 const uint32_t nblocks = uint32_t((m + block - 1) / block);
                 pass_queues pq{};
                 pq.defer_capacity = ((nblocks + DEFER_SHARDS - 1) / DEFER_SHARDS) * block;
-                pq.resume_capacity = d.sk.enabled ? (pq.defer_capacity + 1) / 2 : 0;
+                pq.resume_capacity = d.sk.enabled ? (pq.defer_capacity + 1) / resume_capacity_divisor() : 0;
                 const uint64_t defer_places = uint64_t(DEFER_SHARDS) * pq.defer_capacity, resume_places = uint64_t(DEFER_SHARDS) * pq.resume_capacity;
                 std::lock_guard<std::mutex> enqueue(rep->launch_mutex);
                 char* scratch = static_cast<char*>(rep->scratch_for(

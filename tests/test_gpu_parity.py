@@ -496,3 +496,22 @@ def test_navigational_queries_follow_the_input_strings(case_name, request):
                 assert ids[i, 4 + code[s[j - 1]]] == i - 1
             i += 1
     assert i == n
+
+
+@pytest.mark.parametrize("case_name", ["case_se_regular", "case_se_canonical", "case_k63_regular"])
+def test_a_full_resume_queue_sends_its_queries_down_the_complete_path(case_name, request, monkeypatch):
+    """The second pass's queue holds half a launch piece; a query that finds it full is handed to the complete path
+    (directory / MPHF / skew index) instead. With the queue cut to 1/64 nearly every resumed query takes that route:
+    ids and membership of every k-mer, both strands, plus a random mix against the oracle, must not change."""
+    case = request.getfixturevalue(case_name)
+    d = case.dict.to_device(0)
+    monkeypatch.setenv("SSHASH_AMD_RESUME_DIVISOR", "64")
+    n = d.num_kmers()
+    q = d.access_packed(np.arange(n, dtype=np.uint64))
+    want = np.arange(n, dtype=np.uint64)
+    assert (d.lookup(q).kmer_id == want).all()
+    assert d.is_member(q).all()
+    rc = case.gt._revcomp(q).reshape(-1)
+    assert (d.lookup(rc).kmer_id == want).all()
+    mix = case.queries(20000, 20000, seed=41)
+    assert (d.lookup(mix).kmer_id == case.oracle.lookup_ids(mix)).all()
