@@ -180,6 +180,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test scaffolding (tests/test_gpu_bench_harness.py): on a one-GPU box the N > 1 harness is exercised with every rank
+    # on the same device and the coordination over gloo; never set in a measurement
+    one_device = os.environ.get("SSHASH_BENCH_TEST_ALL_RANKS_ON_DEVICE")
+    if one_device is not None:
+        local_rank = int(one_device)
+    backend = "gloo" if one_device is not None else "nccl"
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -192,7 +198,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tensors of the (few) collectives live
 
     def barrier():
         if use_dist:
@@ -269,10 +279,10 @@ def main():
     avg_kernel_ms = float(np.mean(kernel_ms))
     per_rank = [{"rank": 0, "queries": n, "ms_per_step": round(own_elapsed / args.steps * 1e3, 3), "kernel_ms_per_step": round(avg_kernel_ms, 3)}]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([float(n), own_elapsed / args.steps * 1e3, avg_kernel_ms], dtype=torch.float64, device=dev)
+        mine = torch.tensor([float(n), own_elapsed / args.steps * 1e3, avg_kernel_ms], dtype=torch.float64, device=coll_dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank = [{"rank": r, "queries": int(v[0].item()), "ms_per_step": round(float(v[1].item()), 3),

@@ -1,0 +1,57 @@
+"""GPU: bench.py as the driver runs it -- `python bench.py --gpus N --steps K --warmup W` -- on a reduced workload:
+one JSON line on stdout with the contract's fields, the roofline and cpu_baseline objects at N = 1, and the N = 2 harness
+(self-launched ranks, index built once, the batch split, MAX-reduced time, per-rank times) with both ranks on the one GPU of
+the test box."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ["--workload", "c2", "--bases", "30000000", "--queries", "4000000", "--steps", "3", "--warmup", "1", "--cpu-sample", "100000"]
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline", "cpu_baseline")
+
+
+def run_bench(extra, env_extra, tmp_path):
+    env = dict(os.environ, SSHASH_BENCH_CACHE=str(tmp_path), **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}: {p.stdout[:500]}"
+    return json.loads(lines[0])
+
+
+def test_one_gpu_line_carries_the_contract(tmp_path):
+    r = run_bench([], {}, tmp_path)
+    for key in CONTRACT:
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "strong" and r["higher_is_better"] is True
+    assert r["vs_baseline"] is None and r["data"] == "synthetic" and r["dtype"] == "u64"
+    assert abs(r["value"] - r["config"]["queries_per_step"] / r["ms_per_step"] * 1e3) / r["value"] < 0.02
+    roof = r["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert 0 < roof["frac"] < 1 and roof["avg_kernel_ms"] <= r["ms_per_step"] * 1.05
+    cpu = r["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu
+    assert abs(r["config"]["positive_fraction_found"] - 0.5) < 0.01
+    assert set(r["other_mixes"]) == {"positive100", "negative100_random", "mix50_mutated_negatives"}
+
+
+def test_two_ranks_split_one_batch(tmp_path):
+    r = run_bench(["--gpus", "2", "--no-cpu-baseline"], {"SSHASH_BENCH_TEST_ALL_RANKS_ON_DEVICE": "0"}, tmp_path)
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong"
+    assert [p["rank"] for p in r["per_rank"]] == [0, 1]
+    assert sum(p["queries"] for p in r["per_rank"]) == r["config"]["queries_per_step"] == 4000000
+    assert r["ms_per_step"] >= max(p["ms_per_step"] for p in r["per_rank"]) * 0.98  # the MAX over the ranks
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".sshash")]) == 1  # built once, by rank 0
+    assert r["cpu_baseline"] is None and r["config"]["index_replicated_per_gpu"] is True
