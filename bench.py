@@ -305,12 +305,12 @@ def main():
         found = float((out != -1).float().mean().item())
         bytes_per_lookup = ora.count_bytes(head[: min(sample, 100_000) * W]) / min(sample, 100_000)
         achieved = bytes_per_lookup * n / (avg_kernel_ms * 1e-3) / 1e9
-        pieces = -(-n // (1 << 27))  # launch pairs per step (engine.hip: at most 2^27 queries per pair, equal pieces)
+        pieces = -(-n // (1 << 27))  # launch sequences per step (engine.hip: at most 2^27 queries per sequence, equal pieces)
         traffic, provenance = traffic_record(d, n, args)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_provenance": provenance,
-                    "kernel": "fast_lookup_kernel<W=%d,canonical=%d,ids,%s> + deferred_lookup_kernel (%d launch pair(s) of "
-                              "equal size per step; avg_kernel_ms = HIP-event time around one step, on the launch stream)"
+                    "kernel": "fast_lookup_kernel<W=%d,canonical=%d,ids,%s> + resume_lookup_kernel + deferred_lookup_kernel (%d launch "
+                              "sequence(s) of equal size per step; avg_kernel_ms = HIP-event time around one step, on the launch stream)"
                               % (W, int(d.canonical()), "super-k-mer table" if stats["sk_slots"] else "directory", pieces),
                     "launches_per_step": pieces,
                     "algorithmic_bytes_per_lookup": round(bytes_per_lookup, 2),

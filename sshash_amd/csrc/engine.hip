@@ -397,7 +397,7 @@ __device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries
     return x;
 }
 
-/* Phase 1 of the two-phase lookup (lookup_device.hpp): one query per lane, common case only. Queries it
+/* First pass of the multi-pass lookup (lookup_device.hpp): one query per lane, common case only. Queries it
    cannot settle are appended to `queue` (their index in the batch). SK: through the super-k-mer table
    (device_layout.hpp (5)) instead of directory + atoms; the four lanes of a quad fetch each other's buckets
    together, through LDS (sk_probe_wave), so no lane leaves before the probe. */
@@ -491,7 +491,7 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
 }
 
 /* Second pass of the table lookup: the queries the first pass could not settle with one bucket read (their key's
-   first bucket was full when the key was placed, or the key has an occurrence list), compacted, so that these
+   first bucket was full when the key was placed, or the key is heavy: marker + one slot per k-mer), compacted, so that these
    dependent reads are issued by full waves instead of by the few lanes of every first-pass wave that need them.
    RESUME_PARTS workgroups walk one shard of the queue. */
 constexpr uint32_t RESUME_PARTS = 4;
@@ -530,7 +530,7 @@ resume_lookup_kernel(const dict_view d, const bool check_rc, const result_view o
     }
 }
 
-/* Phase 2: the deferred queries, compacted, through the complete lookup. */
+/* Last pass: the deferred queries, compacted, through the complete lookup. */
 template <int W, bool CANON, int MODE, bool ASCII>
 __global__ void __launch_bounds__(256)
 deferred_lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const void* __restrict__ queries,
@@ -593,7 +593,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
     dict_view const& d = rep->view;
     skew_part_dev const* skew = rep->d_skew;
     const uint32_t block = 256;
-    /* Two-phase lookup through the minimizer directory -- unless the caller wants `minimizer_found`:
+    /* Multi-pass lookup through the table (or the minimizer directory) -- unless the caller wants `minimizer_found`:
        for an absent minimizer the reference's flag depends on which (arbitrary) bucket the MPHF lands
        on, so only the MPHF path can reproduce it (device_layout.hpp (4)). */
     {

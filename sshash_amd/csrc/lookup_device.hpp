@@ -337,7 +337,8 @@ __device__ __forceinline__ hit_t lookup_one(dict_view const& d, skew_part_dev co
     }
 }
 
-/* ---- two-phase lookup: the common case in a lean kernel, everything else deferred ------------
+/* ---- lookup without the table (minimizer shards, SSHASH_AMD_SKTABLE=0): the common case in a lean kernel,
+   everything else deferred ------------
    The generic `lookup_one` above carries the code of every rare case (MIDLOAD scans, the skew index,
    the MPHF fallback of overflowed directory sectors); a wave executes all of it as soon as ONE of its
    64 lanes needs it. `fast_probe_*` resolves: minimizer absent (the directory says so), SINGLETON and

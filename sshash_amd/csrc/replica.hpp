@@ -50,11 +50,11 @@ struct device_replica {
     uint32_t sk_absent_reason = 1;  // SK_ABSENT_* (0 = the table is there)
     std::vector<void*> allocations;
 
-    /* Per-stream scratch for the deferred-query queue of the two-phase lookup. Work on one stream is
+    /* Per-stream scratch for the resume and deferred queues of the multi-pass lookup (engine.hip). Work on one stream is
        ordered, so a buffer keyed by the stream can be reused without synchronisation; it only grows
        (hipFree of the old block synchronises implicitly) and lives as long as the replica: the caller's
        streams are few and the host path's lanes keep theirs. */
-    /* held while one launch sequence (queue reset, phase 1, phase 2) is enqueued: two host threads that share a
+    /* held while one launch sequence (queue reset, first / resume / deferred pass) is enqueued: two host threads that share a
        stream (the null stream, typically) must not interleave their sequences, which share that stream's scratch */
     mutable std::mutex launch_mutex;
     mutable std::mutex scratch_mutex;

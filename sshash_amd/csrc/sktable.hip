@@ -14,7 +14,7 @@
 //   4. fill     the winner writes its slot: the 64 bases around one occurrence, how far the super-k-mer may extend
 //               inside its string, the string id. A key with up to SK_INLINE_MAX occurrences takes one such slot per
 //               occurrence (a lookup then never leaves the table); a key with more takes one slot pointing at its
-//               occurrence list.
+//               marker, and every k-mer of its super-k-mers becomes an item of its own (sk_heavy_kmers_kernel).
 #include <hip/hip_runtime.h>
 
 #include <hipcub/hipcub.hpp>

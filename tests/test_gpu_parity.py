@@ -204,7 +204,7 @@ def test_access_on_device(case_se_regular, case_k63_canonical):
 @pytest.mark.parametrize("case_name", ["case_se_regular", "case_se_canonical", "case_k63_regular", "case_skew_canonical"])
 def test_repeated_launches_are_deterministic(case_name, request):
     """Every id / membership bit of every k-mer, several launches in a row: identical and correct each time
-    (guards the two-phase lookup: settled lanes, deferred lanes, directory overflow)."""
+    (guards the multi-pass lookup: settled lanes, resumed lanes, deferred lanes, directory overflow)."""
     case = request.getfixturevalue(case_name)
     d = case.dict.to_device(0)
     n = d.num_kmers()
@@ -217,7 +217,7 @@ def test_repeated_launches_are_deterministic(case_name, request):
 
 @pytest.mark.parametrize("case_name", ["case_se_regular", "case_skew_canonical", "case_k63_canonical"])
 def test_full_result_without_minimizer_found_uses_the_same_values(case_name, request):
-    """Asking for every field except `minimizer_found` goes through the two-phase kernels; the values
+    """Asking for every field except `minimizer_found` goes through the multi-pass kernels; the values
     must equal the oracle's all the same."""
     import torch
 
@@ -242,7 +242,7 @@ def test_full_result_without_minimizer_found_uses_the_same_values(case_name, req
 
 
 def test_batch_larger_than_one_launch_piece(case_se_regular):
-    """More than 2^27 queries in one call: the two-phase path splits the batch into launch pairs; ids at
+    """More than 2^27 queries in one call: the multi-pass path splits the batch into launch sequences; ids at
     and around the seam must be right (positives planted there, oracle on a sample of the rest)."""
     import torch
 
