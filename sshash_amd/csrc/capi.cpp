@@ -1,6 +1,9 @@
 // capi.cpp -- the C ABI declared in include/sshash_amd.h (thin shim over engine / index).
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -310,19 +313,75 @@ sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char*
     if (!d || !filename || !report) return fail(SSHASH_ERR_ARGUMENT, "null argument");
     std::memset(report, 0, sizeof(*report));
     return guarded([&] {
-        read_batch reads;
-        if (!load_reads(filename, multiline != 0, d->idx->k, reads)) {
+        read_stream in(filename, multiline != 0, d->idx->k);
+        if (!in.supported()) {
             /* src/query.cpp:169-171: unsupported extension -> message on stderr, empty report */
             fprintf(stderr, "unsupported query file format\n");
             return;
         }
-        const streaming_report r = d->eng->streaming_query_host(reads.bases.data(), reads.offsets.data(), reads.num_reads());
-        report->num_kmers = r.num_kmers;
-        report->num_positive_kmers = r.num_positive_kmers;
-        report->num_negative_kmers = r.num_negative_kmers;
-        report->num_invalid_kmers = r.num_invalid_kmers;
-        report->num_searches = r.num_searches;
-        report->num_extensions = r.num_extensions;
+        /* The file goes through in batches of ~256 MiB of bases (a FASTQ of hundreds of gigabytes must not be
+           materialised): a reader thread decompresses batch i+1 while the devices work on batch i. */
+        uint64_t batch_bases = uint64_t(256) << 20;
+        if (char const* e = std::getenv("SSHASH_AMD_QUERY_BATCH_BASES")) batch_bases = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));  // tests
+        read_batch slot[2];
+        std::mutex mu;
+        std::condition_variable cv;
+        int filled[2] = {0, 0};  // 0 = free, 1 = holds a batch, 2 = end of file
+        std::exception_ptr reader_error;
+        bool abandon = false;
+        std::thread reader([&] {
+            try {
+                for (int at = 0;; at ^= 1) {
+                    {
+                        std::unique_lock<std::mutex> lock(mu);
+                        cv.wait(lock, [&] { return filled[at] == 0 || abandon; });
+                        if (abandon) return;
+                    }
+                    const bool more = in.next(slot[at], batch_bases);
+                    std::lock_guard<std::mutex> lock(mu);
+                    filled[at] = more ? 1 : 2;
+                    cv.notify_all();
+                    if (!more) return;
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> lock(mu);
+                reader_error = std::current_exception();
+                filled[0] = filled[1] = 2;
+                cv.notify_all();
+            }
+        });
+        struct joiner {
+            std::thread& t;
+            std::mutex& mu;
+            std::condition_variable& cv;
+            bool& abandon;
+            ~joiner() {
+                {
+                    std::lock_guard<std::mutex> lock(mu);
+                    abandon = true;
+                }
+                cv.notify_all();
+                t.join();
+            }
+        } join_reader{reader, mu, cv, abandon};
+        for (int at = 0;; at ^= 1) {
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return filled[at] != 0; });
+                if (filled[at] == 2) break;
+            }
+            const streaming_report r = d->eng->streaming_query_host(slot[at].bases.data(), slot[at].offsets.data(), slot[at].num_reads());
+            report->num_kmers += r.num_kmers;
+            report->num_positive_kmers += r.num_positive_kmers;
+            report->num_negative_kmers += r.num_negative_kmers;
+            report->num_invalid_kmers += r.num_invalid_kmers;
+            report->num_searches += r.num_searches;
+            report->num_extensions += r.num_extensions;
+            std::lock_guard<std::mutex> lock(mu);
+            filled[at] = 0;
+            cv.notify_all();
+        }
+        if (reader_error) std::rethrow_exception(reader_error);
     });
 }
 

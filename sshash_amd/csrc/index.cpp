@@ -793,12 +793,10 @@ static void validate_index(host_index const& idx) {
         if (idx.mid_load_buckets.get(i) >= idx.num_bases) bad("mid-load offset");
     for (uint64_t i = 0; i < idx.heavy_load_buckets.size; ++i)
         if (idx.heavy_load_buckets.get(i) >= idx.num_bases) bad("heavy-load offset");
-    uint64_t heavy_positions = 0;
     for (uint32_t p = 0; p < idx.skew_num_partitions; ++p) {
         validate_mphf(idx.skew_mphfs[p], "skew index");
         validate_packed(idx.skew_positions[p], "skew positions");
         if (idx.skew_positions[p].size != idx.skew_mphfs[p].num_keys) bad("one skew position per k-mer");
-        heavy_positions += idx.skew_positions[p].size;
     }
     /* control codewords (src/builder/build_sparse_and_skew_index.cpp:110-124,204-235): every one must point inside
        the structure its two low bits select */

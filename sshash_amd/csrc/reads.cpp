@@ -6,6 +6,7 @@
 #include <zlib.h>
 
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 
 namespace sshash_amd {
@@ -51,9 +52,16 @@ void push_read(read_batch& out, std::string const& s, uint32_t k) {
 
 }  // namespace
 
-bool load_reads(std::string const& filename, bool multiline, uint32_t k, read_batch& out) {
-    out.bases.clear();
-    out.offsets.assign(1, 0);
+struct read_stream::impl {
+    line_reader in;
+    enum { FASTQ, FASTA, FASTA_MULTILINE } format;
+    uint32_t k;
+    bool done = false;
+    std::string line, seq, segment;
+    impl(std::string const& filename, int fmt, uint32_t k_) : in(filename), format(decltype(format)(fmt)), k(k_) {}
+};
+
+read_stream::read_stream(std::string const& filename, bool multiline, uint32_t k) {
     const bool fasta = ends_with(filename, ".fa") || ends_with(filename, ".fasta") || ends_with(filename, ".fa.gz") ||
                        ends_with(filename, ".fasta.gz");
     const bool fastq = ends_with(filename, ".fq") || ends_with(filename, ".fastq") || ends_with(filename, ".fq.gz") ||
@@ -61,36 +69,51 @@ bool load_reads(std::string const& filename, bool multiline, uint32_t k, read_ba
     if (!fasta && !fastq) {
         /* the reference opens the file before looking at the extension (src/query.cpp:127-128) */
         line_reader probe(filename);
-        return false;
+        return;
     }
-    line_reader in(filename);
-    std::string line, seq;
-    if (fastq) {
-        for (;;) {
-            if (!in.next(line)) break;   // header
-            if (!in.next(seq)) break;    // bases
-            push_read(out, seq, k);
-            in.next(line);               // '+'
-            in.next(line);               // qualities
-        }
-    } else if (!multiline) {
-        for (;;) {
-            if (!in.next(line)) break;  // header
-            if (!in.next(seq)) break;
-            push_read(out, seq, k);
-        }
-    } else {
-        std::string segment;
-        while (in.next(line)) {
-            if (line.empty()) {
-                push_read(out, segment, k);
-                segment.clear();
+    m = std::make_unique<impl>(filename, fastq ? impl::FASTQ : multiline ? impl::FASTA_MULTILINE : impl::FASTA, k);
+}
+
+read_stream::~read_stream() = default;
+
+bool read_stream::next(read_batch& out, uint64_t max_bases) {
+    out.bases.clear();
+    out.offsets.assign(1, 0);
+    if (!m || m->done) return false;
+    impl& r = *m;
+    while (out.bases.size() < max_bases) {
+        if (r.format == impl::FASTQ) {
+            if (!r.in.next(r.line) || !r.in.next(r.seq)) { r.done = true; break; }  // header, bases
+            push_read(out, r.seq, r.k);
+            r.in.next(r.line);  // '+'
+            r.in.next(r.line);  // qualities
+        } else if (r.format == impl::FASTA) {
+            if (!r.in.next(r.line) || !r.in.next(r.seq)) { r.done = true; break; }
+            push_read(out, r.seq, r.k);
+        } else {
+            if (!r.in.next(r.line)) {
+                push_read(out, r.segment, r.k);
+                r.segment.clear();
+                r.done = true;
+                break;
+            }
+            if (r.line.empty()) {
+                push_read(out, r.segment, r.k);
+                r.segment.clear();
             } else {
-                segment += line;
+                r.segment += r.line;
             }
         }
-        push_read(out, segment, k);
     }
+    return out.num_reads() != 0 || !r.done;
+}
+
+bool load_reads(std::string const& filename, bool multiline, uint32_t k, read_batch& out) {
+    read_stream in(filename, multiline, k);
+    out.bases.clear();
+    out.offsets.assign(1, 0);
+    if (!in.supported()) return false;
+    in.next(out, ~uint64_t(0));
     return true;
 }
 

@@ -11,6 +11,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -22,7 +23,22 @@ struct read_batch {
     uint64_t num_reads() const { return offsets.empty() ? 0 : offsets.size() - 1; }
 };
 
-/* Returns false when the extension is not a supported format; throws std::runtime_error
+/* The same records, a bounded number of bases at a time (whole reads; a batch ends with the first read that takes it to
+   `max_bases` or beyond): a query file of hundreds of gigabytes never sits in host memory as a whole. */
+class read_stream {
+public:
+    read_stream(std::string const& filename, bool multiline, uint32_t k);  // throws when the file cannot be opened
+    ~read_stream();
+    bool supported() const { return bool(m); }  // false: the extension is not a supported format
+    /* false once the file is exhausted and `out` holds nothing */
+    bool next(read_batch& out, uint64_t max_bases);
+
+private:
+    struct impl;
+    std::unique_ptr<impl> m;
+};
+
+/* The whole file at once. Returns false when the extension is not a supported format; throws std::runtime_error
    ("error in opening the file ...") when the file cannot be opened. */
 bool load_reads(std::string const& filename, bool multiline, uint32_t k, read_batch& out);
 

@@ -112,6 +112,32 @@ def test_multiline_fasta_and_unsupported_extension(case_skew_regular, tmp_path):
     assert rep == {k: 0 for k in rep}  # "unsupported query file format": empty report (src/query.cpp:169-171)
 
 
+def test_query_file_goes_through_in_batches(case_se_regular, case_skew_regular, tmp_path, monkeypatch):
+    """The file readers hand over a bounded number of bases at a time (whole reads; a reader thread fills the next batch
+    while the device works): the report does not depend on where the batches end -- FASTQ, one-line and multiline FASTA."""
+    d = case_se_regular.dict.to_device(0)
+    whole = _as_dict(d.streaming_query_from_file(FASTQ))
+    for batch in ("1", "1000", "77777"):
+        monkeypatch.setenv("SSHASH_AMD_QUERY_BATCH_BASES", batch)
+        assert _as_dict(d.streaming_query_from_file(FASTQ)) == whole
+    monkeypatch.delenv("SSHASH_AMD_QUERY_BATCH_BASES")
+    case = case_skew_regular
+    d = case.dict.to_device(0)
+    p = tmp_path / "many.fa"
+    with open(p, "w") as f:
+        for i, s in enumerate(case.sequences):
+            f.write(f">{i}\n{s[:60]}\n{s[60:]}\n\n")
+    for multiline in (True, False):
+        whole = _as_dict(d.streaming_query_from_file(str(p), multiline=multiline))
+        assert whole["num_kmers"] > 0
+        for batch in ("1", "500"):
+            monkeypatch.setenv("SSHASH_AMD_QUERY_BATCH_BASES", batch)
+            assert _as_dict(d.streaming_query_from_file(str(p), multiline=multiline)) == whole
+        monkeypatch.delenv("SSHASH_AMD_QUERY_BATCH_BASES")
+    with pytest.raises(Exception):
+        d.streaming_query_from_file(str(tmp_path / "missing.fq"))
+
+
 # ---- per-k-mer results: streaming_query::lookup for every k-mer (include/streaming_query.hpp:56-109) ----------------
 
 FIELDS = ("kmer_id", "kmer_id_in_string", "string_id", "string_begin", "string_end", "kmer_orientation")  # what
