@@ -71,7 +71,8 @@
 //               capped round 1's table at 38 G reads/s;
 //        slot   32 bytes:
 //                 d0  bit0 valid | bit1 marker | bit2 strand | bits 3-7 go-on flags of the BUCKET, one per choice
-//                     (kept in slot 0 only) | bits 8-13 left | bits 14-19 right | bit 20 (slot 0 only) slot 1 is in use
+//                     (kept in slot 0 only) | bits 8-13 left | bits 14-19 right | bit 20 (slot 0 only) slot 1 is in use |
+//                     bits 21-31 (slot 0 only) filter over the fingerprints of the keys that went on from their FIRST choice
 //                 d1  string id (marker: number of occurrences of the key)
 //                 d2,d3  position of the key occurrence (40 bits) | fingerprint of the key << 40
 //                 d4-d7  the 64 bases starting k-m bases before the occurrence, i.e. every k-mer of the super-k-mer
@@ -163,6 +164,13 @@ constexpr uint32_t SK_CHOICES = 5;            // ... or, for the last choice, in
 constexpr uint32_t SK_BUCKET_SLOTS = 2;       // slots per bucket: one 64-byte line at k <= 31
 constexpr uint32_t SK_LEFT_SHIFT = 8, SK_RIGHT_SHIFT = 14;
 constexpr uint32_t SK_SECOND_USED = 1u << 20;  // in slot 0: slot 1 of the bucket is in use (k <= 63: worth fetching its line)
+/* Bits 21-31 of slot 0: WHICH keys went on from their first choice -- bit sk_filter_index(fingerprint) is set by every item that
+   found this bucket, its first choice, full. The first go-on flag alone sends every query that misses in such a bucket (5 % of
+   the buckets at load factor 0.4) to the resume pass, negative ones included; with the filter a query goes on only if a key
+   with its own filter index did: 1/11 of those negatives. */
+constexpr uint32_t SK_FILTER_SHIFT = 21, SK_FILTER_BITS = 11;
+static_assert(SK_FILTER_SHIFT + SK_FILTER_BITS == 32 && (1u << SK_FILTER_SHIFT) > SK_SECOND_USED, "filter bits are the top of the word");
+SSH_HD uint32_t sk_filter_index(uint32_t fingerprint24) { return (fingerprint24 * SK_FILTER_BITS) >> 24; }
 static_assert((SK_GO_ON << (SK_CHOICES - 1)) < (1u << SK_LEFT_SHIFT), "go-on flags must stay below the extent fields");
 static_assert(SK_CHOICES == 5, "sk_hash and sk_choice spell out five choices");
 constexpr uint32_t SK_INLINE_MAX = 4;         // a key with up to this many occurrences holds one inline slot per occurrence;
@@ -221,11 +229,15 @@ SSH_HD uint64_t sk_kmer_key(kmer_w<W> const& x, kmer_w<W> const& x_rc) {
     return (v ^ (v >> 29)) * 0xBF58476D1CE4E5B9ULL + 0x632BE59BD9B4E019ULL;
 }
 
-/* Key of a k-mer (k <= 31) for the super-k-mer table: an m-mer occurrence chosen so that a k-mer and its
-   reverse complement choose the same one. The table is free to use any such function (it is built and
-   probed with the same one), so this is NOT the reference's minimizer: 32-bit arithmetic, no 64-bit
-   multiply. Per strand the leftmost m-mer with the smallest hash wins; the strand with the smaller of
-   the two winning hashes supplies the key; equal hashes = tie (no key: the caller takes the complete path). */
+/* Key of a k-mer for the super-k-mer table: an m-mer occurrence chosen so that a k-mer and its reverse complement
+   choose the same one. The table is free to use any such function (it is built and probed with the same one), so
+   this is NOT the reference's minimizer. The election looks at the first min(m, 16) bases of every m-mer occurrence
+   only -- ONE 32-bit word per candidate, one funnel shift to extract it, one 32-bit multiply to hash it -- and carries
+   the candidate's position in the low 6 bits of the hash, so that a running minimum replaces compare-and-select: six
+   VALU instructions per candidate (the first version hashed the whole m-mer: eleven; at k = 63, m = 25 the 78
+   candidates made the first pass VALU-bound). Per strand the leftmost occurrence with the smallest
+   26-bit hash wins; the strand with the smaller winning hash supplies the key -- the whole m-mer at the elected
+   position --; equal hashes on the two strands = tie (no key: the caller takes the complete path). */
 struct sk_key_t {
     uint64_t key;  // the m-mer, as read on the winning strand
     uint32_t pos;  // where it starts on that strand
@@ -233,9 +245,10 @@ struct sk_key_t {
     bool tie;
 };
 
-SSH_HD uint32_t sk_mmer_hash(uint64_t mmer) {
-    return uint32_t(mmer) * 0x9E3779B1u + (uint32_t(mmer >> 32) * 0x85EBCA77u + 0x27D4EB2Fu);
-}
+constexpr uint32_t SK_POS_BITS = 6;  // positions 0 .. k - m <= 62
+/* 26-bit election hash (in the top bits) of the first bases of an m-mer occurrence; the xor keeps poly-A (word 0) from
+   winning every election it takes part in */
+SSH_HD uint32_t sk_select_hash(uint32_t prefix) { return ((prefix ^ 0x6A09E667u) * 0x9E3779B1u) & ~((1u << SK_POS_BITS) - 1u); }
 
 /* low 32 bits of (hi:lo) >> s, s in 0..31: one v_alignbit_b32 on the device (a 64-bit shift costs five times as much) */
 SSH_HD uint32_t funnel32(uint32_t lo, uint32_t hi, uint32_t s) {
@@ -248,20 +261,19 @@ SSH_HD uint32_t funnel32(uint32_t lo, uint32_t hi, uint32_t s) {
 
 template <int W>
 SSH_HD sk_key_t sk_key(kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m) {
-    /* the k-mer as 32-bit words (16 bases each), two zero words behind it: the m-mer starting at base i = 16 j + t is
-       the 2m low bits of words j, j+1, j+2 shifted right by 2 t -- two funnel shifts instead of 64-bit (or 128-bit) shifts */
+    /* the k-mer as 32-bit words (16 bases each), one zero word behind it: the 16 bases starting at base i = 16 j + t are
+       words j, j+1 shifted right by 2 t -- a funnel shift instead of a 64-bit (or 128-bit) shift */
     constexpr int D = 2 * W;
-    uint32_t f[D + 2], r[D + 2];
+    uint32_t f[D + 1], r[D + 1];
     for (int j = 0; j < W; ++j) {
         f[2 * j] = uint32_t(x.w[j]);
         f[2 * j + 1] = uint32_t(x.w[j] >> 32);
         r[2 * j] = uint32_t(x_rc.w[j]);
         r[2 * j + 1] = uint32_t(x_rc.w[j] >> 32);
     }
-    f[D] = f[D + 1] = r[D] = r[D + 1] = 0;
-    const uint32_t mask_lo = m >= 16 ? 0xFFFFFFFFu : (1u << (2 * m)) - 1;
-    const uint32_t mask_hi = m > 16 ? uint32_t(low_mask(2 * m) >> 32) : 0u;
-    uint32_t best_f = 0xFFFFFFFFu, best_r = 0xFFFFFFFFu, pos_f = 0, pos_r = 0;
+    f[D] = r[D] = 0;
+    const uint32_t mask = m >= 16 ? 0xFFFFFFFFu : (1u << (2 * m)) - 1;
+    uint32_t best_f = 0xFFFFFFFFu, best_r = 0xFFFFFFFFu;
     const uint32_t n = k - m + 1;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -274,24 +286,16 @@ SSH_HD sk_key_t sk_key(kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, ui
             const uint32_t i = 16 * uint32_t(j) + t;
             if (i >= n) break;
             const uint32_t s = 2 * t;
-            const uint32_t hf = (funnel32(f[j], f[j + 1], s) & mask_lo) * 0x9E3779B1u +
-                                ((funnel32(f[j + 1], f[j + 2], s) & mask_hi) * 0x85EBCA77u + 0x27D4EB2Fu);
-            const uint32_t hr = (funnel32(r[j], r[j + 1], s) & mask_lo) * 0x9E3779B1u +
-                                ((funnel32(r[j + 1], r[j + 2], s) & mask_hi) * 0x85EBCA77u + 0x27D4EB2Fu);
-            if (hf < best_f) {
-                best_f = hf;
-                pos_f = i;
-            }
-            if (hr < best_r) {
-                best_r = hr;
-                pos_r = i;
-            }
+            const uint32_t hf = sk_select_hash(funnel32(f[j], f[j + 1], s) & mask) | i;
+            const uint32_t hr = sk_select_hash(funnel32(r[j], r[j + 1], s) & mask) | i;
+            best_f = hf < best_f ? hf : best_f;
+            best_r = hr < best_r ? hr : best_r;
         }
     }
     sk_key_t out;
-    out.rc = best_r < best_f;
-    out.tie = best_r == best_f;
-    out.pos = out.rc ? pos_r : pos_f;
+    out.rc = (best_r >> SK_POS_BITS) < (best_f >> SK_POS_BITS);
+    out.tie = (best_r >> SK_POS_BITS) == (best_f >> SK_POS_BITS);
+    out.pos = (out.rc ? best_r : best_f) & ((1u << SK_POS_BITS) - 1u);
     out.key = kmer_shr_chars<W>(out.rc ? x_rc : x, out.pos).w[0] & low_mask(2 * m);
     return out;
 }

@@ -499,6 +499,8 @@ __device__ __forceinline__ void sk_examine_slot(dict_view const& d, sk_query_t<W
         /* decided now, in its own register: hipcc 7.2 has been seen recycling a slot word that is only
            consumed much later */
         uint32_t go_on = meta & (SK_GO_ON << c);
+        /* first choice: only if a key with this query's filter index went on from here (device_layout.hpp) */
+        if (c == 0) go_on &= 0u - ((meta >> (SK_FILTER_SHIFT + sk_filter_index(Q.fingerprint))) & 1u);
         asm volatile("" : "+v"(go_on));
         flags.go_on = go_on;
         flags.second_used = (meta & SK_SECOND_USED) != 0;

@@ -212,7 +212,8 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
                 }
             }
             if (!S) {
-                atomicOr(B, SK_GO_ON << choice);  // this item lives further along -- or, after the last choice, nowhere
+                /* this item lives further along -- or, after the last choice, nowhere */
+                atomicOr(B, (SK_GO_ON << choice) | (choice == 0 ? 1u << (SK_FILTER_SHIFT + sk_filter_index(h.fingerprint)) : 0u));
                 unplaced = choice + 1 == SK_CHOICES;
             } else {
                 placed[t] = 1;

@@ -104,15 +104,16 @@ def mmer_hash(mmer_str, seed=1):
 
 
 def table_key_hash(mmer_str):
-    """sk_mmer_hash of csrc/device_layout.hpp (the super-k-mer table's own 32-bit m-mer hash), taken over
-    both strands: an m-mer with a small value wins the table's key election of any window it appears in."""
+    """sk_select_hash of csrc/device_layout.hpp (the super-k-mer table's own election hash: 26 bits over the first
+    min(m, 16) bases of an m-mer occurrence), taken over both strands: an m-mer with a small value wins the table's
+    key election of any window it appears in."""
     comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
 
     def h(t):
         x = 0
-        for i, c in enumerate(t):
+        for i, c in enumerate(t[:16]):
             x |= ((ord(c) >> 1) & 3) << (2 * i)
-        return ((x & 0xFFFFFFFF) * 0x9E3779B1 + ((x >> 32) * 0x85EBCA77 + 0x27D4EB2F)) & 0xFFFFFFFF
+        return (((x ^ 0x6A09E667) * 0x9E3779B1) & 0xFFFFFFFF) >> 6
 
     return min(h(mmer_str), h("".join(comp[c] for c in reversed(mmer_str))))
 

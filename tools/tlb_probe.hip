@@ -181,6 +181,10 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL(gather_coop<2>, grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
         } else if (!strcmp(kernel, "coop") && width == 64) {
             hipLaunchKernelGGL(gather_coop<4>, grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
+        } else if (!strcmp(kernel, "coop") && width == 128) {
+            hipLaunchKernelGGL(gather_coop<8>, grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
+        } else if (!strcmp(kernel, "coop") && width == 256) {
+            hipLaunchKernelGGL(gather_coop<16>, grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
         } else if (width == 8) hipLaunchKernelGGL(gather<8>, grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
         else if (width == 16) hipLaunchKernelGGL(gather<16>, grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
         else if (width == 32) hipLaunchKernelGGL(gather<32>, grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
