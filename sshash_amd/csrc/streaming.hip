@@ -58,6 +58,38 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
     return v;
 }
 
+/* The counters of a workgroup (of 256) reach `report` with ONE set of atomics: the six counters share a cache line, and a set
+   per wave -- 2 x 10^5 atomics on one line for 3 x 10^8 bases -- serialises at ~90 atomics/us. Called by
+   every lane of the workgroup. */
+__device__ __forceinline__ void block_report(uint64_t c_kmers, uint64_t c_invalid, uint64_t c_negative, uint64_t c_searches,
+                                             uint64_t c_extensions, uint64_t* __restrict__ report) {
+    __shared__ uint64_t partial[4][5];
+    c_kmers = wave_sum(c_kmers);
+    c_invalid = wave_sum(c_invalid);
+    c_negative = wave_sum(c_negative);
+    c_searches = wave_sum(c_searches);
+    c_extensions = wave_sum(c_extensions);
+    if ((threadIdx.x & 63) == 0) {
+        uint64_t* mine = partial[threadIdx.x >> 6];
+        mine[0] = c_kmers;
+        mine[1] = c_invalid;
+        mine[2] = c_negative;
+        mine[3] = c_searches;
+        mine[4] = c_extensions;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    uint64_t t[5];
+    for (int j = 0; j < 5; ++j) t[j] = partial[0][j] + partial[1][j] + partial[2][j] + partial[3][j];
+    if (t[0] == 0) return;
+    atomicAdd(reinterpret_cast<unsigned long long*>(report + 0), (unsigned long long)t[0]);
+    atomicAdd(reinterpret_cast<unsigned long long*>(report + 1), (unsigned long long)(t[3] + t[4]));
+    atomicAdd(reinterpret_cast<unsigned long long*>(report + 2), (unsigned long long)t[2]);
+    atomicAdd(reinterpret_cast<unsigned long long*>(report + 3), (unsigned long long)t[1]);
+    atomicAdd(reinterpret_cast<unsigned long long*>(report + 4), (unsigned long long)t[3]);
+    atomicAdd(reinterpret_cast<unsigned long long*>(report + 5), (unsigned long long)t[4]);
+}
+
 template <int W, bool CANON, bool SK>
 __global__ void __launch_bounds__(256)
 streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const char* __restrict__ bases,
@@ -153,19 +185,7 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
             }
         }
     }
-    c_kmers = wave_sum(c_kmers);
-    c_invalid = wave_sum(c_invalid);
-    c_negative = wave_sum(c_negative);
-    c_searches = wave_sum(c_searches);
-    c_extensions = wave_sum(c_extensions);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 0), (unsigned long long)c_kmers);
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 1), (unsigned long long)(c_searches + c_extensions));
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 2), (unsigned long long)c_negative);
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 3), (unsigned long long)c_invalid);
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 4), (unsigned long long)c_searches);
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 5), (unsigned long long)c_extensions);
-    }
+    block_report(c_kmers, c_invalid, c_negative, c_searches, c_extensions, report);
 }
 
 template <int W, bool CANON>
@@ -221,26 +241,39 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t v) {  // 0x80 in ever
     return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
 }
 
+/* The read holding the first base of every tile of 256 places: one lane per TILE. (Looked up by lane 0 of the tile's own
+   workgroup, these ~20 dependent loads were the lifetime of the workgroup: the encode pass was slower than the lookups.) */
+__global__ void __launch_bounds__(256)
+stream_tile_reads_kernel(const uint64_t* __restrict__ offsets, const uint64_t n_reads, const uint64_t first, const uint64_t tiles,
+                         uint64_t* __restrict__ tile_read) {
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    const uint64_t g0 = first + t * 256;
+    uint64_t lo = 0, hi = n_reads - 1;  // largest r with offsets[r] <= g0
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (offsets[mid] <= g0) lo = mid;
+        else hi = mid - 1;
+    }
+    tile_read[t] = lo;
+}
+
 template <int W>
 __global__ void __launch_bounds__(256)
-stream_encode_kernel(const char* __restrict__ bases, const uint64_t* __restrict__ offsets, const uint64_t n_reads,
+stream_encode_kernel(const char* __restrict__ bases, const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ tile_read, const uint64_t n_reads,
                      const uint64_t total_bases, const uint64_t first, const uint64_t count, const uint32_t k,
                      uint64_t* __restrict__ kmers /* relative to `first` */, uint8_t* __restrict__ flags /* absolute */) {
     constexpr uint32_t TILE = 256, SPAN = TILE + 64;
     __shared__ uint32_t chars[SPAN / 4 + 2];
+    /* the same characters as 2-bit codes back to back, and one "is A, C, G or T" bit per character: every lane then cuts
+       its k-mer and its k validity bits out of these with funnel shifts (packing k characters per lane from `chars`
+       cost ~100 VALU instructions per position: the encode pass took longer than the lookups it feeds) */
+    __shared__ uint32_t codes[SPAN / 16 + 4];
+    __shared__ uint32_t okay[SPAN / 32 + 4];
     __shared__ uint64_t ends[TILE + 2];  // offsets[r0 + 1 ...]: the read boundaries that may fall into the tile
-    __shared__ uint64_t r0_shared;
     const uint64_t g0 = first + uint64_t(blockIdx.x) * TILE;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) {  // the read holding the tile's first base: largest r with offsets[r] <= g0
-        uint64_t lo = 0, hi = n_reads - 1;
-        while (lo < hi) {
-            const uint64_t mid = lo + (hi - lo + 1) / 2;
-            if (offsets[mid] <= g0) lo = mid;
-            else hi = mid - 1;
-        }
-        r0_shared = lo;
-    }
+    const uint64_t r0 = tile_read[blockIdx.x];  // the read holding the tile's first base
     /* the characters of the tile and the k - 1 after it */
     for (uint32_t c = tid; c < SPAN / 4 + 2; c += TILE) {
         const uint64_t at = g0 + 4 * uint64_t(c);
@@ -252,7 +285,21 @@ stream_encode_kernel(const char* __restrict__ bases, const uint64_t* __restrict_
         chars[c] = v;
     }
     __syncthreads();
-    const uint64_t r0 = r0_shared;
+    for (uint32_t c = tid; c < SPAN / 4 + 2; c += TILE) {
+        const uint32_t four = chars[c];
+        uint32_t two = (four >> 1) & 0x03030303u;  // (c >> 1) & 3 (include/kmer.hpp:118) for four characters at once
+        two = (two | (two >> 6) | (two >> 12) | (two >> 18)) & 0xFFu;
+        reinterpret_cast<uint8_t*>(codes)[c] = uint8_t(two);
+    }
+    for (uint32_t q = tid; q < SPAN + 64; q += TILE) {  // uniform over each wave: whole waves take part in the ballot
+        /* A C G T a c g t only (include/kmer.hpp:209-219): fold the case */
+        const uint32_t u = (q < 4 * (SPAN / 4 + 2) ? reinterpret_cast<const uint8_t*>(chars)[q] : 0u) & 0xDFu;
+        const uint64_t mask = __ballot(u == 0x41u || u == 0x43u || u == 0x47u || u == 0x54u);
+        if ((q & 63u) == 0) {
+            okay[q / 32] = uint32_t(mask);
+            okay[q / 32 + 1] = uint32_t(mask >> 32);
+        }
+    }
     for (uint32_t c = tid; c < TILE + 2; c += TILE) ends[c] = r0 + 1 + c <= n_reads ? offsets[r0 + 1 + c] : ~uint64_t(0);
     __syncthreads();
     const uint64_t p = g0 + tid;
@@ -281,23 +328,15 @@ stream_encode_kernel(const char* __restrict__ bases, const uint64_t* __restrict_
     uint8_t f = 0;
     kmer_w<W> x = kmer_zero<W>();
     if (p + k <= end) {
-        bool valid = true;
-        const uint32_t w0 = tid >> 2, sh = tid & 3;
-        for (uint32_t j = 0; 4 * j < k; ++j) {
-            const uint32_t four = __builtin_amdgcn_alignbyte(chars[w0 + j + 1], chars[w0 + j], sh);
-            const uint32_t rem = k - 4 * j;
-            /* A C G T a c g t only (include/kmer.hpp:209-219): fold the case, every byte must be one of the four */
-            const uint32_t u = four & 0xDFDFDFDFu;
-            uint32_t bad = nonzero_bytes(u ^ 0x41414141u) & nonzero_bytes(u ^ 0x43434343u) & nonzero_bytes(u ^ 0x47474747u) &
-                           nonzero_bytes(u ^ 0x54545454u);
-            if (rem < 4) bad &= (1u << (8 * rem)) - 1;
-            valid = valid && bad == 0;
-            uint32_t c = (four >> 1) & 0x03030303u;  // (c >> 1) & 3 for four characters at once
-            c = (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xFFu;
-            if (rem < 4) c &= (1u << (2 * rem)) - 1;
-            if (8 * j < 64) x.w[0] |= uint64_t(c) << (8 * j);
-            else if constexpr (W == 2) x.w[1] |= uint64_t(c) << (8 * j - 64);
-        }
+        const uint32_t cw = tid >> 4, cs = 2 * (tid & 15u);
+        uint32_t word[2 * W];
+        for (int j = 0; j < 2 * W; ++j) word[j] = __builtin_amdgcn_alignbit(codes[cw + j + 1], codes[cw + j], cs);
+        for (int j = 0; j < W; ++j) x.w[j] = uint64_t(word[2 * j]) | (uint64_t(word[2 * j + 1]) << 32);
+        x = kmer_take_chars<W>(x, k);
+        const uint32_t vw = tid >> 5, vs = tid & 31u;
+        const uint64_t ok = uint64_t(__builtin_amdgcn_alignbit(okay[vw + 1], okay[vw], vs)) |
+                            (uint64_t(__builtin_amdgcn_alignbit(okay[vw + 2], okay[vw + 1], vs)) << 32);
+        const bool valid = (~ok & low_mask(k)) == 0;  // k <= 63
         f = (valid ? SQ_VALID : SQ_INVALID) | (p == begin ? SQ_FIRST : 0);
     }
     flags[p] = f;
@@ -310,51 +349,60 @@ stream_classify_kernel(const uint8_t* __restrict__ flags, const uint64_t total_b
     /* grid-stride: the six counters are accumulated in registers and reach `report` once per wave -- one hot set of
        atomics per wave of 64 k-mers would serialise at ~90 atomics/us */
     uint64_t c_kmer = 0, c_invalid = 0, c_negative = 0, c_search = 0, c_extension = 0;
-    const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
-    for (uint64_t p = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < total_bases; p += stride) {
-        const uint8_t f = flags[p];
-        if (f & SQ_INVALID) {
-            /* what streaming_query::lookup returns after its reset(): a default lookup_result (include/util.hpp:38-62) */
-            ++c_kmer;
-            ++c_invalid;
-            out.kmer_id[p] = INVALID_U64;
-            if (out.kmer_id_in_string) out.kmer_id_in_string[p] = INVALID_U64;
-            if (out.kmer_offset) out.kmer_offset[p] = INVALID_U64;
-            if (out.string_id) out.string_id[p] = INVALID_U64;
-            if (out.string_begin) out.string_begin[p] = INVALID_U64;
-            if (out.string_end) out.string_end[p] = INVALID_U64;
-            if (out.kmer_orientation) out.kmer_orientation[p] = 1;
-        } else if (f & SQ_VALID) {
-            ++c_kmer;
-            const uint64_t id = out.kmer_id[p];
-            if (id == INVALID_U64) {
-                ++c_negative;
-            } else {
-                bool extension = false;
-                if (!(f & SQ_FIRST) && (flags[p - 1] & SQ_VALID)) {
-                    const uint64_t before = out.kmer_id[p - 1];
-                    extension = before != INVALID_U64 && string_id[p - 1] == string_id[p] &&
-                                id == before + uint64_t(int64_t(orientation[p - 1]));
+    /* Four consecutive places per lane and turn, everything they may need requested at once (what a branch does not use
+       is ignored): one load after the other, each behind its test, made a chain of round trips per place, and the pass
+       ran at a quarter of the memory rate. `flags` is this file's own array (4-byte loads); the others may be the caller's. */
+    constexpr uint32_t PLACES = 4;
+    const uint64_t stride = uint64_t(gridDim.x) * blockDim.x * PLACES;
+    for (uint64_t p0 = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) * PLACES; p0 < total_bases; p0 += stride) {
+        const uint64_t q = p0 ? p0 - 1 : 0;
+        uint8_t f[PLACES + 1];
+        uint64_t id[PLACES + 1], sid[PLACES + 1];
+        int8_t ori[PLACES + 1];
+        f[0] = flags[q];
+        id[0] = out.kmer_id[q];
+        sid[0] = string_id[q];
+        ori[0] = orientation[q];
+        const bool whole = p0 + PLACES <= total_bases && ((reinterpret_cast<uintptr_t>(flags) + p0) & 3) == 0;
+        const uint32_t four = whole ? *reinterpret_cast<const uint32_t*>(flags + p0) : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < PLACES; ++j) {
+            const uint64_t p = p0 + j < total_bases ? p0 + j : total_bases - 1;
+            f[j + 1] = whole ? uint8_t(four >> (8 * j)) : flags[p];
+            id[j + 1] = out.kmer_id[p];
+            sid[j + 1] = string_id[p];
+            ori[j + 1] = orientation[p];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < PLACES; ++j) {
+            const uint64_t p = p0 + j;
+            if (p >= total_bases) break;
+            if (f[j + 1] & SQ_INVALID) {
+                /* what streaming_query::lookup returns after its reset(): a default lookup_result (include/util.hpp:38-62) */
+                ++c_kmer;
+                ++c_invalid;
+                out.kmer_id[p] = INVALID_U64;
+                if (out.kmer_id_in_string) out.kmer_id_in_string[p] = INVALID_U64;
+                if (out.kmer_offset) out.kmer_offset[p] = INVALID_U64;
+                if (out.string_id) out.string_id[p] = INVALID_U64;
+                if (out.string_begin) out.string_begin[p] = INVALID_U64;
+                if (out.string_end) out.string_end[p] = INVALID_U64;
+                if (out.kmer_orientation) out.kmer_orientation[p] = 1;
+            } else if (f[j + 1] & SQ_VALID) {
+                ++c_kmer;
+                if (id[j + 1] == INVALID_U64) {
+                    ++c_negative;
+                } else {
+                    const bool extension = !(f[j + 1] & SQ_FIRST) && (f[j] & SQ_VALID) && id[j] != INVALID_U64 && sid[j] == sid[j + 1] &&
+                                           id[j + 1] == id[j] + uint64_t(int64_t(ori[j]));
+                    c_extension += extension;
+                    c_search += !extension;
                 }
-                c_extension += extension;
-                c_search += !extension;
             }
         }
     }
-    if (!report) return;
-    c_kmer = wave_sum(c_kmer);
-    c_invalid = wave_sum(c_invalid);
-    c_negative = wave_sum(c_negative);
-    c_search = wave_sum(c_search);
-    c_extension = wave_sum(c_extension);
-    if ((threadIdx.x & 63) == 0 && c_kmer) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 0), (unsigned long long)c_kmer);
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 1), (unsigned long long)(c_search + c_extension));
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 2), (unsigned long long)c_negative);
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 3), (unsigned long long)c_invalid);
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 4), (unsigned long long)c_search);
-        atomicAdd(reinterpret_cast<unsigned long long*>(report + 5), (unsigned long long)c_extension);
-    }
+    if (!report) return;  // uniform
+    block_report(c_kmer, c_invalid, c_negative, c_search, c_extension, report);
 }
 
 void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t const* d_read_offsets, uint64_t n_reads,
@@ -376,6 +424,8 @@ void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t c
     if (!ids) HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&ids), total_bases * sizeof(uint64_t), s));
     HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&flags), total_bases, s));
     HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&kmers), chunk * W * sizeof(uint64_t), s));
+    uint64_t* tile_read = nullptr;
+    HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tile_read), ((chunk + 255) / 256) * sizeof(uint64_t), s));
     if (!sid) HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&sid), total_bases * sizeof(uint64_t), s));
     if (!ori) HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&ori), total_bases, s));
     result_view all = d_out;
@@ -385,8 +435,9 @@ void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t c
     for (uint64_t first = 0; first < total_bases; first += chunk) {
         const uint64_t count = std::min(chunk, total_bases - first);
         const dim3 grid(uint32_t((count + 255) / 256)), block(256);
-        if (W == 1) hipLaunchKernelGGL(stream_encode_kernel<1>, grid, block, 0, s, d_bases, d_read_offsets, n_reads, total_bases, first, count, d.k, kmers, flags);
-        else hipLaunchKernelGGL(stream_encode_kernel<2>, grid, block, 0, s, d_bases, d_read_offsets, n_reads, total_bases, first, count, d.k, kmers, flags);
+        hipLaunchKernelGGL(stream_tile_reads_kernel, dim3((grid.x + 255) / 256), block, 0, s, d_read_offsets, n_reads, first, uint64_t(grid.x), tile_read);
+        if (W == 1) hipLaunchKernelGGL(stream_encode_kernel<1>, grid, block, 0, s, d_bases, d_read_offsets, tile_read, n_reads, total_bases, first, count, d.k, kmers, flags);
+        else hipLaunchKernelGGL(stream_encode_kernel<2>, grid, block, 0, s, d_bases, d_read_offsets, tile_read, n_reads, total_bases, first, count, d.k, kmers, flags);
         HIP_CHECK(hipGetLastError());
         result_view part = all;
         part.kmer_id += first;
@@ -408,7 +459,7 @@ void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t c
         if (part.string_begin) part.string_begin += first;
         if (part.string_end) part.string_end += first;
         if (part.kmer_orientation) part.kmer_orientation += first;
-        hipLaunchKernelGGL(stream_classify_kernel, dim3(uint32_t(std::min<uint64_t>((count + 255) / 256, 8192))), dim3(256), 0, s, flags + first, count, part,
+        hipLaunchKernelGGL(stream_classify_kernel, dim3(uint32_t(std::min<uint64_t>((count + 1023) / 1024, 2048))), dim3(256), 0, s, flags + first, count, part,
                            sid + first, ori + first, d_report);
         HIP_CHECK(hipGetLastError());
     }
@@ -416,6 +467,7 @@ void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t c
     if (!d_out.kmer_orientation) HIP_CHECK(hipFreeAsync(ori, s));
     if (!d_out.string_id) HIP_CHECK(hipFreeAsync(sid, s));
     HIP_CHECK(hipFreeAsync(kmers, s));
+    HIP_CHECK(hipFreeAsync(tile_read, s));
     HIP_CHECK(hipFreeAsync(flags, s));
 }
 
