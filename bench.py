@@ -135,8 +135,8 @@ def traffic_record(d, n_local: int, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--bases", type=int, default=None, help="bases in the synthetic SPSS (default: the workload's)")
     ap.add_argument("--queries", type=int, default=None, help="queries in the batch, ALL GPUs together (default: the workload's)")

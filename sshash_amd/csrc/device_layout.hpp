@@ -233,7 +233,7 @@ SSH_HD uint64_t sk_kmer_key(kmer_w<W> const& x, kmer_w<W> const& x_rc) {
    choose the same one. The table is free to use any such function (it is built and probed with the same one), so
    this is NOT the reference's minimizer. The election looks at the first min(m, 16) bases of every m-mer occurrence
    only -- ONE 32-bit word per candidate, one funnel shift to extract it, one 32-bit multiply to hash it -- and carries
-   the candidate's position in the low 6 bits of the hash, so that a running minimum replaces compare-and-select: six
+   the candidate's position in the low 6 bits of the hash, so that a running minimum replaces compare-and-select: four
    VALU instructions per candidate (the first version hashed the whole m-mer: eleven; at k = 63, m = 25 the 78
    candidates made the first pass VALU-bound). Per strand the leftmost occurrence with the smallest
    26-bit hash wins; the strand with the smaller winning hash supplies the key -- the whole m-mer at the elected
@@ -246,9 +246,18 @@ struct sk_key_t {
 };
 
 constexpr uint32_t SK_POS_BITS = 6;  // positions 0 .. k - m <= 62
-/* 26-bit election hash (in the top bits) of the first bases of an m-mer occurrence; the xor keeps poly-A (word 0) from
-   winning every election it takes part in */
-SSH_HD uint32_t sk_select_hash(uint32_t prefix) { return ((prefix ^ 0x6A09E667u) * 0x9E3779B1u) & ~((1u << SK_POS_BITS) - 1u); }
+/* 26-bit election hash (in the top bits) of the first bases of an m-mer occurrence: (bases ^ salt) * constant. The salt keeps
+   poly-A (all zero) from winning every election it takes part in. Two salts:
+     k <= 31  SK_SELECT_SALT, irregular, applied to every candidate: consecutive candidates are shifts of one another and
+              a multiplicative hash alone orders them in a correlated way -- 2 % more super-k-mers (table slots) measured
+              with a salt that commutes with the shift; the lookup is bound by memory there, not by instructions;
+     k <= 63  SK_SELECT_FLIP, whose pattern repeats every base and so commutes with a shift by whole bases: the k-mer's
+              words are salted once instead of 78 candidates one by one -- there the election is what bounds the first
+              pass (92 % VALU utilisation before), and the denser election costs less than it saves. */
+constexpr uint32_t SK_SELECT_SALT = 0x6A09E667u, SK_SELECT_FLIP = 0xAAAAAAAAu;
+template <int W>
+SSH_HD uint32_t sk_select_salt() { return W == 1 ? SK_SELECT_SALT : SK_SELECT_FLIP; }
+SSH_HD uint32_t sk_select_hash(uint32_t salted) { return (salted * 0x9E3779B1u) & ~((1u << SK_POS_BITS) - 1u); }
 
 /* low 32 bits of (hi:lo) >> s, s in 0..31: one v_alignbit_b32 on the device (a 64-bit shift costs five times as much) */
 SSH_HD uint32_t funnel32(uint32_t lo, uint32_t hi, uint32_t s) {
@@ -259,22 +268,12 @@ SSH_HD uint32_t funnel32(uint32_t lo, uint32_t hi, uint32_t s) {
 #endif
 }
 
-template <int W>
-SSH_HD sk_key_t sk_key(kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m) {
-    /* the k-mer as 32-bit words (16 bases each), one zero word behind it: the 16 bases starting at base i = 16 j + t are
-       words j, j+1 shifted right by 2 t -- a funnel shift instead of a 64-bit (or 128-bit) shift */
-    constexpr int D = 2 * W;
-    uint32_t f[D + 1], r[D + 1];
-    for (int j = 0; j < W; ++j) {
-        f[2 * j] = uint32_t(x.w[j]);
-        f[2 * j + 1] = uint32_t(x.w[j] >> 32);
-        r[2 * j] = uint32_t(x_rc.w[j]);
-        r[2 * j + 1] = uint32_t(x_rc.w[j] >> 32);
-    }
-    f[D] = r[D] = 0;
-    const uint32_t mask = m >= 16 ? 0xFFFFFFFFu : (1u << (2 * m)) - 1;
-    uint32_t best_f = 0xFFFFFFFFu, best_r = 0xFFFFFFFFu;
-    const uint32_t n = k - m + 1;
+/* the election over one strand: f = the strand's words (SALT_EACH false: already salted), one more word behind them.
+   MASKED: m < 16 (the hashed word is cut to 2m bits). Four instructions per candidate at best: funnel shift, multiply,
+   and-or, minimum */
+template <int D, bool MASKED, bool SALT_EACH>
+SSH_HD uint32_t sk_elect(uint32_t const (&f)[D + 1], uint32_t n, uint32_t mask) {
+    uint32_t best = 0xFFFFFFFFu;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -285,12 +284,40 @@ SSH_HD sk_key_t sk_key(kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, ui
         for (uint32_t t = 0; t < 16; ++t) {
             const uint32_t i = 16 * uint32_t(j) + t;
             if (i >= n) break;
-            const uint32_t s = 2 * t;
-            const uint32_t hf = sk_select_hash(funnel32(f[j], f[j + 1], s) & mask) | i;
-            const uint32_t hr = sk_select_hash(funnel32(r[j], r[j + 1], s) & mask) | i;
-            best_f = hf < best_f ? hf : best_f;
-            best_r = hr < best_r ? hr : best_r;
+            uint32_t word = funnel32(f[j], f[j + 1], 2 * t);
+            if constexpr (SALT_EACH) word ^= SK_SELECT_SALT;
+            if constexpr (MASKED) word &= mask;
+            const uint32_t h = sk_select_hash(word) | i;
+            best = h < best ? h : best;
         }
+    }
+    return best;
+}
+
+template <int W>
+SSH_HD sk_key_t sk_key(kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m) {
+    /* the k-mer as 32-bit words (16 bases each), one more word behind it: the 16 bases starting at base i = 16 j + t are
+       words j, j+1 shifted right by 2 t -- a funnel shift instead of a 64-bit (or 128-bit) shift */
+    constexpr int D = 2 * W;
+    constexpr bool EACH = W == 1;                       // see SK_SELECT_SALT
+    constexpr uint32_t once = EACH ? 0u : SK_SELECT_FLIP;
+    uint32_t f[D + 1], r[D + 1];
+    for (int j = 0; j < W; ++j) {
+        f[2 * j] = uint32_t(x.w[j]) ^ once;
+        f[2 * j + 1] = uint32_t(x.w[j] >> 32) ^ once;
+        r[2 * j] = uint32_t(x_rc.w[j]) ^ once;
+        r[2 * j + 1] = uint32_t(x_rc.w[j] >> 32) ^ once;
+    }
+    f[D] = r[D] = once;
+    const uint32_t n = k - m + 1;
+    uint32_t best_f, best_r;
+    if (m >= 16) {  // uniform
+        best_f = sk_elect<D, false, EACH>(f, n, 0u);
+        best_r = sk_elect<D, false, EACH>(r, n, 0u);
+    } else {
+        const uint32_t mask = (1u << (2 * m)) - 1;
+        best_f = sk_elect<D, true, EACH>(f, n, mask);
+        best_r = sk_elect<D, true, EACH>(r, n, mask);
     }
     sk_key_t out;
     out.rc = (best_r >> SK_POS_BITS) < (best_f >> SK_POS_BITS);

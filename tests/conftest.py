@@ -103,7 +103,7 @@ def mmer_hash(mmer_str, seed=1):
     return ((x * 0x517CC1B727220A95) & ((1 << 64) - 1)) ^ O.xxh64_u64(seed, 0)
 
 
-def table_key_hash(mmer_str):
+def table_key_hash(mmer_str, k=31):
     """sk_select_hash of csrc/device_layout.hpp (the super-k-mer table's own election hash: 26 bits over the first
     min(m, 16) bases of an m-mer occurrence), taken over both strands: an m-mer with a small value wins the table's
     key election of any window it appears in."""
@@ -113,7 +113,9 @@ def table_key_hash(mmer_str):
         x = 0
         for i, c in enumerate(t[:16]):
             x |= ((ord(c) >> 1) & 3) << (2 * i)
-        return (((x ^ 0x6A09E667) * 0x9E3779B1) & 0xFFFFFFFF) >> 6
+        mask = 0xFFFFFFFF if len(t) >= 16 else (1 << (2 * len(t))) - 1
+        salt = 0x6A09E667 if k <= 31 else 0xAAAAAAAA  # SK_SELECT_SALT / SK_SELECT_FLIP
+        return ((((x ^ salt) & mask) * 0x9E3779B1) & 0xFFFFFFFF) >> 6
 
     return min(h(mmer_str), h("".join(comp[c] for c in reversed(mmer_str))))
 
@@ -138,7 +140,7 @@ def skewed_sequences(k, m, seed=3, n_heavy=150, n_mid=7, n_plain=60, canonical=F
     seqs.append(random_dna(rng, k))  # a string holding exactly one k-mer
     # the same for the device's super-k-mer table, which elects keys with its own hash: one key with more
     # occurrences than the table lists (left to the complete path), one with a list in `occ`, one with two
-    table_motifs = [c for c in sorted(cands, key=table_key_hash) if c not in motifs][:3]
+    table_motifs = [c for c in sorted(cands, key=lambda c: table_key_hash(c, k)) if c not in motifs][:3]
     comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
 
     def canonical_kmers(t):

@@ -33,15 +33,15 @@ static int check(uint32_t k, uint32_t m, uint64_t trials, std::mt19937_64& rng, 
         if ((kmer_shr_chars<W>(winner, a.pos).w[0] & mask) != a.key) return printf("key is not the m-mer at its position\n"), 1;
         /* leftmost among equal hashes on the winning strand */
         const uint32_t prefix_mask = m >= 16 ? 0xFFFFFFFFu : uint32_t(mask);
-        const uint32_t won = sk_select_hash(uint32_t(a.key) & prefix_mask);
+        const uint32_t won = sk_select_hash((uint32_t(a.key) ^ sk_select_salt<W>()) & prefix_mask);
         for (uint32_t i = 0; i + m <= k; ++i) {
-            const uint32_t h = sk_select_hash(uint32_t(kmer_shr_chars<W>(winner, i).w[0]) & prefix_mask);
+            const uint32_t h = sk_select_hash((uint32_t(kmer_shr_chars<W>(winner, i).w[0]) ^ sk_select_salt<W>()) & prefix_mask);
             if (i < a.pos ? h <= won : h < won)
                 return printf("another m-mer of the winning strand should have been elected (k=%u m=%u)\n", k, m), 1;
         }
         const kmer_w<W>& loser = a.rc ? x : y;
         for (uint32_t i = 0; i + m <= k; ++i)
-            if (sk_select_hash(uint32_t(kmer_shr_chars<W>(loser, i).w[0]) & prefix_mask) <= won)
+            if (sk_select_hash((uint32_t(kmer_shr_chars<W>(loser, i).w[0]) ^ sk_select_salt<W>()) & prefix_mask) <= won)
                 return printf("an m-mer of the other strand should have been elected (k=%u m=%u)\n", k, m), 1;
     }
     return 0;
