@@ -257,7 +257,10 @@ constexpr uint32_t SK_POS_BITS = 6;  // positions 0 .. k - m <= 62
 constexpr uint32_t SK_SELECT_SALT = 0x6A09E667u, SK_SELECT_FLIP = 0xAAAAAAAAu;
 template <int W>
 SSH_HD uint32_t sk_select_salt() { return W == 1 ? SK_SELECT_SALT : SK_SELECT_FLIP; }
-SSH_HD uint32_t sk_select_hash(uint32_t salted) { return (salted * 0x9E3779B1u) & ~((1u << SK_POS_BITS) - 1u); }
+/* the multiplier carries the shift that makes room for the position: (salted * odd) << 6 -- a bijection on the first 13
+   bases, the best-mixed bits of the product on top; one multiply, no masking (and + or would be two more instructions:
+   gfx950's v_and_or_b32 takes no 32-bit literal) */
+SSH_HD uint32_t sk_select_hash(uint32_t salted) { return salted * (0x9E3779B1u << SK_POS_BITS); }
 
 /* low 32 bits of (hi:lo) >> s, s in 0..31: one v_alignbit_b32 on the device (a 64-bit shift costs five times as much) */
 SSH_HD uint32_t funnel32(uint32_t lo, uint32_t hi, uint32_t s) {
@@ -283,11 +286,15 @@ SSH_HD uint32_t sk_elect(uint32_t const (&f)[D + 1], uint32_t n, uint32_t mask) 
 #endif
         for (uint32_t t = 0; t < 16; ++t) {
             const uint32_t i = 16 * uint32_t(j) + t;
-            if (i >= n) break;
+            if (16 * uint32_t(j) >= n) break;  // whole words beyond the last candidate
             uint32_t word = funnel32(f[j], f[j + 1], 2 * t);
             if constexpr (SALT_EACH) word ^= SK_SELECT_SALT;
             if constexpr (MASKED) word &= mask;
-            const uint32_t h = sk_select_hash(word) | i;
+            /* a candidate beyond the last one loses every comparison; n is the same for all lanes, so this tag is computed
+               by the scalar unit and the vector side spends one OR on position and bound together (a `break` here is
+               compiled into a select per candidate) */
+            const uint32_t tag = i < n ? i : 0xFFFFFFFFu;
+            const uint32_t h = sk_select_hash(word) | tag;
             best = h < best ? h : best;
         }
     }

@@ -115,7 +115,7 @@ def table_key_hash(mmer_str, k=31):
             x |= ((ord(c) >> 1) & 3) << (2 * i)
         mask = 0xFFFFFFFF if len(t) >= 16 else (1 << (2 * len(t))) - 1
         salt = 0x6A09E667 if k <= 31 else 0xAAAAAAAA  # SK_SELECT_SALT / SK_SELECT_FLIP
-        return ((((x ^ salt) & mask) * 0x9E3779B1) & 0xFFFFFFFF) >> 6
+        return ((((x ^ salt) & mask) * (0x9E3779B1 << 6)) & 0xFFFFFFFF) >> 6
 
     return min(h(mmer_str), h("".join(comp[c] for c in reversed(mmer_str))))
 
