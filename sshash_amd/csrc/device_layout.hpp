@@ -273,29 +273,37 @@ SSH_HD uint32_t funnel32(uint32_t lo, uint32_t hi, uint32_t s) {
 
 /* the election over one strand: f = the strand's words (SALT_EACH false: already salted), one more word behind them.
    MASKED: m < 16 (the hashed word is cut to 2m bits). Four instructions per candidate at best: funnel shift, multiply,
-   and-or, minimum */
+   or, minimum */
 template <int D, bool MASKED, bool SALT_EACH>
 SSH_HD uint32_t sk_elect(uint32_t const (&f)[D + 1], uint32_t n, uint32_t mask) {
     uint32_t best = 0xFFFFFFFFu;
+    auto candidate = [&](uint32_t lo, uint32_t hi, uint32_t t, uint32_t i) {
+        uint32_t word = funnel32(lo, hi, 2 * t);
+        if constexpr (SALT_EACH) word ^= SK_SELECT_SALT;
+        if constexpr (MASKED) word &= mask;
+        const uint32_t h = sk_select_hash(word) | i;
+        best = h < best ? h : best;
+    };
+    /* n is the same for all lanes. A word whose 16 candidates all exist is unrolled: shifts and positions are constants,
+       nothing for the scalar unit to do; the last, partial word is a counted loop. (One loop over all candidates with a
+       bound test per candidate costs a select per candidate on the vector side, or -- the bound folded into a scalar tag --
+       four scalar instructions per candidate: at k = 63 the CU's single scalar unit was then 72 % busy.) */
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int j = 0; j < D; ++j) {
+        if (16 * uint32_t(j + 1) <= n) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 4
+#pragma unroll
 #endif
-        for (uint32_t t = 0; t < 16; ++t) {
-            const uint32_t i = 16 * uint32_t(j) + t;
-            if (16 * uint32_t(j) >= n) break;  // whole words beyond the last candidate
-            uint32_t word = funnel32(f[j], f[j + 1], 2 * t);
-            if constexpr (SALT_EACH) word ^= SK_SELECT_SALT;
-            if constexpr (MASKED) word &= mask;
-            /* a candidate beyond the last one loses every comparison; n is the same for all lanes, so this tag is computed
-               by the scalar unit and the vector side spends one OR on position and bound together (a `break` here is
-               compiled into a select per candidate) */
-            const uint32_t tag = i < n ? i : 0xFFFFFFFFu;
-            const uint32_t h = sk_select_hash(word) | tag;
-            best = h < best ? h : best;
+            for (uint32_t t = 0; t < 16; ++t) candidate(f[j], f[j + 1], t, 16 * uint32_t(j) + t);
+        } else {
+            const uint32_t rest = n > 16 * uint32_t(j) ? n - 16 * uint32_t(j) : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+            for (uint32_t t = 0; t < rest; ++t) candidate(f[j], f[j + 1], t, 16 * uint32_t(j) + t);
+            break;
         }
     }
     return best;
