@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+RANDOM_UNIT_PROBE = 43.75e9  # random 64-byte units/s one MI355X sustains on a 32 GiB array (tools/tlb_probe)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
@@ -316,7 +317,12 @@ def main():
                     "algorithmic_bytes_per_lookup": round(bytes_per_lookup, 2),
                     "algorithmic_bytes_rule": "SURVEY 8(d): 8 B per distinct 64-bit index word the REFERENCE algorithm dereferences "
                                               "+ query in + id out, counted by the instrumented oracle on this batch",
-                    "avg_kernel_ms": round(avg_kernel_ms, 3)}
+                    "avg_kernel_ms": round(avg_kernel_ms, 3),
+                    # what bounds a structure of one random bucket per query on this chip is random UNITS, not bytes: 43.8 G
+                    # random 64-byte units/s, 39.9 G 128-byte ones (tools/tlb_probe)
+                    "random_unit_bound": {"probe_units_per_s": RANDOM_UNIT_PROBE, "source": "profiles/r02/tlb_probe_128_256_byte_units.jsonl",
+                                          "lookups_per_s_this_gpu": round(n / (avg_kernel_ms * 1e-3), 1),
+                                          "frac": round(n / (avg_kernel_ms * 1e-3) / RANDOM_UNIT_PROBE, 4)}}
         if traffic:
             # the kernels' own bytes: what the PMC passes of this very workload saw moving between L2 and HBM per step
             # (64 B per bucket line -- both slots of a line are compared --, the query and id streams, the pass queues)
