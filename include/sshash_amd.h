@@ -130,7 +130,13 @@ sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out
  *      src/dictionary.cpp:58-78. Batched. ------------------------------------------------------
  * *_device: `kmers` and every non-NULL array of `out` are DEVICE pointers in the HBM of `device`;
  *           the launch is asynchronous on `hip_stream` (hipStream_t as void*, NULL = default stream).
- * host variants: caller-owned host buffers; the batch is sharded over all resident devices.    */
+ * host variants: caller-owned host buffers; the batch is sharded over all resident devices.
+ * Cost of the fields: NULL arrays are skipped. kmer_id alone, or any of the position fields with it, is answered by the
+ * device's super-k-mer table at full speed (33 G lookups/s); asking for `minimizer_found` sends the
+ * whole batch down the MPHF path (10 G/s), the only one that can reproduce the flag of an absent minimizer -- it depends on
+ * which bucket the MPHF maps that minimizer to (include/spectrum_preserving_string_set.hpp:46-65). (Hits from the table and
+ * only the misses through the MPHF was measured: 9.0 against 10.1 G/s at 50 % positives -- the misses' eight scattered
+ * result stores cost more than the hits save -- and is not done.)                                                    */
 sshash_status sshash_lookup_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
                                           int check_reverse_complement, const sshash_results* out, void* hip_stream);
 sshash_status sshash_lookup_ascii_device(const sshash_dict* d, int device, const char* kmers, uint64_t n,
