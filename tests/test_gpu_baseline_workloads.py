@@ -118,6 +118,60 @@ def test_mixed_batches_match_the_oracle(synthetic_case):
         assert 0.45 < float((got != INVALID).mean()) < 0.56
 
 
+def test_streaming_query_at_the_read_count_of_config_c4(synthetic_case):
+    """BASELINE.json configs[3]: k = 63, streaming_query over 10^8 reads of 150 bases (1.5 x 10^10 bases in one call -- past
+    every 2^32 boundary a launch or an index could trip over). The counters of the whole equal the sum over ten parts, the
+    position-parallel pipeline (counters-only mode) agrees on one part, and num_kmers is reads x (150 - k + 1). Reads are cut
+    out of the dictionary's own strings (concatenated: some run across two strings) with substitutions and N's."""
+    import torch
+
+    c, d = synthetic_case, synthetic_case.dict
+    if c.k != 63:
+        pytest.skip("the C4-shaped case")
+    dev = torch.device("cuda", 0)
+    R, L, parts = 100_000_000, 150, 10
+    total = int(c.endpoints[-1])
+    words = torch.from_numpy(c.words.view(np.int64)).to(dev)
+    pos = torch.arange(total, dtype=torch.int64, device=dev)
+    codes = (words[pos >> 5] >> ((pos & 31) * 2)) & 3
+    text = torch.tensor(list(b"ACTG"), dtype=torch.uint8, device=dev)[codes]  # the strings as characters
+    del pos, codes
+    bases = torch.empty(R * L, dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    per = R // parts
+    for a in range(0, R, per):
+        start = torch.randint(0, total - L, (per,), generator=g, device=dev, dtype=torch.int64)
+        chunk = text[(start[:, None] + torch.arange(L, device=dev)[None, :]).reshape(-1)]
+        noise = torch.rand(per * L, generator=g, device=dev)
+        chunk[noise < 0.004] = ord("N")
+        sub = (noise > 0.99).nonzero()[:, 0]
+        chunk[sub] = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (sub.numel(),), generator=g, device=dev)]
+        bases[a * L:(a + per) * L] = chunk
+        del start, chunk, noise, sub
+    offsets = torch.arange(R + 1, dtype=torch.int64, device=dev) * L
+    whole = torch.zeros(6, dtype=torch.int64, device=dev)
+    d.streaming_query_device(0, bases.data_ptr(), offsets.data_ptr(), R, whole.data_ptr())
+    torch.cuda.synchronize()
+    whole = whole.cpu().numpy()
+    assert whole[0] == R * (L - c.k + 1)
+    assert whole[0] == whole[1] + whole[2] + whole[3] and whole[1] == whole[4] + whole[5]
+    assert whole[1] > 0.2 * whole[0] and whole[3] > 0 and whole[5] > whole[4]  # hits, N's, mostly extensions
+    summed = np.zeros(6, dtype=np.int64)
+    rel = torch.arange(per + 1, dtype=torch.int64, device=dev) * L
+    for a in range(0, R, per):
+        part = torch.zeros(6, dtype=torch.int64, device=dev)
+        d.streaming_query_device(0, bases.data_ptr() + a * L, rel.data_ptr(), per, part.data_ptr())
+        torch.cuda.synchronize()
+        summed += part.cpu().numpy()
+        if a == 0:  # the same part through encode -> masked lookup -> classify
+            again = torch.zeros(6, dtype=torch.int64, device=dev)
+            d.streaming_lookup_device(0, bases.data_ptr(), rel.data_ptr(), per, per * L, 0, d_report=again.data_ptr())
+            torch.cuda.synchronize()
+            assert (again.cpu().numpy() == part.cpu().numpy()).all()
+    assert (summed == whole).all()
+
+
 def test_full_size_human_scale_dictionary_properties():
     """BASELINE.json configs[2] at FULL size: the dictionary bench.py indexes by default (built here, or taken from the
     bench's cache), 10^8 strided ids: lookup(access(id)) == id on both strands, is_member, two launches identical, and
