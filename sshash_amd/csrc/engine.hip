@@ -16,6 +16,15 @@
 
 namespace sshash_amd {
 
+/* One lane per item, one launch: a launch of 2^32 threads or more is NOT carried out and reports no error (DESIGN.md
+   section 6), so entry points that launch once say so instead of returning untouched output. The lookups themselves are
+   split into pieces and take any n. */
+static void check_single_launch(uint64_t lanes, char const* what) {
+    if (lanes >= (uint64_t(1) << 32))
+        throw error(error_kind::argument, std::string(what) + ": at most 2^32 - 1 lanes per call (split the batch)");
+}
+
+
 int visible_device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -251,6 +260,7 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
         rep->allocations.push_back(wide);
         rep->bytes += std::max<uint64_t>(n, 1) * sizeof(uint64_t);
         if (n) {
+            check_single_launch(n, "upload (one lane per minimizer)");
             hipLaunchKernelGGL(widen_codewords_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, 0, v, packed, n, wide);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipDeviceSynchronize());
@@ -723,6 +733,7 @@ void engine::neighbours_packed_device(int device, uint64_t const* d_kmers, uint6
     device_guard guard(device);
     hipStream_t s = hipStream_t(stream);
     const uint32_t W = rep->view.k <= 31 ? 1 : 2;
+    check_single_launch(8 * n, "kmer_neighbours");
     uint64_t* expanded = nullptr;
     HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&expanded), 8 * n * W * sizeof(uint64_t), s));
     const dim3 grid(uint32_t((8 * n + 255) / 256)), block(256);
@@ -809,6 +820,7 @@ void engine::route_packed_device(int device, uint64_t const* d_kmers, uint64_t n
                                  uint32_t* d_owner_fwd, uint32_t* d_owner_rc, void* stream) const {
     device_replica const* rep = replica(device);
     if (n == 0) return;
+    check_single_launch(n, "route");
     device_guard guard(device);
     const dim3 grid(uint32_t((n + 255) / 256)), block(256);
     if (rep->view.k <= 31)
@@ -965,6 +977,7 @@ void engine::route_combine_device(int device, uint64_t const* d_replies, uint32_
                                   void* stream) const {
     (void)replica(device);
     if (m == 0) return;
+    check_single_launch(m, "route_combine");
     device_guard guard(device);
     hipLaunchKernelGGL(route_combine_kernel, dim3(uint32_t((m + 255) / 256)), dim3(256), 0, hipStream_t(stream), d_replies, d_slots, m, d_out);
     HIP_CHECK(hipGetLastError());
@@ -997,6 +1010,7 @@ access_kernel(const dict_view d, const uint64_t* __restrict__ ids, const uint64_
 void engine::access_packed_device(int device, uint64_t const* d_ids, uint64_t n, uint64_t* d_out, void* stream) const {
     device_replica const* rep = replica(device);
     if (n == 0) return;
+    check_single_launch(n, "access");
     device_guard guard(device);
     const dim3 grid(uint32_t((n + 255) / 256)), block(256);
     if (rep->view.k <= 31) hipLaunchKernelGGL(access_kernel<1>, grid, block, 0, hipStream_t(stream), rep->view, d_ids, n, d_out);
@@ -1028,6 +1042,7 @@ void engine::weight_device(int device, uint64_t const* d_ids, uint64_t n, uint64
     device_replica const* rep = replica(device);
     if (!rep->view.num_weight_intervals) throw error(error_kind::argument, "the dictionary does not store weights");
     if (n == 0) return;
+    check_single_launch(n, "weight");
     device_guard guard(device);
     hipLaunchKernelGGL(weight_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, hipStream_t(stream), rep->view, d_ids, n, d_out);
     HIP_CHECK(hipGetLastError());

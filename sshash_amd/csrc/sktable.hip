@@ -34,10 +34,10 @@ constexpr uint32_t NEW_PER_WAVE = WAVE - 1;  // lane 0 only supplies its right n
 
 template <int W, bool EMIT>
 __global__ void __launch_bounds__(256)
-sk_scan_kernel(const dict_view d, const uint64_t num_waves, uint32_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
-               uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+sk_scan_kernel(const dict_view d, const uint64_t first_wave, const uint64_t num_waves, uint32_t* __restrict__ counts,
+               const uint64_t* __restrict__ offsets, uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
     const uint64_t gtid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    const uint64_t wave = gtid / WAVE;
+    const uint64_t wave = first_wave + gtid / WAVE;  // (launched in pieces: a launch of 2^32 threads is not carried out)
     const uint32_t lane = uint32_t(gtid % WAVE);
     if (wave >= num_waves) return;  // whole waves only: the grid is sized in waves
     const int64_t i = int64_t(wave * NEW_PER_WAVE + lane) - 1;
@@ -305,16 +305,23 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
 
     const uint64_t positions = idx.num_bases - idx.k + 1;
     const uint64_t num_waves = (positions + 1 + NEW_PER_WAVE - 1) / NEW_PER_WAVE;
-    const uint64_t threads = num_waves * WAVE;
-    const dim3 block(256), grid(uint32_t((threads + 255) / 256));
-    if (threads >= (uint64_t(1) << 32) || num_waves >= (uint64_t(1) << 31)) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);  // one launch, and hipCUB item counts are int
+    const dim3 block(256);
+    if (num_waves >= (uint64_t(1) << 31)) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);  // hipCUB item counts are int
+    /* one lane per k-mer start, in pieces of 2^24 waves (2^30 threads) */
+    auto scan = [&](auto kernel, uint32_t* counts, uint64_t const* offsets, uint64_t* keys, uint64_t* vals) {
+        const uint64_t piece = uint64_t(1) << 24;
+        for (uint64_t first = 0; first < num_waves; first += piece) {
+            const uint64_t waves = std::min(piece, num_waves - first);
+            hipLaunchKernelGGL(kernel, dim3(uint32_t((waves * WAVE + 255) / 256)), block, 0, 0, v, first, num_waves, counts, offsets, keys, vals);
+        }
+    };
 
     temp_buffers tmp;
     uint32_t* counts = tmp.alloc<uint32_t>(num_waves);
     uint64_t* offsets = tmp.alloc<uint64_t>(num_waves + 1);
     const bool wide = idx.k > 31;
-    if (wide) hipLaunchKernelGGL((sk_scan_kernel<2, false>), grid, block, 0, 0, v, num_waves, counts, nullptr, nullptr, nullptr);
-    else hipLaunchKernelGGL((sk_scan_kernel<1, false>), grid, block, 0, 0, v, num_waves, counts, nullptr, nullptr, nullptr);
+    if (wide) scan(sk_scan_kernel<2, false>, counts, nullptr, nullptr, nullptr);
+    else scan(sk_scan_kernel<1, false>, counts, nullptr, nullptr, nullptr);
     HIP_CHECK(hipGetLastError());
     {
         /* exclusive scan of the per-wave counts into 64-bit offsets */
@@ -334,8 +341,8 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
 
     uint64_t* keys = tmp.alloc<uint64_t>(T);
     uint64_t* vals = tmp.alloc<uint64_t>(T);
-    if (wide) hipLaunchKernelGGL((sk_scan_kernel<2, true>), grid, block, 0, 0, v, num_waves, counts, offsets, keys, vals);
-    else hipLaunchKernelGGL((sk_scan_kernel<1, true>), grid, block, 0, 0, v, num_waves, counts, offsets, keys, vals);
+    if (wide) scan(sk_scan_kernel<2, true>, counts, offsets, keys, vals);
+    else scan(sk_scan_kernel<1, true>, counts, offsets, keys, vals);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipDeviceSynchronize());
     tmp.release(counts);

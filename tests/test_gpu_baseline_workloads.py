@@ -224,3 +224,32 @@ def test_full_size_human_scale_dictionary_properties():
         asked = neg[found].unsqueeze(1)
         assert bool(((back == asked) | (revcomp_device(back, 31) == asked)).all().item())
     d.close()
+
+
+@pytest.mark.skipif(os.environ.get("SSHASH_TEST_HUGE") != "1", reason="several minutes and ~100 GB of HBM: set SSHASH_TEST_HUGE=1")
+def test_a_dictionary_with_more_than_2_32_kmer_starts_still_gets_its_table():
+    """4.6 x 10^9 bases: the table build's one-lane-per-k-mer-start scans no longer fit one launch (2^32 threads: such a
+    launch is silently not carried out) and run in pieces; lookup(access(id)) == id over strided ids, both strands."""
+    import torch
+
+    import bench
+    from sshash_amd.synthetic import revcomp_device
+
+    args = argparse.Namespace(bases=4_600_000_000, k=31, m=21, mean_len=274.0, canonical=False, seed=0x77AA,
+                              cache_dir=os.environ.get("SSHASH_BENCH_CACHE", "/tmp"), verbose=False)
+    d, _ = bench.get_index(args, 0, 1, lambda: None)
+    d.to_device(0)
+    stats = d.device_stats(0)
+    assert d.num_kmers() > 4_000_000_000 and stats["sk_slots"] > 0 and stats["sk_absent_reason"] is None, stats
+    dev = torch.device("cuda", 0)
+    n = 50_000_000
+    ids = torch.arange(n, dtype=torch.int64, device=dev) * (d.num_kmers() // n) + 3
+    q = torch.empty((n, 1), dtype=torch.int64, device=dev)
+    d.access_packed_device(0, ids.data_ptr(), n, q.data_ptr())
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    for qq in (q, revcomp_device(q, 31).contiguous()):
+        d.lookup_device(0, qq.data_ptr(), n, out.data_ptr())
+        torch.cuda.synchronize()
+        assert int((out != ids).sum().item()) == 0
+    d.close()
+
