@@ -515,3 +515,17 @@ def test_a_full_resume_queue_sends_its_queries_down_the_complete_path(case_name,
     assert (d.lookup(rc).kmer_id == want).all()
     mix = case.queries(20000, 20000, seed=41)
     assert (d.lookup(mix).kmer_id == case.oracle.lookup_ids(mix)).all()
+
+
+def test_entry_points_that_launch_once_refuse_what_one_launch_cannot_carry(case_se_regular):
+    """A launch of 2^32 threads or more is silently not carried out: access / weight / neighbours /
+    route say so instead of returning untouched output. (Nothing is dereferenced before the check.)"""
+    import torch
+
+    d = case_se_regular.dict.to_device(0)
+    buf = torch.zeros(16, dtype=torch.int64, device="cuda:0")
+    with pytest.raises(sshash_amd.SSHashError, match="2\\^32"):
+        d.access_packed_device(0, buf.data_ptr(), 1 << 32, buf.data_ptr())
+    d.access_packed_device(0, buf.data_ptr(), 16, buf.data_ptr())  # (ids 0: fine)
+    torch.cuda.synchronize()
+
