@@ -10,7 +10,8 @@
 //   2. sort     stable radix sort of the tuples by key (hipCUB), run-length encode -> one run per key.
 //   3. place    SK_CHOICES rounds, one per hashed bucket choice: a key claims the first free slot of the bucket with a
 //               CAS on the slot's flag word; a key that finds the bucket full sets the bucket's "go on" flag and waits
-//               for the next round.
+//               for the next round. The first round runs in three turns, the items of long super-k-mers first: the 7 %
+//               of items that cannot stay in their first bucket are then the ones the fewest queries ask for.
 //   4. fill     the winner writes its slot: the 64 bases around one occurrence, how far the super-k-mer may extend
 //               inside its string, the string id. A key with up to SK_INLINE_MAX occurrences takes one such slot per
 //               occurrence (a lookup then never leaves the table); a key with more takes one slot pointing at its
@@ -30,6 +31,11 @@ namespace sshash_amd {
 namespace {
 
 constexpr uint32_t WAVE = 64;
+/* a tuple's value: position of the key occurrence << 1 | strand (40 bits), and -- bits 56-61 -- how many consecutive k-mers
+   elected this occurrence, as far as the scanning wave saw (a super-k-mer running into the next wave is cut short: it is a
+   priority, not a fact anything relies on) */
+constexpr uint32_t SK_LEN_SHIFT = 56;
+constexpr uint64_t SK_VAL_MASK = (uint64_t(1) << 40) - 1;
 constexpr uint32_t NEW_PER_WAVE = WAVE - 1;  // lane 0 only supplies its right neighbour's "previous"
 
 template <int W, bool EMIT>
@@ -63,8 +69,11 @@ sk_scan_kernel(const dict_view d, const uint64_t first_wave, const uint64_t num_
     } else {
         if (start) {
             const uint64_t at = offsets[wave] + uint64_t(__popcll(ballot & ((uint64_t(1) << lane) - 1)));
+            const uint64_t later = lane < 63 ? ballot >> (lane + 1) : 0;
+            const uint32_t run = later ? uint32_t(__ffsll((unsigned long long)later)) : WAVE - lane;  // k-mers up to the next start
+            const uint32_t most = d.k - d.m + 1;
             keys[at] = key;
-            vals[at] = val;
+            vals[at] = val | (uint64_t(run < most ? run : most) << SK_LEN_SHIFT);
         }
     }
 }
@@ -148,7 +157,7 @@ sk_heavy_kmers_kernel(const dict_view d, const uint64_t first_tuple, const uint6
     bool mine = false;
     uint64_t key = 0, v = 0;
     if (t < num_tuples && flags[t] != SK_ITEM_INLINE) {
-        v = occ[t];
+        v = occ[t] & SK_VAL_MASK;
         const uint64_t p = v >> 1;
         if (p + a >= km && p + a - km + d.k <= d.num_bases) {
             const window_t<W> w = read_window<W>(d.granules, p + a - km, d.k);
@@ -186,12 +195,18 @@ template <int W>
 __global__ void __launch_bounds__(256)
 sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_items, const uint64_t* __restrict__ item_keys,
                 const uint64_t* __restrict__ item_vals, const uint8_t* __restrict__ flags, uint32_t* __restrict__ slots,
-                const uint32_t num_buckets, uint8_t* __restrict__ placed, unsigned long long* __restrict__ stats) {
+                const uint32_t num_buckets, uint8_t* __restrict__ placed, unsigned long long* __restrict__ stats,
+                const uint32_t len_lo, const uint32_t len_hi) {
     const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     bool unplaced = false, used = false;
     if (t < num_items && !placed[t]) {
         const uint8_t kind = flags ? flags[t] : SK_ITEM_INLINE;
-        if (kind == SK_ITEM_NONE) {
+        /* who takes part in this launch: the items whose super-k-mer holds len_lo .. len_hi k-mers (a marker counts as
+           the longest: every k-mer of its key passes through it) -- see the rounds in build_sk_table */
+        const uint32_t len = kind == SK_ITEM_MARKER ? 63u : uint32_t(item_vals[t] >> SK_LEN_SHIFT);
+        if (kind != SK_ITEM_NONE && (len < len_lo || len > len_hi)) {
+            // not its turn
+        } else if (kind == SK_ITEM_NONE) {
             placed[t] = 1;
         } else {
             const sk_hash_t h = sk_hash(item_keys[t], num_buckets);
@@ -223,7 +238,7 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
                 uint64_t w1;
                 uint64_t body[2 * W];
                 for (int i = 0; i < 2 * W; ++i) body[i] = 0;
-                const uint64_t v = item_vals[t];
+                const uint64_t v = item_vals[t] & SK_VAL_MASK;
                 const uint64_t p = v >> 1;
                 if (kind == SK_ITEM_INLINE) {
                     const uint32_t km = d.k - d.m;
@@ -438,21 +453,31 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     uint8_t* placed = tmp.alloc<uint8_t>(T + heavy_kmers);
     HIP_CHECK(hipMemset(slots, 0, num_slots * slot_bytes));
     HIP_CHECK(hipMemset(placed, 0, T + heavy_kmers));
-    for (uint32_t choice = 0; choice < SK_CHOICES; ++choice) {
+    /* Rounds: one per bucket choice; the FIRST choice in three turns, long super-k-mers first. At load factor 0.4 with two
+       slots per bucket 7.2 % of the items do not fit their first bucket whatever the order (Poisson), but WHICH items
+       matters: a query is a k-mer, and an item answers as many queries as its super-k-mer holds k-mers (1 .. k-m+1, a
+       quarter of them the full k-m+1). Served in order of length, the overflowing 7.2 % of the items hold 3.9 % of the
+       k-mers instead of 7.2 % -- that many fewer positive queries need a second bucket (resume pass). */
+    const uint32_t most = idx.k - idx.m + 1;
+    const uint32_t turns[3][2] = {{(7 * most + 9) / 10, 63u}, {(35 * most + 99) / 100, (7 * most + 9) / 10 - 1}, {0u, (35 * most + 99) / 100 - 1}};
+    auto place = [&](uint32_t choice, uint32_t lo, uint32_t hi, bool with_heavy_kmers) {
         const dim3 g1(uint32_t((T + 255) / 256)), g2(uint32_t((heavy_kmers + 255) / 256));
         if (wide) {
-            hipLaunchKernelGGL(sk_place_kernel<2>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(num_buckets), placed, stats);
-            if (heavy_kmers)
+            hipLaunchKernelGGL(sk_place_kernel<2>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(num_buckets), placed, stats, lo, hi);
+            if (heavy_kmers && with_heavy_kmers)
                 hipLaunchKernelGGL(sk_place_kernel<2>, g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, slots,
-                                   uint32_t(num_buckets), placed + T, stats);
+                                   uint32_t(num_buckets), placed + T, stats, 0u, 63u);
         } else {
-            hipLaunchKernelGGL(sk_place_kernel<1>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(num_buckets), placed, stats);
-            if (heavy_kmers)
+            hipLaunchKernelGGL(sk_place_kernel<1>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(num_buckets), placed, stats, lo, hi);
+            if (heavy_kmers && with_heavy_kmers)
                 hipLaunchKernelGGL(sk_place_kernel<1>, g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, slots,
-                                   uint32_t(num_buckets), placed + T, stats);
+                                   uint32_t(num_buckets), placed + T, stats, 0u, 63u);
         }
         HIP_CHECK(hipGetLastError());
-    }
+    };
+    for (int turn = 0; turn < 3; ++turn)
+        if (turns[turn][0] <= turns[turn][1]) place(0, turns[turn][0], turns[turn][1], turn == 2);  // (the heavy keys' k-mers: one k-mer each)
+    for (uint32_t choice = 1; choice < SK_CHOICES; ++choice) place(choice, 0u, 63u, true);
     HIP_CHECK(hipMemcpy(h_stats, stats, 64, hipMemcpyDeviceToHost));
     HIP_CHECK(hipDeviceSynchronize());
 
