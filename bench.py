@@ -279,6 +279,7 @@ def main():
     kernel_ms = [starts[i].elapsed_time(stops[i]) for i in range(args.steps)]
     avg_kernel_ms = float(np.mean(kernel_ms))
     per_rank = [{"rank": 0, "queries": n, "ms_per_step": round(own_elapsed / args.steps * 1e3, 3), "kernel_ms_per_step": round(avg_kernel_ms, 3)}]
+    kernel_ms_steps = [round(float(t), 3) for t in kernel_ms]  # rank 0's steps one by one: sustained load drifts (clocks), see DESIGN.md section 6
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -317,7 +318,7 @@ def main():
                     "algorithmic_bytes_per_lookup": round(bytes_per_lookup, 2),
                     "algorithmic_bytes_rule": "SURVEY 8(d): 8 B per distinct 64-bit index word the REFERENCE algorithm dereferences "
                                               "+ query in + id out, counted by the instrumented oracle on this batch",
-                    "avg_kernel_ms": round(avg_kernel_ms, 3),
+                    "avg_kernel_ms": round(avg_kernel_ms, 3), "kernel_ms_steps": kernel_ms_steps,
                     # what bounds a structure of one random bucket per query on this chip is random UNITS, not bytes: 43.8 G
                     # random 64-byte units/s, 39.9 G 128-byte ones (tools/tlb_probe)
                     "random_unit_bound": {"probe_units_per_s": RANDOM_UNIT_PROBE, "source": "profiles/r02/tlb_probe_128_256_byte_units.jsonl",
