@@ -11,6 +11,7 @@
 #pragma once
 
 #include <algorithm>
+#include <array>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -56,6 +57,12 @@ struct uint_kmer_t {
     uint_kmer_t() = default;
     uint_kmer_t(uint64_t lo) : bits{lo, 0} {}
     uint_kmer_t(unsigned __int128 v) : bits{uint64_t(v), uint64_t(v >> 64)} {}
+};
+
+/* reference include/util.hpp:76-80: the four forward and the four backward neighbours of a k-mer, indexed by the 2-bit
+   code of the added character (alphabet order "ACTG", include/kmer.hpp:118) */
+struct neighbourhood {
+    std::array<lookup_result, 4> forward, backward;
 };
 
 /* struct-of-arrays batch result */
@@ -163,6 +170,39 @@ public:
         return ids;
     }
 
+    /* include/dictionary.hpp:48-62, src/dictionary.cpp:111-201: the reference's navigational queries with its own
+       signatures -- forward neighbours = suffix + each character, backward = each character + prefix; the *_forward_ /
+       *_backward_ variants leave the other half default-constructed (not found), as the reference does */
+    neighbourhood kmer_neighbours(uint_kmer_t uint_kmer, bool check_reverse_complement = true) const {
+        return neighbours_of(uint_kmer, check_reverse_complement, true, true);
+    }
+    neighbourhood kmer_neighbours(char const* string_kmer, bool check_reverse_complement = true) const {
+        return neighbours_of(pack(string_kmer), check_reverse_complement, true, true);
+    }
+    neighbourhood kmer_forward_neighbours(uint_kmer_t uint_kmer, bool check_reverse_complement = true) const {
+        return neighbours_of(uint_kmer, check_reverse_complement, true, false);
+    }
+    neighbourhood kmer_forward_neighbours(char const* string_kmer, bool check_reverse_complement = true) const {
+        return neighbours_of(pack(string_kmer), check_reverse_complement, true, false);
+    }
+    neighbourhood kmer_backward_neighbours(uint_kmer_t uint_kmer, bool check_reverse_complement = true) const {
+        return neighbours_of(uint_kmer, check_reverse_complement, false, true);
+    }
+    neighbourhood kmer_backward_neighbours(char const* string_kmer, bool check_reverse_complement = true) const {
+        return neighbours_of(pack(string_kmer), check_reverse_complement, false, true);
+    }
+    neighbourhood string_neighbours(uint64_t string_id, bool check_reverse_complement = true) const {
+        lookup_results r;
+        sshash_results out = bind(r, 8);
+        check(sshash_string_neighbours(m_h, &string_id, 1, check_reverse_complement, &out));
+        neighbourhood n;
+        for (int c = 0; c < 4; ++c) {
+            n.forward[c] = r[c];
+            n.backward[c] = r[4 + c];
+        }
+        return n;
+    }
+
     /* Return the number of kmers in string -- include/dictionary.hpp:44-46 */
     uint64_t string_size(uint64_t string_id) const {
         uint64_t size = 0;
@@ -255,6 +295,23 @@ private:
     void reset() {
         sshash_free(m_h);
         m_h = nullptr;
+    }
+    /* util::string_to_uint_kmer (include/util.hpp:207-213): k characters, (c >> 1) & 3 each, no validation */
+    uint_kmer_t pack(char const* string_kmer) const {
+        uint_kmer_t x;
+        for (uint64_t i = 0; i < m_info.k; ++i) x.bits[i >> 5] |= uint64_t((string_kmer[i] >> 1) & 3) << (2 * (i & 31));
+        return x;
+    }
+    neighbourhood neighbours_of(uint_kmer_t x, bool check_reverse_complement, bool forward, bool backward) const {
+        lookup_results r;
+        sshash_results out = bind(r, 8);
+        check(sshash_neighbours_packed(m_h, x.bits, 1, check_reverse_complement, &out));
+        neighbourhood n;
+        for (int c = 0; c < 4; ++c) {
+            if (forward) n.forward[c] = r[c];
+            if (backward) n.backward[c] = r[4 + c];
+        }
+        return n;
     }
     static sshash_results bind(lookup_results& r, uint64_t n) {
         r.kmer_id.resize(n);

@@ -185,6 +185,32 @@ static bool check_navigational(dictionary const& dict, std::vector<std::string> 
             if (sn[c] != nb[8 * (n - 1) + c]) FAIL("string_neighbours forward of string " << s);
             if (sn[4 + c] != nb[4 + c]) FAIL("string_neighbours backward of string " << s);
         }
+        if (s < 20) {
+            /* the reference's own shapes (include/dictionary.hpp:48-62): neighbourhood structs, one k-mer per call, every
+               field a lookup of the neighbouring k-mer string (src/dictionary.cpp:111-126) */
+            const uint64_t mid = n / 2;
+            const neighbourhood both = dict.kmer_neighbours(seq.c_str() + mid);
+            const neighbourhood fwd = dict.kmer_forward_neighbours(seq.c_str() + mid), bwd = dict.kmer_backward_neighbours(seq.c_str() + mid);
+            uint_kmer_t x;
+            for (uint64_t j = 0; j < k; ++j) x.bits[(2 * j) / 64] |= code(seq[mid + j]) << ((2 * j) % 64);
+            const neighbourhood typed = dict.kmer_neighbours(x);
+            const neighbourhood of_string = dict.string_neighbours(s);
+            for (uint64_t c = 0; c < 4; ++c) {
+                const std::string next = seq.substr(mid + 1, k - 1) + "ACTG"[c], prev = std::string(1, "ACTG"[c]) + seq.substr(mid, k - 1);
+                const lookup_result f = dict.lookup(next.c_str()), b = dict.lookup(prev.c_str());
+                auto same = [](lookup_result const& p, lookup_result const& q) {
+                    return p.kmer_id == q.kmer_id && p.kmer_id_in_string == q.kmer_id_in_string && p.kmer_offset == q.kmer_offset &&
+                           p.kmer_orientation == q.kmer_orientation && p.string_id == q.string_id && p.string_begin == q.string_begin &&
+                           p.string_end == q.string_end;
+                };
+                if (!same(both.forward[c], f) || !same(both.backward[c], b)) FAIL("kmer_neighbours(char const*) of string " << s);
+                if (!same(typed.forward[c], f) || !same(typed.backward[c], b)) FAIL("kmer_neighbours(Kmer) of string " << s);
+                if (!same(fwd.forward[c], f) || fwd.backward[c].kmer_id != constants::invalid_uint64) FAIL("kmer_forward_neighbours of string " << s);
+                if (!same(bwd.backward[c], b) || bwd.forward[c].kmer_id != constants::invalid_uint64) FAIL("kmer_backward_neighbours of string " << s);
+                if (of_string.forward[c].kmer_id != sn[c] || of_string.backward[c].kmer_id != sn[4 + c]) FAIL("string_neighbours of string " << s);
+            }
+            if (mid + 1 < n && both.forward[code(seq[mid + k])].kmer_id != kmer_id + mid + 1) FAIL("forward neighbour along the string");
+        }
         kmer_id += n;
         if (s >= 400) break;  // the batched form makes one round trip per string: a prefix of the file is enough
     }
