@@ -184,6 +184,9 @@ sshash_status sshash_neighbours_packed(const sshash_dict* d, const uint64_t* kme
 /* dictionary::string_size(string_id): include/dictionary.hpp:44-46, src/dictionary.cpp:102-109 -- the number of
  * k-mers of each string (its length is size + k - 1). Host arrays. */
 sshash_status sshash_string_size(const sshash_dict* d, const uint64_t* string_ids, uint64_t n, uint64_t* out_sizes);
+/* dictionary::string_offsets(string_id) -> [begin, end) in bases (include/dictionary.hpp:105-108): what lookup_result's
+ * string_begin / string_end refer to */
+sshash_status sshash_string_offsets(const sshash_dict* d, const uint64_t* string_ids, uint64_t n, uint64_t* out_begin, uint64_t* out_end);
 
 /* dictionary::string_neighbours(string_id, bool): include/dictionary.hpp:62, src/dictionary.cpp:189-201 -- the
  * forward neighbours of the string's last k-mer and the backward neighbours of its first one, same layout. */

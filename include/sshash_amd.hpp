@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "sshash_amd.h"
@@ -208,6 +209,13 @@ public:
         uint64_t size = 0;
         check(sshash_string_size(m_h, &string_id, 1, &size));
         return size;
+    }
+
+    /* [begin, end) of a string in bases -- include/dictionary.hpp:105-108 */
+    std::pair<uint64_t, uint64_t> string_offsets(uint64_t string_id) const {
+        uint64_t begin = 0, end = 0;
+        check(sshash_string_offsets(m_h, &string_id, 1, &begin, &end));
+        return {begin, end};
     }
 
     /* Return the weight of the kmer given its id -- include/dictionary.hpp (weight), src/dictionary.cpp:96-100 */

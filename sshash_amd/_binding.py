@@ -158,6 +158,7 @@ def _load() -> C.CDLL:
         "sshash_neighbours_packed": (C.c_int, [P, P, C.c_uint64, C.c_int, C.POINTER(_Results)]),
         "sshash_string_neighbours": (C.c_int, [P, P, C.c_uint64, C.c_int, C.POINTER(_Results)]),
         "sshash_string_size": (C.c_int, [P, P, C.c_uint64, P]),
+        "sshash_string_offsets": (C.c_int, [P, P, C.c_uint64, P, P]),
         "sshash_is_member_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_int, P, P]),
         "sshash_is_member_packed": (C.c_int, [P, P, C.c_uint64, C.c_int, P]),
         "sshash_is_member_ascii": (C.c_int, [P, P, C.c_uint64, C.c_int, P]),
@@ -186,7 +187,7 @@ C_ABI_SYMBOLS = (
     "sshash_last_error sshash_build_config_default sshash_build_from_fasta sshash_build_from_packed sshash_save "
     "sshash_load sshash_free sshash_get_info sshash_device_count sshash_to_device sshash_to_device_table_shard sshash_device_bytes sshash_device_stats "
     "sshash_lookup_packed_device sshash_lookup_ascii_device sshash_lookup_packed sshash_lookup_ascii "
-    "sshash_neighbours_packed_device sshash_neighbours_packed sshash_string_neighbours sshash_string_size "
+    "sshash_neighbours_packed_device sshash_neighbours_packed sshash_string_neighbours sshash_string_size sshash_string_offsets "
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
     "sshash_access_packed_device sshash_weight sshash_weight_device "
     "sshash_streaming_query_from_file sshash_streaming_query sshash_streaming_query_device "
@@ -438,6 +439,13 @@ class Dictionary:
         out = np.empty(sids.size, dtype=np.uint64)
         _check(_load().sshash_string_size(self._h, sids.ctypes.data, sids.size, out.ctypes.data))
         return out
+
+    def string_offsets(self, string_ids: Iterable[int]):
+        """dictionary::string_offsets (reference include/dictionary.hpp:105-108): [begin, end) of each string, in bases."""
+        sids = np.ascontiguousarray(np.asarray(string_ids, dtype=np.uint64))
+        begin, end = np.empty(sids.size, dtype=np.uint64), np.empty(sids.size, dtype=np.uint64)
+        _check(_load().sshash_string_offsets(self._h, sids.ctypes.data, sids.size, begin.ctypes.data, end.ctypes.data))
+        return begin, end
 
     def string_neighbours(self, string_ids: Iterable[int], check_reverse_complement: bool = True) -> np.ndarray:
         """Batched dictionary::string_neighbours (reference src/dictionary.cpp:189-201): ids, 8 per string."""

@@ -246,6 +246,18 @@ sshash_status sshash_string_size(const sshash_dict* d, const uint64_t* string_id
     });
 }
 
+sshash_status sshash_string_offsets(const sshash_dict* d, const uint64_t* string_ids, uint64_t n, uint64_t* out_begin, uint64_t* out_end) {
+    if (!d || (n && (!string_ids || !out_begin || !out_end))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] {
+        host_index const& x = *d->idx;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (string_ids[i] >= x.num_strings) throw error(error_kind::argument, "string_id out of range");
+            out_begin[i] = x.endpoints[string_ids[i]];
+            out_end[i] = x.endpoints[string_ids[i] + 1];
+        }
+    });
+}
+
 sshash_status sshash_string_neighbours(const sshash_dict* d, const uint64_t* string_ids, uint64_t n, int check_rc,
                                        const sshash_results* out) {
     if (!d || !out || (!string_ids && n)) return fail(SSHASH_ERR_ARGUMENT, "null argument");

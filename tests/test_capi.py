@@ -164,6 +164,12 @@ def test_string_size(case_skew_regular):
     assert int(sizes.sum()) == case.dict.num_kmers()
     with pytest.raises(sshash_amd.SSHashError):
         case.dict.string_size([len(case.sequences)])
+    # string_offsets: [begin, end) in bases, strings back to back (include/dictionary.hpp:105-108)
+    begin, end = case.dict.string_offsets(range(len(case.sequences)))
+    assert int(begin[0]) == 0 and (begin[1:] == end[:-1]).all()
+    assert list(end - begin) == [len(s) for s in case.sequences]
+    with pytest.raises(sshash_amd.SSHashError):
+        case.dict.string_offsets([len(case.sequences)])
 
 
 def test_cuttlefish_segment_input(case_skew_regular, tmp_path):
