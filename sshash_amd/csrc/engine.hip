@@ -401,7 +401,7 @@ __device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries
         x = kmer_from_ascii<W>(static_cast<const char*>(queries) + i * k, k);
     } else {
         const uint64_t* q = static_cast<const uint64_t*>(queries) + i * W;
-        for (int j = 0; j < W; ++j) x.w[j] = q[j];
+        for (int j = 0; j < W; ++j) x.w[j] = __builtin_nontemporal_load(q + j);
         x = kmer_take_chars<W>(x, k);
     }
     return x;

@@ -808,11 +808,7 @@ __device__ __forceinline__ uint32_t wave_queue_place(bool push, uint32_t* counte
 /* hit -> lookup_result fields (include/offsets.hpp:138-154, spss.hpp:226-228) */
 template <bool FULL>
 __device__ __forceinline__ void store_result(dict_view const& d, result_view const& out, uint64_t i, hit_t const& h) {
-    if (h.found) {
-        out.kmer_id[i] = h.kmer_offset - uint64_t(h.string_id) * (d.k - 1);
-    } else {
-        out.kmer_id[i] = INVALID_U64;
-    }
+    __builtin_nontemporal_store(h.found ? h.kmer_offset - uint64_t(h.string_id) * (d.k - 1) : INVALID_U64, out.kmer_id + i);
     if constexpr (FULL) {
         uint64_t begin = INVALID_U64, end = INVALID_U64;
         if (h.found && (out.string_begin || out.string_end || out.kmer_id_in_string)) {
