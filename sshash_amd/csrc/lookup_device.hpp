@@ -652,6 +652,12 @@ __device__ __forceinline__ uint32_t quad_broadcast(uint32_t v) {
    the wait before DS reads it believes unrelated (glds_check: 91 % stale reads) -- the explicit wait below covers that --
    and presumably takes further liberties of the same origin that were not pinned down. The register path uses nothing
    the compiler does not fully model; every parity test passes on it, three runs in a row, without any guard. */
+typedef uint32_t sk_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 sk_load_piece(char const* p) {
+    const sk_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const sk_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <int P>
 __device__ __forceinline__ void sk_stage_round_dma(char const* __restrict__ line_of_owner_base, uint64_t line_offset, uint32_t sub, uint4* wave_stage) {
     __builtin_amdgcn_global_load_lds((sk_global_ptr)(line_of_owner_base + line_offset + 16 * sub), (sk_lds_ptr)(wave_stage + P * 64), 16, 0, 0);
@@ -677,8 +683,9 @@ __device__ __forceinline__ void sk_stage_lines(dict_view const& d, uint32_t buck
                    a3 = uint64_t(b3) * (64 * W) + 64 * l3;
 #if !SSHASH_STAGE_WITH_LDS_DMA
     const uint32_t lane = threadIdx.x & 63u;
-    const uint4 p0 = *reinterpret_cast<const uint4*>(slots + a0 + 16 * sub), p1 = *reinterpret_cast<const uint4*>(slots + a1 + 16 * sub),
-                p2 = *reinterpret_cast<const uint4*>(slots + a2 + 16 * sub), p3 = *reinterpret_cast<const uint4*>(slots + a3 + 16 * sub);
+    /* nontemporal: a bucket line is not read again before a few hundred million others have passed */
+    const uint4 p0 = sk_load_piece(slots + a0 + 16 * sub), p1 = sk_load_piece(slots + a1 + 16 * sub),
+                p2 = sk_load_piece(slots + a2 + 16 * sub), p3 = sk_load_piece(slots + a3 + 16 * sub);
     wave_stage[0 * 64 + lane] = p0;
     wave_stage[1 * 64 + lane] = p1;
     wave_stage[2 * 64 + lane] = p2;
