@@ -435,7 +435,7 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
         if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
             for (uint32_t c = threadIdx.x; c * 16 < bytes; c += blockDim.x) {
                 if (c * 16 + 16 <= bytes) {
-                    reinterpret_cast<uint4*>(tile)[c] = reinterpret_cast<const uint4*>(src)[c];
+                    reinterpret_cast<uint4*>(tile)[c] = sk_load_piece(src + 16 * c);  // nontemporal: read once
                 } else {
                     for (uint32_t b = c * 16; b < bytes; ++b) reinterpret_cast<char*>(tile)[b] = src[b];
                 }
@@ -487,7 +487,7 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
     /* every remaining lane stores first (a deferred or resumed lane's value is a placeholder that a later pass
        overwrites), the deferred-queue push comes last */
     if constexpr (MODE == int(out_mode::member)) {
-        member[i] = r.outcome == FAST_HIT ? 1 : 0;
+        __builtin_nontemporal_store(uint8_t(r.outcome == FAST_HIT ? 1 : 0), member + i);
     } else {
         hit_t h;
         h.kmer_offset = r.kmer_offset;

@@ -822,13 +822,13 @@ __device__ __forceinline__ void store_result(dict_view const& d, result_view con
             begin = d.endpoints[h.string_id];
             end = d.endpoints[h.string_id + 1];
         }
-        if (out.kmer_id_in_string) out.kmer_id_in_string[i] = h.found ? h.kmer_offset - begin : INVALID_U64;
-        if (out.kmer_offset) out.kmer_offset[i] = h.found ? h.kmer_offset : INVALID_U64;
-        if (out.string_id) out.string_id[i] = h.found ? uint64_t(h.string_id) : INVALID_U64;
-        if (out.string_begin) out.string_begin[i] = begin;
-        if (out.string_end) out.string_end[i] = end;
-        if (out.kmer_orientation) out.kmer_orientation[i] = h.orientation;
-        if (out.minimizer_found) out.minimizer_found[i] = h.minimizer_found ? 1 : 0;
+        if (out.kmer_id_in_string) __builtin_nontemporal_store(h.found ? h.kmer_offset - begin : INVALID_U64, out.kmer_id_in_string + i);
+        if (out.kmer_offset) __builtin_nontemporal_store(h.found ? h.kmer_offset : INVALID_U64, out.kmer_offset + i);
+        if (out.string_id) __builtin_nontemporal_store(h.found ? uint64_t(h.string_id) : INVALID_U64, out.string_id + i);
+        if (out.string_begin) __builtin_nontemporal_store(begin, out.string_begin + i);
+        if (out.string_end) __builtin_nontemporal_store(end, out.string_end + i);
+        if (out.kmer_orientation) __builtin_nontemporal_store(h.orientation, out.kmer_orientation + i);
+        if (out.minimizer_found) __builtin_nontemporal_store(uint8_t(h.minimizer_found ? 1 : 0), out.minimizer_found + i);
     }
 }
 
