@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) gather(const char* __restrict__ a, uint64
    instruction (the memory pipeline sees one request and one translation per unit instead of COOP); COOP rounds
    serve the units of all COOP lanes. What a lane would then fetch from its neighbours by DPP is left out: the
    point here is the memory side. */
-template <int COOP>
+template <int COOP, bool NT = false>
 __global__ void __launch_bounds__(256) gather_coop(const char* __restrict__ a, uint64_t n_units, uint64_t* __restrict__ out, uint64_t salt) {
     const uint64_t tid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const uint32_t sub = threadIdx.x & (COOP - 1);
@@ -73,8 +73,18 @@ __global__ void __launch_bounds__(256) gather_coop(const char* __restrict__ a, u
         const uint64_t owner = (tid & ~uint64_t(COOP - 1)) + r;  // the lane of the group whose unit is read in round r
         const uint64_t x = mix(owner * 0x9E3779B97F4A7C15ULL + salt);
         const uint64_t unit = uint64_t((__uint128_t(x) * n_units) >> 64);
-        const uint4 v = *reinterpret_cast<const uint4*>(a + unit * (16 * COOP) + 16 * sub);
-        acc += v.x ^ v.w;
+        uint32_t x0, x3;
+        if (NT) {  // nontemporal: the policy the lookup kernels use for their bucket lines
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + unit * (16 * COOP) + 16 * sub));
+            x0 = v.x;
+            x3 = v.w;
+        } else {
+            const uint4 v = *reinterpret_cast<const uint4*>(a + unit * (16 * COOP) + 16 * sub);
+            x0 = v.x;
+            x3 = v.w;
+        }
+        acc += x0 ^ x3;
     }
     out[tid] = acc;
 }
@@ -181,6 +191,10 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL(gather_coop<2>, grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
         } else if (!strcmp(kernel, "coop") && width == 64) {
             hipLaunchKernelGGL(gather_coop<4>, grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
+        } else if (!strcmp(kernel, "coopnt") && width == 64) {
+            hipLaunchKernelGGL((gather_coop<4, true>), grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
+        } else if (!strcmp(kernel, "coopnt") && width == 128) {
+            hipLaunchKernelGGL((gather_coop<8, true>), grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
         } else if (!strcmp(kernel, "coop") && width == 128) {
             hipLaunchKernelGGL(gather_coop<8>, grid, block, 0, 0, a, n_units, out, uint64_t(r) + 1);
         } else if (!strcmp(kernel, "coop") && width == 256) {
