@@ -374,10 +374,15 @@ class Dictionary:
         a = encode_kmers(list(kmers), self.k())
         return True, np.ascontiguousarray(a), a.shape[0]
 
-    def lookup(self, kmers: KmerBatch, check_reverse_complement: bool = True, full: bool = False) -> LookupResult:
-        """Batched dictionary::lookup (reference src/dictionary.cpp:58-78). Host buffers in/out."""
+    def lookup(self, kmers: KmerBatch, check_reverse_complement: bool = True, full: bool = False,
+               out: Optional[np.ndarray] = None) -> LookupResult:
+        """Batched dictionary::lookup (reference src/dictionary.cpp:58-78). Host buffers in/out. `out`: a uint64 array
+        of n entries to receive the ids (e.g. page-locked memory: with input and output both page-locked the library
+        copies from and to them directly instead of staging through its own pinned lanes)."""
         is_ascii, a, n = self._as_batch(kmers)
-        res = LookupResult(kmer_id=np.empty(n, dtype=np.uint64))
+        if out is not None and (out.dtype != np.uint64 or out.size != n or not out.flags["C_CONTIGUOUS"]):
+            raise ValueError("out must be a contiguous uint64 array with one entry per k-mer")
+        res = LookupResult(kmer_id=out if out is not None else np.empty(n, dtype=np.uint64))
         r = _Results()
         r.kmer_id = res.kmer_id.ctypes.data
         if full:

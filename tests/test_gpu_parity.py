@@ -529,3 +529,23 @@ def test_entry_points_that_launch_once_refuse_what_one_launch_cannot_carry(case_
     d.access_packed_device(0, buf.data_ptr(), 16, buf.data_ptr())  # (ids 0: fine)
     torch.cuda.synchronize()
 
+
+def test_page_locked_caller_buffers_are_used_in_place(case_se_regular):
+    """Host entry points: page-locked input and output are copied from and to directly (no staging through the library's
+    lanes); same ids as with pageable buffers, also when only one side is page-locked (then both are staged)."""
+    import torch
+
+    case = case_se_regular
+    d = case.dict.to_device(0)
+    q = case.queries(150_000, 150_000, seed=41)
+    want = d.lookup(q).kmer_id
+    q_pin = torch.from_numpy(q.view(np.int64)).pin_memory()
+    out_pin = torch.empty(want.size, dtype=torch.int64).pin_memory()
+    out_pin.fill_(7)
+    d.lookup(q_pin.numpy().view(np.uint64), out=out_pin.numpy().view(np.uint64))
+    assert (out_pin.numpy().view(np.uint64) == want).all()
+    mixed = np.full(want.size, 7, dtype=np.uint64)
+    d.lookup(q_pin.numpy().view(np.uint64), out=mixed)
+    assert (mixed == want).all()
+    assert (want == case.oracle.lookup_packed(q, True)["kmer_id"]).all()
+

@@ -106,6 +106,17 @@ def main():
         best = min(best, time.perf_counter() - t0)
     report("host_buffers_packed_mix50_pcie_inclusive", best * 1e3, units=m)
     assert (ids == out[:m].cpu().numpy().view(np.uint64)).all()
+    # the same with page-locked caller buffers: copied from and to directly
+    q_pin = torch.from_numpy(q[: m * W].view(np.int64)).pin_memory()
+    ids_pin = torch.empty(m, dtype=torch.int64).pin_memory()
+    best = 1e9
+    for _ in range(4):
+        t0 = time.perf_counter()
+        d.lookup(q_pin.numpy().view(np.uint64), out=ids_pin.numpy().view(np.uint64))
+        best = min(best, time.perf_counter() - t0)
+    report("host_buffers_page_locked_packed_mix50_pcie_inclusive", best * 1e3, units=m)
+    assert (ids_pin.numpy().view(np.uint64) == ids).all()
+    del q_pin, ids_pin
 
     if not args.skip_streaming:
         from oracle import oracle as O  # checker for the counters of a sample
