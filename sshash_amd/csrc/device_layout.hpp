@@ -52,7 +52,9 @@
 //      MPHF lands on. Built on the GPU at upload; SSHASH_AMD_DIRECTORY=0 disables it.
 //
 //  (5) a *super-k-mer table*, built on the GPU at upload from the strings alone (described for k <= 31;
-//      for k <= 63 a slot is 64 bytes -- the same 16-byte head, then 128 bases -- and a bucket two 64-byte lines). Structures
+//      for k <= 63 a slot is 64 bytes -- the same 16-byte head, then 128 bases, then 16 spare bytes -- and a bucket two 64-byte
+//      lines; slot 1's line is fetched only by the probes whose key's fingerprint matches slot 1's, which slot 0 keeps in its
+//      spare bytes). Structures
 //      (1)-(4) answer a positive lookup with two dependent random reads per probe (minimizer ->
 //      position, then the strings) and a regular index probes both strands (src/dictionary.cpp:70-75);
 //      what bounds the batch is the number of such reads. The table answers most lookups with ONE:
@@ -163,6 +165,7 @@ constexpr uint32_t SK_GO_ON = 8u;             // << c: a key whose choice c is t
 constexpr uint32_t SK_CHOICES = 5;            // ... or, for the last choice, in no slot at all (flags: bits 3-7 of slot 0)
 constexpr uint32_t SK_BUCKET_SLOTS = 2;       // slots per bucket: one 64-byte line at k <= 31
 constexpr uint32_t SK_LEFT_SHIFT = 8, SK_RIGHT_SHIFT = 14;
+constexpr uint32_t SK_SECOND_FINGERPRINT_WORD = 12;  // k <= 63: 32-bit word of slot 0 (its last 16 bytes are spare) holding slot 1's fingerprint
 constexpr uint32_t SK_SECOND_USED = 1u << 20;  // in slot 0: slot 1 of the bucket is in use (k <= 63: worth fetching its line)
 /* Bits 21-31 of slot 0: WHICH keys went on from their first choice -- bit sk_filter_index(fingerprint) is set by every item that
    found this bucket, its first choice, full. The first go-on flag alone sends every query that misses in such a bucket (5 % of

@@ -504,6 +504,12 @@ __device__ __forceinline__ void sk_examine_slot(dict_view const& d, sk_query_t<W
         asm volatile("" : "+v"(go_on));
         flags.go_on = go_on;
         flags.second_used = (meta & SK_SECOND_USED) != 0;
+        if constexpr (W == 2) {
+            /* slot 1 is in the bucket's second line: worth fetching only if it holds this query's key (an item holding
+               the query's k-mer has the query's key, so equal fingerprints are necessary for anything slot 1 could add) */
+            const uint4 spare = piece(SK_SECOND_FINGERPRINT_WORD / 4);
+            flags.second_used = flags.second_used && spare.x == Q.fingerprint;
+        }
     }
     const bool valid = (meta & SK_VALID) != 0, is_marker = (meta & SK_MARKER) != 0;
     const bool same_fingerprint = valid && (q0.w >> 8) == Q.fingerprint;

@@ -233,7 +233,12 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
             } else {
                 placed[t] = 1;
                 used = true;
-                if (S != B) atomicOr(B, SK_SECOND_USED);
+                if (S != B) {
+                    atomicOr(B, SK_SECOND_USED);
+                    /* k <= 63: slot 1 lives in the bucket's second line; its fingerprint is kept in slot 0's spare bytes, so
+                       that a probe fetches that line only when its own key is there */
+                    if constexpr (W == 2) B[SK_SECOND_FINGERPRINT_WORD] = h.fingerprint;
+                }
                 uint32_t meta, d1;
                 uint64_t w1;
                 uint64_t body[2 * W];
