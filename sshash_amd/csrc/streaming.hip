@@ -109,8 +109,49 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
         uint64_t off = 0;
         int ori = 1;
         const char* p = bases + begin;
+        /* While a run of found k-mers is extended along a string, the string's k-mer at `off` is kept in registers (`at`)
+           and the next one is made from it with ONE base of the strings -- taken, with its string-start mark, from a block
+           of the strings cached in registers (64 bases at k <= 31, 32 at k <= 63). A window read per extension was a
+           dependent memory access per k-mer of a high-hit read; this is one per 32-64 extensions. */
+        kmer_w<W> at = kmer_zero<W>();
+        uint64_t c_idx = ~uint64_t(0) - 1, c_b0 = 0, c_b1 = 0, c_marks = 0;  // (neither c_idx nor c_idx + 1 is a block)
+        auto string_base = [&](uint64_t pb, uint32_t& base, bool& starts) {
+            const uint64_t idx = pb >> 5;
+            if constexpr (W == 1) {
+                if (idx != c_idx && idx != c_idx + 1) {
+                    const uint4* A = reinterpret_cast<const uint4*>(d.granules) + 2 * idx;
+                    const uint4 q0 = A[0], q1 = A[1];
+                    c_idx = idx;
+                    c_b0 = uint64_t(q0.x) | (uint64_t(q0.y) << 32);
+                    c_b1 = uint64_t(q0.z) | (uint64_t(q0.w) << 32);
+                    c_marks = uint64_t(q1.x) | (uint64_t(q1.y) << 32);
+                }
+                const uint32_t rel = uint32_t(pb - (c_idx << 5));  // 0 .. 63
+                base = uint32_t(((rel < 32 ? c_b0 : c_b1) >> (2 * (rel & 31u))) & 3u);
+                starts = ((c_marks >> rel) & 1u) != 0;
+            } else {
+                if (idx != c_idx) {
+                    const uint4 g = reinterpret_cast<const uint4*>(d.granules)[idx];
+                    c_idx = idx;
+                    c_b0 = uint64_t(g.z) | (uint64_t(g.w) << 32);
+                    c_marks = g.y;
+                }
+                const uint32_t rel = uint32_t(pb) & 31u;
+                base = uint32_t((c_b0 >> (2 * rel)) & 3u);
+                starts = ((c_marks >> rel) & 1u) != 0;
+            }
+        };
+        uint64_t eight = 0;  // the read's characters, eight per load (a byte load per base is a round trip per base)
         for (uint64_t j = 0; j < len; ++j) {
-            const char c = p[j];
+            if ((j & 7u) == 0) {
+                if (j + 8 <= len) {
+                    __builtin_memcpy(&eight, p + j, 8);
+                } else {
+                    eight = 0;
+                    for (uint64_t b = j; b < len; ++b) eight |= uint64_t(uint8_t(p[b])) << (8 * (b - j));
+                }
+            }
+            const char c = char(eight >> (8 * (j & 7u)));
             const uint64_t code = base_code(c);
             x = kmer_roll<W>(x, code, k);
             x_rc = kmer_roll_rc<W>(x_rc, code, k);
@@ -123,11 +164,19 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
                 continue;
             }
             if (in_run && !(ori < 0 && off == 0)) {  // :86-100
+                /* the string's next k-mer in the direction of the run: forward it gains the base at off + k, and leaves
+                   its string iff a string starts there; backward it gains the base at off - 1, and leaves its string iff
+                   a string starts at off (read_window's `crosses` for a window whose neighbour did not cross) */
                 const uint64_t next = ori > 0 ? off + 1 : off - 1;
-                const window_t<W> w = read_window<W>(d.granules, next, k);
-                if (!w.crosses && (kmer_eq<W>(w.kmer, x) || kmer_eq<W>(w.kmer, x_rc))) {
+                uint32_t base, unused;
+                bool boundary;
+                string_base(ori > 0 ? off + k : off - 1, base, boundary);
+                if (ori < 0) string_base(off, unused, boundary);  // (the mark that matters is the one at off)
+                const kmer_w<W> t = ori > 0 ? kmer_roll<W>(at, base, k) : kmer_roll_rc<W>(at, base ^ 2u, k);
+                if (!boundary && (kmer_eq<W>(t, x) || kmer_eq<W>(t, x_rc))) {
                     ++c_extensions;
                     off = next;
+                    at = t;
                     continue;
                 }
             }
@@ -148,6 +197,7 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
                             in_run = true;
                             off = r.kmer_offset;
                             ori = r.orientation;
+                            at = ori > 0 ? x : x_rc;  // what the strings hold at `off`
                             neg_unknown_mini = false;
                         } else {
                             ++c_negative;
@@ -177,6 +227,7 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
                 in_run = true;
                 off = h.kmer_offset;
                 ori = h.orientation;
+                at = ori > 0 ? x : x_rc;
                 neg_unknown_mini = false;
             } else {
                 ++c_negative;
