@@ -605,15 +605,44 @@ __device__ __forceinline__ bool sk_walk_step(dict_view const& d, kmer_w<W> const
 }
 
 /* One lane on its own, every piece read from global memory: the streaming query, whose lanes are at different
-   points of their reads when they need a seed. */
+   points of their reads when they need a seed. The first line of the key's first bucket stays in registers from one seed
+   to the next (`sk_line_cache`): consecutive k-mers of a read share their key more often than not -- the 30 negative seeds
+   that follow a substitution in a high-hit read, the k-mers of an absent region -- and then this probe needs no memory at
+   all unless it has to go on. */
+struct sk_line_cache {
+    uint32_t bucket = 0xFFFFFFFFu;
+    uint4 piece[4];
+};
+
 template <int W>
 __device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
-                                           bool& key_seen) {
+                                           bool& key_seen, sk_line_cache& cache) {
     sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), 0);
     sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, w.h.fingerprint);
     fast_t r = fast_unsettled(false);
     key_seen = false;
     bool more = true;
+    {
+        /* first bucket of the key's own sequence: through the cache */
+        const uint32_t b = sk_choice(w.h, 0);
+        const uint4* B = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(b);
+        if (b != cache.bucket) {
+            cache.bucket = b;
+            for (int i = 0; i < 4; ++i) cache.piece[i] = B[i];
+        }
+        const uint4 c0 = cache.piece[0], c1 = cache.piece[1], c2 = cache.piece[2], c3 = cache.piece[3];
+        auto cached = [c0, c1, c2, c3](uint32_t i) { return i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3; };
+        sk_bucket_flags flags;
+        bool marker = false, seen = false;
+        sk_examine_slot<W, true>(d, Q, w.c, cached, r, seen, marker, flags);
+        if (r.outcome == FAST_MISS && flags.second_used) {
+            if constexpr (W == 1) sk_examine_slot<W, false>(d, Q, w.c, [cached](uint32_t i) { return cached(2 + i); }, r, seen, marker, flags);
+            else sk_examine_slot<W, false>(d, Q, w.c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags);
+        }
+        key_seen = seen;
+        const uint32_t go_on = flags.go_on;
+        more = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
+    }
 #pragma unroll 1
     while (more) {
         const uint4* B = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(sk_choice(w.h, w.c));

@@ -114,6 +114,7 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
            of the strings cached in registers (64 bases at k <= 31, 32 at k <= 63). A window read per extension was a
            dependent memory access per k-mer of a high-hit read; this is one per 32-64 extensions. */
         kmer_w<W> at = kmer_zero<W>();
+        sk_line_cache line_cache;
         uint64_t c_idx = ~uint64_t(0) - 1, c_b0 = 0, c_b1 = 0, c_marks = 0;  // (neither c_idx nor c_idx + 1 is a block)
         auto string_base = [&](uint64_t pb, uint32_t& base, bool& starts) {
             const uint64_t idx = pb >> 5;
@@ -190,7 +191,7 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
                         continue;
                     }
                     bool key_seen;
-                    const fast_t r = sk_probe<W>(d, x, x_rc, kk, key_seen);
+                    const fast_t r = sk_probe<W>(d, x, x_rc, kk, key_seen, line_cache);
                     if (r.outcome != FAST_DEFER) {
                         if (r.outcome == FAST_HIT) {
                             ++c_searches;
