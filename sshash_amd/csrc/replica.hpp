@@ -52,25 +52,45 @@ struct device_replica {
 
     /* Per-stream scratch for the resume and deferred queues of the multi-pass lookup (engine.hip). Work on one stream is
        ordered, so a buffer keyed by the stream can be reused without synchronisation; it only grows
-       (hipFree of the old block synchronises implicitly) and lives as long as the replica: the caller's
-       streams are few and the host path's lanes keep theirs. */
+       (hipFree of the old block synchronises implicitly). At most SCRATCH_STREAMS_MAX streams keep a block. */
     /* held while one launch sequence (queue reset, first / resume / deferred pass) is enqueued: two host threads that share a
        stream (the null stream, typically) must not interleave their sequences, which share that stream's scratch */
     mutable std::mutex launch_mutex;
     mutable std::mutex scratch_mutex;
-    mutable std::unordered_map<void*, std::pair<void*, size_t>> scratch;
+    struct stream_scratch {
+        void* block = nullptr;
+        size_t bytes = 0;
+        uint64_t last_use = 0;
+    };
+    mutable std::unordered_map<void*, stream_scratch> scratch;
+    mutable uint64_t scratch_clock = 0;
+    static constexpr size_t SCRATCH_STREAMS_MAX = 16;  // an application that makes a stream per request must not keep a
+                                                       // gigabyte of queues per stream it ever used: the
+                                                       // least recently used stream's block goes first
     void* scratch_for(void* stream, size_t bytes) const {
         std::lock_guard<std::mutex> lock(scratch_mutex);
-        auto& slot = scratch[stream];
-        if (slot.second < bytes) {
-            if (slot.first) HIP_CHECK(hipFree(slot.first));
-            slot.first = nullptr;
-            slot.second = 0;
-            const size_t want = bytes + bytes / 4 + 4096;
-            HIP_CHECK(hipMalloc(&slot.first, want));
-            slot.second = want;
+        auto it = scratch.find(stream);
+        if (it == scratch.end()) {
+            if (scratch.size() >= SCRATCH_STREAMS_MAX) {
+                auto oldest = scratch.begin();
+                for (auto jt = scratch.begin(); jt != scratch.end(); ++jt)
+                    if (jt->second.last_use < oldest->second.last_use) oldest = jt;
+                if (oldest->second.block) HIP_CHECK(hipFree(oldest->second.block));  // (synchronises: nothing in flight still uses it)
+                scratch.erase(oldest);
+            }
+            it = scratch.emplace(stream, stream_scratch{}).first;
         }
-        return slot.first;
+        stream_scratch& slot = it->second;
+        slot.last_use = ++scratch_clock;
+        if (slot.bytes < bytes) {
+            if (slot.block) HIP_CHECK(hipFree(slot.block));
+            slot.block = nullptr;
+            slot.bytes = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            HIP_CHECK(hipMalloc(&slot.block, want));
+            slot.bytes = want;
+        }
+        return slot.block;
     }
 
     /* pooled lanes of the host-buffer path */
@@ -106,7 +126,7 @@ struct device_replica {
         (void)hipSetDevice(device);
         for (void* p : allocations) (void)hipFree(p);
         for (auto& kv : scratch)
-            if (kv.second.first) (void)hipFree(kv.second.first);
+            if (kv.second.block) (void)hipFree(kv.second.block);
         for (host_lane* lane : idle_lanes) {
             if (lane->pinned) (void)hipHostFree(lane->pinned);
             if (lane->device) (void)hipFree(lane->device);

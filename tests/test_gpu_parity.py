@@ -549,3 +549,26 @@ def test_page_locked_caller_buffers_are_used_in_place(case_se_regular):
     assert (mixed == want).all()
     assert (want == case.oracle.lookup_packed(q, True)["kmer_id"]).all()
 
+
+def test_many_caller_streams(case_se_regular):
+    """A stream per request: the per-stream queue scratch is capped (the least recently used stream's block is freed when a
+    17th stream shows up), and every stream -- new, evicted and back again -- gets right answers."""
+    import torch
+
+    case = case_se_regular
+    d = case.dict.to_device(0)
+    q = case.queries(20_000, 20_000, seed=43)
+    want = torch.from_numpy(case.oracle.lookup_packed(q, True)["kmer_id"].view(np.int64)).cuda()
+    dq = torch.from_numpy(q.view(np.int64)).cuda()
+    streams = [torch.cuda.Stream() for _ in range(40)]
+    outs = [torch.empty(want.numel(), dtype=torch.int64, device="cuda:0") for _ in streams]
+    torch.cuda.synchronize()
+    for turn in range(2):
+        for s, o in zip(streams, outs):
+            o.fill_(5)
+            torch.cuda.synchronize()
+            d.lookup_device(0, dq.data_ptr(), want.numel(), o.data_ptr(), stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, want)
+
