@@ -46,4 +46,20 @@ def test_point(k, m, canonical, tmp_path):
     # forward only: the reverse complements are misses unless the k-mer is in the input on that strand too
     fwd = d.lookup(queries, check_reverse_complement=False).kmer_id
     assert (fwd == case.oracle.lookup_packed(queries, False)["kmer_id"]).all()
+    # the streaming query over reads cut out of the strings (substitutions, N's, both strands, ends of strings) and random
+    # ones: the six counters and every per-k-mer result against the oracle's restated state machine
+    from test_gpu_streaming import _as_dict, _synthetic_reads
+
+    reads = _synthetic_reads(case, 400, seed=k + m, read_len=3 * k) + [sequences[-1], sequences[0] + "ACGT" * 5, sequences[2][::-1]]
+    want_report = case.oracle.streaming_query(reads)
+    assert _as_dict(d.streaming_query(reads)) == want_report
+    per_read, report = d.streaming_lookup(reads, full=True)
+    assert _as_dict(report) == want_report
+    for read, got in zip(reads, per_read):
+        want = case.oracle.streaming_read(read)
+        assert got.kmer_id.size == want.size == max(0, len(read) - k + 1)
+        found = want["kmer_id"] != np.uint64(0xFFFFFFFFFFFFFFFF)
+        for f in ("kmer_id", "kmer_id_in_string", "string_id", "string_begin", "string_end"):
+            assert (getattr(got, f) == want[f]).all(), f
+        assert (got.kmer_orientation[found] == want["kmer_orientation"][found]).all()
     d.close()
