@@ -133,12 +133,13 @@ sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out
  * host variants: caller-owned host buffers; the batch is sharded over all resident devices. Page-locked buffers (hipHostMalloc /
  *           hipHostRegister; input AND every requested output) are copied from and to directly: 4.5 G lookups/s over PCIe
  *           against 1.5 G/s for pageable memory, which is staged through the library's own pinned lanes.
- * Cost of the fields: NULL arrays are skipped. kmer_id alone, or any of the position fields with it, is answered by the
- * device's super-k-mer table at full speed (33 G lookups/s); asking for `minimizer_found` sends the
- * whole batch down the MPHF path (10 G/s), the only one that can reproduce the flag of an absent minimizer -- it depends on
- * which bucket the MPHF maps that minimizer to (include/spectrum_preserving_string_set.hpp:46-65). (Hits from the table and
- * only the misses through the MPHF was measured: 9.0 against 10.1 G/s at 50 % positives -- the misses' eight scattered
- * result stores cost more than the hits save -- and is not done.)                                                    */
+ * Cost of the fields: NULL arrays are skipped. kmer_id alone is answered by the device's super-k-mer table at full speed (DESIGN.md
+ * section 6: 35-39 G lookups/s); the position fields come from the same probe (all seven: 22 G/s at 50 % positives -- seven output
+ * streams, and string_begin / string_end cost a hit one more random read). `minimizer_found` is true for a hit; for a miss only the
+ * MPHF can reproduce it -- the flag of an absent minimizer depends on which bucket the MPHF maps that minimizer to
+ * (include/spectrum_preserving_string_set.hpp:46-65) --, so the misses of a batch that asks for it go through the MPHF path in a
+ * last pass that stores that one byte: 17 G/s at 100 % positives, 12 at 50 %, 9 at 0 % (everything through the MPHF path, as a
+ * replica without the table does it: 9 / 10 / 12).                                                                            */
 sshash_status sshash_lookup_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
                                           int check_reverse_complement, const sshash_results* out, void* hip_stream);
 sshash_status sshash_lookup_ascii_device(const sshash_dict* d, int device, const char* kmers, uint64_t n,

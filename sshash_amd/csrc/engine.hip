@@ -392,7 +392,13 @@ struct pass_queues {
     uint64_t* resume_kmers;
     uint32_t defer_capacity;   // places per shard
     uint32_t resume_capacity;
+    /* the caller wants `minimizer_found`: a hit has it (true) and every other field of a miss is known as well, so the first
+       two passes store complete results for everything; only the flag of a MISS needs the MPHF (for an absent minimizer the
+       reference's flag depends on which arbitrary bucket the MPHF lands on): misses are queued with DEFER_FLAG_ONLY set
+       and the last pass stores that one byte for them */
+    uint32_t flag_misses;
 };
+constexpr uint32_t DEFER_FLAG_ONLY = 1u << 31;  // in a deferred-queue entry (query indices stay below 2^27)
 
 template <int W, bool ASCII>
 __device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries, uint64_t i, uint32_t k) {
@@ -494,10 +500,12 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
         h.string_id = r.string_id;
         h.orientation = r.orientation;
         h.found = r.outcome == FAST_HIT;
-        h.minimizer_found = true;  // never stored on this path (see launch())
+        h.minimizer_found = true;  // a hit has it; a miss gets the real one from the last pass when the caller asked for it (pass_queues)
         store_result<MODE == int(out_mode::full)>(d, out, i, h);
     }
     if (r.outcome == FAST_DEFER) q.defer_index[uint64_t(shard) * q.defer_capacity + atomicAdd(q.defer_counts + shard, 1u)] = uint32_t(i);
+    else if (MODE == int(out_mode::full) && SK && q.flag_misses && r.outcome == FAST_MISS)
+        q.defer_index[uint64_t(shard) * q.defer_capacity + atomicAdd(q.defer_counts + shard, 1u)] = uint32_t(i) | DEFER_FLAG_ONLY;
 }
 
 /* Second pass of the table lookup: the queries the first pass could not settle with one bucket read (their key's
@@ -536,6 +544,8 @@ resume_lookup_kernel(const dict_view d, const bool check_rc, const result_view o
             h.found = r.outcome == FAST_HIT;
             h.minimizer_found = true;
             store_result<MODE == int(out_mode::full)>(d, out, i, h);
+            if (MODE == int(out_mode::full) && q.flag_misses && r.outcome == FAST_MISS)
+                q.defer_index[uint64_t(shard) * q.defer_capacity + atomicAdd(q.defer_counts + shard, 1u)] = uint32_t(i) | DEFER_FLAG_ONLY;
         }
     }
 }
@@ -551,8 +561,18 @@ deferred_lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew
     const uint32_t total = q.defer_counts[shard];
     const uint32_t* mine = q.defer_index + uint64_t(shard) * q.defer_capacity;
     for (uint32_t j = part * blockDim.x + threadIdx.x; j < total; j += DEFER_BLOCKS_PER_SHARD * blockDim.x) {
-        const uint64_t i = mine[j];
+        const uint32_t entry = mine[j];
+        const uint64_t i = entry & ~DEFER_FLAG_ONLY;
         const kmer_w<W> x = load_query<W, ASCII>(queries, i, d.k);
+        if constexpr (MODE == int(out_mode::full)) {
+            if (q.flag_misses) {
+                /* the MPHF path without the directory: it alone reproduces the flag (launch()) */
+                const hit_t h = lookup_one<W, CANON, false>(d, skew, x, check_rc);
+                if (entry & DEFER_FLAG_ONLY) out.minimizer_found[i] = h.minimizer_found ? 1 : 0;  // everything else is stored already
+                else store_result<true>(d, out, i, h);
+                continue;
+            }
+        }
         const hit_t h = lookup_one<W, CANON, true>(d, skew, x, check_rc);
         if constexpr (MODE == int(out_mode::member)) {
             member[i] = h.found ? 1 : 0;
@@ -603,11 +623,13 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
     dict_view const& d = rep->view;
     skew_part_dev const* skew = rep->d_skew;
     const uint32_t block = 256;
-    /* Multi-pass lookup through the table (or the minimizer directory) -- unless the caller wants `minimizer_found`:
-       for an absent minimizer the reference's flag depends on which (arbitrary) bucket the MPHF lands
-       on, so only the MPHF path can reproduce it (device_layout.hpp (4)). */
+    /* Multi-pass lookup through the table (or the minimizer directory). A caller that wants `minimizer_found` still gets
+       everything from the table except the flag of the misses: for an absent minimizer the reference's flag depends on which
+       (arbitrary) bucket the MPHF lands on, so only the MPHF path can reproduce it (device_layout.hpp (4)) -- the last pass
+       computes that one byte for them. Without a table such a caller gets the MPHF kernel for everything. */
     {
-        if ((d.directory.enabled || d.sk.enabled) && !(MODE == int(out_mode::full) && out.minimizer_found)) {
+        const bool wants_flag = MODE == int(out_mode::full) && out.minimizer_found;
+        if ((d.directory.enabled || d.sk.enabled) && !(wants_flag && !d.sk.enabled)) {
             /* multi-pass: at most 2^27 queries per launch sequence (queue entries are 32-bit; the scratch
                queues stay below 1.3 GiB (2.1 for 128-bit k-mers)) */
             const uint64_t piece_max = launch_piece_queries();
@@ -618,6 +640,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 const uint64_t m = std::min(piece, n - at);
                 const uint32_t nblocks = uint32_t((m + block - 1) / block);
                 pass_queues pq{};
+                pq.flag_misses = wants_flag ? 1u : 0u;
                 pq.defer_capacity = ((nblocks + DEFER_SHARDS - 1) / DEFER_SHARDS) * block;
                 pq.resume_capacity = d.sk.enabled ? (pq.defer_capacity + 1) / resume_capacity_divisor() : 0;
                 const uint64_t defer_places = uint64_t(DEFER_SHARDS) * pq.defer_capacity, resume_places = uint64_t(DEFER_SHARDS) * pq.resume_capacity;
