@@ -138,8 +138,8 @@ sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out
  * streams, and string_begin / string_end cost a hit one more random read). `minimizer_found` is true for a hit; for a miss only the
  * MPHF can reproduce it -- the flag of an absent minimizer depends on which bucket the MPHF maps that minimizer to
  * (include/spectrum_preserving_string_set.hpp:46-65) --, so the misses of a batch that asks for it go through the MPHF path in a
- * last pass that stores that one byte: 17 G/s at 100 % positives, 12 at 50 %, 9 at 0 % (everything through the MPHF path, as a
- * replica without the table does it: 9 / 10 / 12).                                                                            */
+ * last pass that stores that one byte (one probe: the reference's result for a miss is that of its last probe): 17 G/s at 100 %
+ * positives, 15 at 50 %, 14 at 0 % (everything through the MPHF path, as a replica without the table does it: 9 / 10 / 12).                                                                            */
 sshash_status sshash_lookup_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
                                           int check_reverse_complement, const sshash_results* out, void* hip_stream);
 sshash_status sshash_lookup_ascii_device(const sshash_dict* d, int device, const char* kmers, uint64_t n,

@@ -567,9 +567,11 @@ deferred_lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew
         if constexpr (MODE == int(out_mode::full)) {
             if (q.flag_misses) {
                 /* the MPHF path without the directory: it alone reproduces the flag (launch()) */
-                const hit_t h = lookup_one<W, CANON, false>(d, skew, x, check_rc);
-                if (entry & DEFER_FLAG_ONLY) out.minimizer_found[i] = h.minimizer_found ? 1 : 0;  // everything else is stored already
-                else store_result<true>(d, out, i, h);
+                if (entry & DEFER_FLAG_ONLY) {  // everything else is stored already
+                    out.minimizer_found[i] = minimizer_found_of_a_miss<W, CANON>(d, skew, x, check_rc) ? 1 : 0;
+                } else {
+                    store_result<true>(d, out, i, lookup_one<W, CANON, false>(d, skew, x, check_rc));
+                }
                 continue;
             }
         }

@@ -337,6 +337,21 @@ __device__ __forceinline__ hit_t lookup_one(dict_view const& d, skew_part_dev co
     }
 }
 
+/* `minimizer_found` of a k-mer already known to be absent (the table said so): what the reference's lookup returns for it is
+   the result of its LAST probe -- a regular dictionary probes the k-mer, then, not having found it, its reverse complement
+   and returns that result (src/dictionary.cpp:70-75); a canonical one probes once (or twice on a minimizer tie) -- so the
+   forward probe of a regular dictionary need not be repeated here. MPHF path, no directory (device_layout.hpp (4)). */
+template <int W, bool CANON>
+__device__ __forceinline__ bool minimizer_found_of_a_miss(dict_view const& d, skew_part_dev const* __restrict__ skew, kmer_w<W> const& x,
+                                                          bool check_rc) {
+    if constexpr (CANON) {
+        return lookup_one<W, true, false>(d, skew, x, check_rc).minimizer_found;
+    } else {
+        const kmer_w<W> y = check_rc ? kmer_revcomp<W>(x, d.k) : x;
+        return probe_regular<W, false>(d, skew, y, compute_minimizer<W>(y, d.k, d.m, d.hash_magic)).minimizer_found;
+    }
+}
+
 /* ---- lookup without the table (minimizer shards, SSHASH_AMD_SKTABLE=0): the common case in a lean kernel,
    everything else deferred ------------
    The generic `lookup_one` above carries the code of every rare case (MIDLOAD scans, the skew index,
