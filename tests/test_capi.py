@@ -136,6 +136,39 @@ def test_table_key_function_is_strand_symmetric(tmp_path):
     assert p.returncode == 0 and p.stdout.startswith("OK "), p.stdout + p.stderr
 
 
+def test_query_file_readers_hand_over_bounded_batches(tmp_path):
+    """csrc/reads.cpp on the host: read_stream (what sshash_streaming_query_from_file feeds the device from, a bounded batch
+    of whole reads at a time) yields exactly the reads of the whole file, in order, whatever the batch size -- FASTQ, one-line
+    FASTA, multiline FASTA (src/query.cpp:9-108). tests/cpp/check_reads.cpp, plain g++ + zlib."""
+    import gzip
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "check_reads")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "check_reads.cpp"),
+                           os.path.join(ROOT, "sshash_amd", "csrc", "reads.cpp"), "-lz", "-o", exe])
+    golden = os.path.join(ROOT, "tests", "golden")
+    multi = tmp_path / "multi.fa"
+    with gzip.open(os.path.join(golden, "se.ust.k63.head.fa.gz"), "rt") as f:
+        seqs = [line.strip() for line in f if not line.startswith(">")][:200]
+    with open(multi, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(f">{i}\n{s[:70]}\n{s[70:]}\n\n")
+    for path, multiline, k, reads in ((os.path.join(golden, "SRR5833294.10K.fastq.gz"), 0, 31, 10000),
+                                      (os.path.join(golden, "salmonella_enterica_k31_ust.fa.gz"), 0, 31, None),
+                                      (str(multi), 1, 63, len(seqs)), (str(multi), 0, 63, None)):
+        p = subprocess.run([exe, path, str(multiline), str(k)], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and p.stdout.startswith("OK "), (path, multiline, p.stdout + p.stderr)
+        if reads is not None:
+            assert int(p.stdout.split()[1]) == reads
+    txt = tmp_path / "reads.txt"
+    txt.write_text("ACGT\n")
+    p = subprocess.run([exe, str(txt), "0", "31"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and p.stdout.startswith("unsupported")
+
+
 def test_repeated_kmer_in_a_heavy_bucket_fails_fast(tmp_path):
     """Every k-mer of the input must occur once (a spectrum-preserving string set). A k-mer repeated often enough
     to land in the skew index makes two MPHF keys equal; the builder must say so at once instead of searching
