@@ -136,6 +136,16 @@ def test_table_key_function_is_strand_symmetric(tmp_path):
     assert p.returncode == 0 and p.stdout.startswith("OK "), p.stdout + p.stderr
 
 
+def test_lookup_output_buffer_is_checked_before_anything_runs(case_skew_regular):
+    """Dictionary.lookup(out=...) hands the caller's array to the library (page-locked buffers are then used in place): a
+    wrong dtype, size or layout is refused in the binding, before any call into the library."""
+    d = case_skew_regular.dict
+    q = case_skew_regular.queries(4, 4, seed=1)
+    for bad in (np.empty(8, dtype=np.int64), np.empty(7, dtype=np.uint64), np.empty(16, dtype=np.uint64)[::2]):
+        with pytest.raises(ValueError):
+            d.lookup(q, out=bad)
+
+
 def test_query_file_readers_hand_over_bounded_batches(tmp_path):
     """csrc/reads.cpp on the host: read_stream (what sshash_streaming_query_from_file feeds the device from, a bounded batch
     of whole reads at a time) yields exactly the reads of the whole file, in order, whatever the batch size -- FASTQ, one-line
