@@ -39,11 +39,13 @@ RANDOM_UNIT_PROBE = 43.75e9  # random 64-byte units/s one MI355X sustains on a 3
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
-    # name: (bases, mean string length, queries in the batch, description)
-    "c3": (2_813_553_873, 274.0, 1_000_000_000,
-           "C3 stand-in: synthetic SPSS with the human-genome k=31 build's size statistics"),
-    "c2": (1_387_536_274, 85.0, 100_000_000,
-           "C2 stand-in: synthetic SPSS with S. enterica pangenome size statistics"),
+    # name: (bases, recipe of sshash_amd/recipes/, queries in the batch, description)
+    "c3": (2_813_192_630, "human_k31", 1_000_000_000,
+           "C3 stand-in: synthetic SPSS fitted to the bucket statistics the reference printed for human.k31 (repeat families + "
+           "de-duplication, sshash_amd/repeats.py; target vs achieved in config.index_statistics)"),
+    "c2": (1_387_536_274, "se_k31", 100_000_000,
+           "C2 stand-in: synthetic SPSS fitted to the bucket statistics the reference printed for the S. enterica pangenome "
+           "(sshash_amd/repeats.py; target vs achieved in config.index_statistics)"),
 }
 
 
@@ -87,14 +89,12 @@ def split_batch(total: int, world: int, rank: int) -> tuple[int, int]:
 def get_index(args, rank: int, world: int, barrier):
     """Build the synthetic dictionary once (rank 0), cache it on local disk, load it on every rank."""
     import sshash_amd
-    from sshash_amd.synthetic import make_spss
 
-    mean_len = getattr(args, "mean_len", 85.0)
-    key = f"v3-{args.bases}-{args.k}-{args.m}-{int(args.canonical)}-{args.seed}-{mean_len}"
+    key = f"v4-{args.bases}-{args.k}-{args.m}-{int(args.canonical)}-{args.seed}-{args.recipe}-{args.repeat_scale}-{recipe_digest(args.recipe)}"
     path = os.path.join(args.cache_dir, "sshash_amd_bench_" + hashlib.sha1(key.encode()).hexdigest()[:16] + ".sshash")
     if rank == 0 and not os.path.exists(path):
         t0 = time.time()
-        words, endpoints = make_spss(args.bases, k=args.k, m=args.m, seed=args.seed, mean_len=mean_len)
+        words, endpoints = make_standin(args)
         log(f"synthetic SPSS: {endpoints.size - 1} strings, {int(endpoints[-1])} bases in {time.time() - t0:.1f}s")
         t0 = time.time()
         d = sshash_amd.Dictionary.build_from_packed(words, endpoints, k=args.k, m=args.m, canonical=args.canonical,
@@ -114,6 +114,84 @@ def get_index(args, rank: int, world: int, barrier):
     if rank == 0:
         log(f"dictionary loaded from cache in {time.time() - t0:.1f}s")
     return d, path
+
+
+def recipe_digest(name: str) -> str:
+    path = os.path.join(ROOT, "sshash_amd", "recipes", name + ".json")
+    return hashlib.sha1(open(path, "rb").read()).hexdigest()[:12]
+
+
+def make_standin(args):
+    """The synthetic SPSS of this run: the named recipe at --bases bases; --repeat-scale multiplies the amount of every repeat
+    family (the heavy-key sweep of DESIGN.md section 6; 1.0 = the fitted recipe)."""
+    import torch
+    from sshash_amd.repeats import load_recipe, make_repeat_spss
+
+    if args.k > 31:  # (the recipes are fitted at k = 31; the two-word k-mer runs keep the planted-motif generator)
+        from sshash_amd.synthetic import make_spss
+
+        return make_spss(args.bases, k=args.k, m=args.m, seed=args.seed, mean_len=274.0)
+    r = load_recipe(args.recipe)
+    classes = [dict(c, families=c["families"] * args.repeat_scale) for c in r["classes"]]
+    background = r["background"]
+    if args.repeat_scale != 1.0:
+        background = None  # the background fills whatever the families leave of --bases
+    mean_len = max(b["mean_len"] for b in r["background"])
+    out = make_repeat_spss(args.bases, k=args.k, classes=classes, seed=args.seed, reference_bases=float(r["reference_bases"]),
+                           background=background, mean_len=mean_len)
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()  # the generator's scratch must not count as used HBM when the table is sized
+    return out
+
+
+def measure_other_paths(args, index_path, device, dq, ids_of_table_path, W, bytes_per_lookup):
+    """Side measurement, OUTSIDE the timed region: the same batch (its first 10^8 queries) through the replica layouts that
+    have no super-k-mer table -- what a minimizer shard, a dictionary too large for a table, or SSHASH_AMD_SKTABLE=0 run:
+      directory   minimizer -> one-atom directory -> bucket probe (lookup_device.hpp fast_probe_*)
+      mphf        the path north_star names: minimizer -> MPHF -> control codeword -> bucket probe
+    Every id is compared with the table path's (itself checked against the oracle)."""
+    import torch
+
+    import sshash_amd
+
+    m = min(dq.numel() // W, 100_000_000)
+    out = torch.empty(m, dtype=torch.int64, device=dq.device)
+    stream = torch.cuda.current_stream()
+    res = {}
+    for name, env in (("directory", {"SSHASH_AMD_SKTABLE": "0"}), ("mphf", {"SSHASH_AMD_SKTABLE": "0", "SSHASH_AMD_DIRECTORY": "0"})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            d2 = sshash_amd.Dictionary.load(index_path)
+            d2.to_device(device)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        st = d2.device_stats(device)
+        assert st["sk_slots"] == 0 and (name == "directory") == bool(st["directory_sectors"]), st
+
+        def run():
+            d2.lookup_device(device, dq.data_ptr(), m, out.data_ptr(), check_reverse_complement=True, stream=stream.cuda_stream)
+
+        run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(3):
+            run()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        if not bool((out == ids_of_table_path[:m]).all().item()):
+            raise SystemExit(f"PARITY FAILURE: the {name} path and the table path disagree")
+        gbs = bytes_per_lookup * m / (ms * 1e-3) / 1e9
+        res[name] = {"lookups_per_s": round(m / ms * 1e3, 1), "ms": round(ms, 3), "queries": m, "ids_equal_table_path": True,
+                     "device_index_bytes": st["bytes"], "roofline_frac": round(gbs / HBM_PEAK_GBS, 5), "algorithmic_GBps": round(gbs, 1)}
+        d2.close()
+    return res
 
 
 def traffic_record(d, n_local: int, args):
@@ -143,7 +221,9 @@ def main():
     ap.add_argument("--queries", type=int, default=None, help="queries in the batch, ALL GPUs together (default: the workload's)")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--m", type=int, default=21)
-    ap.add_argument("--mean-len", type=float, default=None, help="mean string length of the synthetic SPSS")
+    ap.add_argument("--recipe", default=None, help="sshash_amd/recipes/<name>.json (default: the workload's)")
+    ap.add_argument("--repeat-scale", type=float, default=1.0, help="multiply the amount of every repeat family of the recipe")
+    ap.add_argument("--no-other-paths", action="store_true", help="skip the table-less paths (side measurement, outside the timed region)")
     ap.add_argument("--canonical", action="store_true")
     ap.add_argument("--positive", type=float, default=0.5, help="fraction of positive queries in the batch")
     ap.add_argument("--negatives", choices=["random", "mutated"], default="random",
@@ -159,11 +239,11 @@ def main():
                          "route every query to its owner with an all-to-all over RCCL (sshash_sharded_lookup_device)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
-    bases, mean_len, queries, what = WORKLOADS[args.workload]
+    bases, recipe, queries, what = WORKLOADS[args.workload]
     if args.bases is None:
         args.bases = bases
-    if args.mean_len is None:
-        args.mean_len = mean_len
+    if args.recipe is None:
+        args.recipe = recipe
     if args.queries is None:
         args.queries = queries
 
@@ -227,9 +307,8 @@ def main():
         else:
             # rank r keeps the buckets of its own minimizers only: rebuilt from the cached dictionary's strings
             import sshash_amd
-            from sshash_amd.synthetic import make_spss
 
-            words, endpoints = make_spss(args.bases, k=args.k, m=args.m, seed=args.seed, mean_len=args.mean_len)
+            words, endpoints = make_standin(args)
             shard = sshash_amd.Dictionary.build_from_packed(words, endpoints, k=args.k, m=args.m, canonical=args.canonical, num_threads=0,
                                                             num_shards=world, shard_id=rank)
             del words
@@ -373,6 +452,19 @@ def main():
                 extra[name] = {"lookups_per_s": round(m / ms * 1e3, 1), "ms": round(ms, 3), "queries": m,
                                "fraction_found": round(float((o2 != -1).float().mean().item()), 4)}
                 del q2
+        other_paths = None
+        if world == 1 and sharded is None and not args.no_other_paths and stats["sk_slots"]:
+            other_paths = measure_other_paths(args, index_path, local_rank, dq, out, W, bytes_per_lookup)
+        index_statistics = table_histogram = None
+        if args.k <= 31:
+            from sshash_amd.repeats import statistics_vs_target
+
+            index_statistics = statistics_vs_target(d.bucket_stats(), args.recipe)
+            table_histogram = d.device_table_histogram(local_rank)
+            heavy = sum(v for kk, v in table_histogram["super_kmers_by_occurrences_of_their_key"].items() if kk not in ("1", "2", "3", "4"))
+            table_histogram["super_kmers_under_heavy_keys_fraction"] = round(heavy / max(1, table_histogram["super_kmers"]), 5)
+            table_histogram["kmers_under_heavy_keys"] = stats["sk_heavy_kmers"]
+            table_histogram["kmers_under_heavy_keys_fraction"] = round(stats["sk_heavy_kmers"] / d.num_kmers(), 5)
         total = args.queries * args.steps
         result = {
             "metric": "k-mer Lookups/sec (batched random queries, bit-exact ids)",
@@ -396,11 +488,13 @@ def main():
                        "canonical": d.canonical(), "index_replicated_per_gpu": sharded is None, "sharded": args.sharded,
                        "positive_fraction_found": round(found, 4), "device_index_bytes": d.device_bytes(local_rank),
                        "device_bytes_per_kmer": round(d.device_bytes(local_rank) / d.num_kmers(), 2),
-                       "device_stats": stats},
+                       "device_stats": stats, "recipe": args.recipe, "repeat_scale": args.repeat_scale,
+                       "index_statistics": index_statistics, "table_histogram": table_histogram},
             "per_rank": per_rank,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "other_mixes": extra,
+            "other_paths": other_paths,
         }
     barrier()
     if use_dist:

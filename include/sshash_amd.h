@@ -107,6 +107,15 @@ sshash_status sshash_load(const char* filename, sshash_dict** out);
 void sshash_free(sshash_dict* d);
 sshash_status sshash_get_info(const sshash_dict* d, sshash_info* info);
 
+/* The bucket statistics `sshash build --verbose` prints (src/builder/build_sparse_and_skew_index.cpp:64-99,
+ * include/buckets_statistics.hpp: "num_buckets_larger_than_1_not_in_skew_index", "num_buckets_in_skew_index",
+ * "max_bucket_size", "num kmers in skew index", "buckets with s minimizer positions"), recomputed from the finished index:
+ * out = { [0] minimizers, [1] minimizer positions, [2] buckets of 2..64 positions, [3] positions in them, [4] buckets in the
+ *         skew index, [5] positions in them, [6] k-mers in the skew index, [7] largest bucket, [8..15] k-mers per skew
+ *         partition, [16..31] buckets of exactly 1..16 positions, [32] k-mers, [33] strings, [34] bases, [35] skew
+ *         partitions, [36] longest string, [37..63] zero } */
+sshash_status sshash_bucket_stats(const sshash_dict* d, uint64_t out[64]);
+
 /* ---- device residency (no reference counterpart: the reference is host-only) ------------- */
 int sshash_device_count(void);
 sshash_status sshash_to_device(sshash_dict* d, int device);
@@ -125,6 +134,12 @@ sshash_status sshash_device_bytes(const sshash_dict* d, int device, uint64_t* by
  *         -- in all these cases lookups take the directory / MPHF path, about half as fast --, [12] bytes of the table,
  *         [13..15] reserved } */
 sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out[16]);
+/* The keys of the super-k-mer table by number of occurrences -- the table-side counterpart of sshash_bucket_stats (a key
+ * with more than 4 occurrences is "heavy": one slot per k-mer, one more bucket read per lookup):
+ * out = { [0..9) keys with 1, 2, 3, 4, 5-8, 9-16, 17-64, 65-1024, > 1024 occurrences, [9..18) the occurrences (super-k-mers)
+ *         in each of these bins, [18] super-k-mers in all, [19] slots asked for (inline occurrences + markers + k-mers of heavy
+ *         keys), [20..31] zero }; all zero when the replica has no table. */
+sshash_status sshash_device_table_histogram(const sshash_dict* d, int device, uint64_t out[32]);
 
 /* ---- dictionary::lookup(Kmer, bool) / lookup(char const*, bool): include/dictionary.hpp:41-42,
  *      src/dictionary.cpp:58-78. Batched. ------------------------------------------------------

@@ -141,11 +141,13 @@ def _load() -> C.CDLL:
         "sshash_load": (C.c_int, [C.c_char_p, C.POINTER(P)]),
         "sshash_free": (None, [P]),
         "sshash_get_info": (C.c_int, [P, C.POINTER(_Info)]),
+        "sshash_bucket_stats": (C.c_int, [P, C.POINTER(C.c_uint64 * 64)]),
         "sshash_device_count": (C.c_int, []),
         "sshash_to_device": (C.c_int, [P, C.c_int]),
         "sshash_to_device_table_shard": (C.c_int, [P, C.c_int, C.c_uint32, C.c_uint32]),
         "sshash_device_bytes": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64)]),
         "sshash_device_stats": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64 * 16)]),
+        "sshash_device_table_histogram": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64 * 32)]),
         "sshash_sharded_lookup_device": (C.c_int, [P, C.c_int, C.c_uint32, C.c_int, P, C.c_uint64, C.c_int, P, C.POINTER(_Exchange), P]),
         "sshash_sharded_lookup_rccl": (C.c_int, [P, C.c_int, P, C.c_int, P, C.c_uint64, C.c_int, P, P]),
         "sshash_streaming_lookup_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, C.c_uint64, C.POINTER(_Results), P, P]),
@@ -185,7 +187,7 @@ def _load() -> C.CDLL:
 
 C_ABI_SYMBOLS = (
     "sshash_last_error sshash_build_config_default sshash_build_from_fasta sshash_build_from_packed sshash_save "
-    "sshash_load sshash_free sshash_get_info sshash_device_count sshash_to_device sshash_to_device_table_shard sshash_device_bytes sshash_device_stats "
+    "sshash_load sshash_free sshash_get_info sshash_bucket_stats sshash_device_count sshash_to_device sshash_to_device_table_shard sshash_device_bytes sshash_device_stats sshash_device_table_histogram "
     "sshash_lookup_packed_device sshash_lookup_ascii_device sshash_lookup_packed sshash_lookup_ascii "
     "sshash_neighbours_packed_device sshash_neighbours_packed sshash_string_neighbours sshash_string_size sshash_string_offsets "
     "sshash_is_member_packed_device sshash_is_member_packed sshash_is_member_ascii sshash_access sshash_access_packed "
@@ -345,6 +347,17 @@ class Dictionary:
         _check(_load().sshash_device_bytes(self._h, int(device), C.byref(out)))
         return int(out.value)
 
+    def bucket_stats(self) -> dict:
+        """The statistics `sshash build --verbose` prints for the sparse and skew index (sshash_bucket_stats)."""
+        out = (C.c_uint64 * 64)()
+        _check(_load().sshash_bucket_stats(self._h, C.byref(out)))
+        v = [int(x) for x in out]
+        return {"num_minimizers": v[0], "num_minimizer_positions": v[1], "num_buckets_larger_than_1_not_in_skew_index": v[2],
+                "num_minimizer_positions_of_buckets_larger_than_1": v[3], "num_buckets_in_skew_index": v[4],
+                "num_minimizer_positions_of_buckets_in_skew_index": v[5], "num_kmers_in_skew_index": v[6], "max_bucket_size": v[7],
+                "num_kmers_in_skew_partition": v[8:8 + v[35]], "buckets_with_n_positions": v[16:32], "num_kmers": v[32],
+                "num_strings": v[33], "num_bases": v[34], "max_string_length": v[36]}
+
     def device_stats(self, device: int = 0) -> dict:
         out = (C.c_uint64 * 16)()
         _check(_load().sshash_device_stats(self._h, int(device), C.byref(out)))
@@ -355,6 +368,15 @@ class Dictionary:
                 "sk_deferred_keys": int(out[7]), "sk_slots_used": int(out[8]), "sk_heavy_keys": int(out[9]),
                 "sk_heavy_kmers": int(out[10]), "sk_absent_reason": reasons.get(int(out[11]), str(int(out[11]))),
                 "sk_bytes": int(out[12]), "sk_load_factor": round(int(out[8]) / int(out[4]), 4) if int(out[4]) else 0.0}
+
+    def device_table_histogram(self, device: int = 0) -> dict:
+        """Keys of the super-k-mer table by number of occurrences (sshash_device_table_histogram)."""
+        out = (C.c_uint64 * 32)()
+        _check(_load().sshash_device_table_histogram(self._h, int(device), C.byref(out)))
+        v = [int(x) for x in out]
+        bins = ["1", "2", "3", "4", "5-8", "9-16", "17-64", "65-1024", ">1024"]
+        return {"keys_by_occurrences": dict(zip(bins, v[0:9])), "super_kmers_by_occurrences_of_their_key": dict(zip(bins, v[9:18])),
+                "super_kmers": v[18], "slots_asked_for": v[19]}
 
     def _as_batch(self, kmers: KmerBatch):
         """-> (is_ascii, contiguous ndarray, n)"""

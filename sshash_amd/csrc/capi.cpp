@@ -165,6 +165,11 @@ sshash_status sshash_get_info(const sshash_dict* d, sshash_info* info) {
     return SSHASH_OK;
 }
 
+sshash_status sshash_bucket_stats(const sshash_dict* d, uint64_t out[64]) {
+    if (!d || !out) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { bucket_statistics(*d->idx, out); });
+}
+
 int sshash_device_count(void) { return visible_device_count(); }
 
 sshash_status sshash_to_device(sshash_dict* d, int device) {
@@ -180,6 +185,11 @@ sshash_status sshash_device_bytes(const sshash_dict* d, int device, uint64_t* by
 sshash_status sshash_device_stats(const sshash_dict* d, int device, uint64_t out[16]) {
     if (!d || !out) return fail(SSHASH_ERR_ARGUMENT, "null argument");
     return guarded([&] { d->eng->device_stats(device, out); });
+}
+
+sshash_status sshash_device_table_histogram(const sshash_dict* d, int device, uint64_t out[32]) {
+    if (!d || !out) return fail(SSHASH_ERR_ARGUMENT, "null argument");
+    return guarded([&] { d->eng->device_table_histogram(device, out); });
 }
 
 sshash_status sshash_lookup_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,

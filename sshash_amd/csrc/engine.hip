@@ -192,6 +192,11 @@ void engine::device_stats(int device, uint64_t out[16]) const {
     out[13] = out[14] = out[15] = 0;
 }
 
+void engine::device_table_histogram(int device, uint64_t out[32]) const {
+    device_replica const* r = replica(device);
+    for (int i = 0; i < 32; ++i) out[i] = i < 20 && r->view.sk.enabled ? r->sk_histogram[i] : 0;
+}
+
 device_replica const* engine::replica(int device) const {
     std::shared_lock<std::shared_mutex> lock(m_replicas_mutex);
     for (auto const& r : m_replicas)

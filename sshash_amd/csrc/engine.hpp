@@ -45,6 +45,7 @@ public:
     /* {bytes in HBM, directory sectors, directory sectors flagged overflow, keys held by the directory,
         super-k-mer table slots (0 = disabled), its keys, its inline keys, its keys left to the complete path} */
     void device_stats(int device, uint64_t out[16]) const;
+    void device_table_histogram(int device, uint64_t out[32]) const;
 
     /* Device-pointer entry points: queries and outputs already live in the HBM of `device`;
        the launch is asynchronous on `stream` (a hipStream_t, may be null = default stream).

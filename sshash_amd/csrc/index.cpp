@@ -883,6 +883,47 @@ void load_index(host_index& idx, std::string const& filename) {
     fclose(f);
 }
 
+void bucket_statistics(host_index const& idx, uint64_t* out) {
+    for (uint32_t i = 0; i < BUCKET_STATS_WORDS; ++i) out[i] = 0;
+    const uint64_t n = idx.control_codewords.size;
+    std::vector<uint64_t> heavy_begins;
+    uint64_t singletons = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t code = idx.control_codewords.get(i);
+        if ((code & 1) == 0) {
+            ++singletons;
+        } else if ((code & 3) == 1) {
+            const uint32_t size = uint32_t((code >> 2) & (MAX_BUCKET_SMALL - 1)) + 2;
+            ++out[2];
+            out[3] += size;
+            if (size <= 16) ++out[16 + size - 1];
+            out[7] = std::max<uint64_t>(out[7], size);
+        } else {
+            heavy_begins.push_back(code >> 5);
+        }
+    }
+    out[0] = n;
+    out[16] = singletons;
+    if (singletons) out[7] = std::max<uint64_t>(out[7], 1);
+    std::sort(heavy_begins.begin(), heavy_begins.end());
+    out[4] = heavy_begins.size();
+    out[5] = idx.heavy_load_buckets.size;
+    for (size_t h = 0; h < heavy_begins.size(); ++h) {
+        const uint64_t end = h + 1 < heavy_begins.size() ? heavy_begins[h + 1] : idx.heavy_load_buckets.size;
+        out[7] = std::max<uint64_t>(out[7], end - heavy_begins[h]);
+    }
+    out[1] = singletons + out[3] + out[5];
+    for (uint32_t p = 0; p < idx.skew_num_partitions && p < 8; ++p) {
+        out[8 + p] = idx.skew_mphfs[p].num_keys;
+        out[6] += idx.skew_mphfs[p].num_keys;
+    }
+    out[32] = idx.num_kmers;
+    out[33] = idx.num_strings;
+    out[34] = idx.num_bases;
+    out[35] = idx.skew_num_partitions;
+    for (uint64_t s = 0; s < idx.num_strings; ++s) out[36] = std::max(out[36], idx.endpoints[s + 1] - idx.endpoints[s]);
+}
+
 std::string index_summary(host_index const& idx) {
     std::ostringstream os;
     const double n = double(idx.num_kmers ? idx.num_kmers : 1);

@@ -113,4 +113,13 @@ uint64_t weight_of(host_index const& idx, uint64_t kmer_id);
 
 std::string index_summary(host_index const& idx);
 
+/* The bucket statistics the reference's builder prints (src/builder/build_sparse_and_skew_index.cpp:64-99,
+   include/buckets_statistics.hpp), recomputed from the finished index (so they are available for a loaded file too).
+   out[0] minimizers, [1] minimizer positions (= super-k-mers with distinct positions), [2] buckets of 2..64 positions,
+   [3] positions in them, [4] buckets in the skew index (> 64 positions), [5] positions in them, [6] k-mers in the skew index,
+   [7] largest bucket, [8..15] k-mers per skew partition, [16..31] buckets of exactly 1..16 positions, [32] k-mers,
+   [33] strings, [34] bases, [35] skew partitions, [36] longest string, [37..63] zero. */
+constexpr uint32_t BUCKET_STATS_WORDS = 64;
+void bucket_statistics(host_index const& idx, uint64_t* out);
+
 }  // namespace sshash_amd

@@ -680,8 +680,6 @@ __device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& 
    staging area: quad q's line lands contiguously at region p + 64 q, which transposes "lane = piece" into "lane =
    owner of the whole line". 4 W rounds fetch the buckets of all 64 lanes. The memory pipeline sees one request (and
    one address translation) per line instead of one per 16-byte load (device_layout.hpp (5)). */
-typedef __attribute__((address_space(3))) void* sk_lds_ptr;
-typedef const __attribute__((address_space(1))) void* sk_global_ptr;
 
 template <int OWNER>
 __device__ __forceinline__ uint32_t quad_broadcast(uint32_t v) {
@@ -692,25 +690,13 @@ __device__ __forceinline__ uint32_t quad_broadcast(uint32_t v) {
    are executed by ALL lanes, unconditionally: a quad whose owner of the round has no use for a bucket fetches bucket 0
    (one line, shared by all such quads: an L2 hit) into a place nobody reads.
 
-   Two ways to move the pieces: through registers (global_load_dwordx4 + ds_write_b128; the default) or straight into
-   LDS with global_load_lds_dwordx4 (SSHASH_STAGE_WITH_LDS_DMA=1), which needs no staging VGPRs and no ds_write. The
-   LDS-DMA path measured the same speed (the kernel is bound by DRAM line fetches, not by issue), and some kernel
-   instances built on it -- which ones changed with unrelated edits -- reported 0.1-0.4 % of the indexed k-mers absent,
-   differently from launch to launch, although micro-benchmarks of the very same instruction sequence (tools/debug/:
-   glds_check, m0_check, vcc_check; 10^9 checked lines) never returned a wrong byte once the wait for the DMA was
-   spelled out. hipcc 7.2 models the builtin as a 16-byte store at the given LDS address (it is a 1 KiB scatter), skips
-   the wait before DS reads it believes unrelated (glds_check: 91 % stale reads) -- the explicit wait below covers that --
-   and presumably takes further liberties of the same origin that were not pinned down. The register path uses nothing
-   the compiler does not fully model; every parity test passes on it, three runs in a row, without any guard. */
+   The pieces move through registers (global_load_dwordx4 + ds_write_b128). Moving them straight into LDS
+   (global_load_lds_dwordx4) measured the same speed and miscompiled under hipcc 7.2 -- the repro and the micro-benchmarks
+   are kept in tools/debug/ (glds_check, m0_check, vcc_check), the code path is gone. */
 typedef uint32_t sk_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 sk_load_piece(char const* p) {
     const sk_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const sk_u32x4*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
-}
-
-template <int P>
-__device__ __forceinline__ void sk_stage_round_dma(char const* __restrict__ line_of_owner_base, uint64_t line_offset, uint32_t sub, uint4* wave_stage) {
-    __builtin_amdgcn_global_load_lds((sk_global_ptr)(line_of_owner_base + line_offset + 16 * sub), (sk_lds_ptr)(wave_stage + P * 64), 16, 0, 0);
 }
 
 /* LINE: which 64-byte line of the bucket (k <= 31: the bucket is one line holding both slots; k <= 63: line 0 = slot 0,
@@ -731,7 +717,6 @@ __device__ __forceinline__ void sk_stage_lines(dict_view const& d, uint32_t buck
     }
     const uint64_t a0 = uint64_t(b0) * (64 * W) + 64 * l0, a1 = uint64_t(b1) * (64 * W) + 64 * l1, a2 = uint64_t(b2) * (64 * W) + 64 * l2,
                    a3 = uint64_t(b3) * (64 * W) + 64 * l3;
-#if !SSHASH_STAGE_WITH_LDS_DMA
     const uint32_t lane = threadIdx.x & 63u;
     /* nontemporal: a bucket line is not read again before a few hundred million others have passed */
     const uint4 p0 = sk_load_piece(slots + a0 + 16 * sub), p1 = sk_load_piece(slots + a1 + 16 * sub),
@@ -745,14 +730,6 @@ __device__ __forceinline__ void sk_stage_lines(dict_view const& d, uint32_t buck
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
-    sk_stage_round_dma<0>(slots, a0, sub, wave_stage);
-    sk_stage_round_dma<1>(slots, a1, sub, wave_stage);
-    sk_stage_round_dma<2>(slots, a2, sub, wave_stage);
-    sk_stage_round_dma<3>(slots, a3, sub, wave_stage);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the lines must have landed before any DS read of the staging area
-    __builtin_amdgcn_wave_barrier();
-#endif
 }
 
 /* One bucket for every lane with need = true: fetch (cooperatively) and examine. Called by all 64 lanes. k <= 31: one

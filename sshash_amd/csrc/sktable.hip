@@ -117,13 +117,30 @@ __device__ __forceinline__ void read_bases(void const* __restrict__ blocks, int6
    under the key. The k-mers of the heavy keys' occurrences are items of their own (keys = sk_kmer_key). */
 constexpr uint8_t SK_ITEM_INLINE = 0, SK_ITEM_MARKER = 1, SK_ITEM_NONE = 2;
 
-/* one lane per run: classify its tuples */
+/* bin of a key with `size` occurrences: 1, 2, 3, 4, 5-8, 9-16, 17-64, 65-1024, > 1024 */
+constexpr uint32_t SK_HIST_BINS = 9;
+__device__ __forceinline__ uint32_t sk_hist_bin(uint32_t size) {
+    return size <= 4 ? size - 1 : size <= 8 ? 4 : size <= 16 ? 5 : size <= 64 ? 6 : size <= 1024 ? 7 : 8;
+}
+
+/* one lane per run: classify its tuples; histogram of the keys by number of occurrences (LDS per workgroup, then one
+   atomic per bin and workgroup) */
 __global__ void __launch_bounds__(256)
 sk_classify_kernel(const uint64_t num_keys, const uint32_t* __restrict__ run_sizes, const uint32_t* __restrict__ run_begins,
-                   uint8_t* __restrict__ flags, unsigned long long* __restrict__ stats) {
+                   uint8_t* __restrict__ flags, unsigned long long* __restrict__ stats, unsigned long long* __restrict__ histogram) {
+    __shared__ unsigned long long local[2 * SK_HIST_BINS];
+    if (threadIdx.x < 2 * SK_HIST_BINS) local[threadIdx.x] = 0;
+    __syncthreads();
     const uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     bool heavy = false;
     uint32_t size = 0;
+    if (r < num_keys) {
+        const uint32_t s = run_sizes[r];
+        atomicAdd(&local[sk_hist_bin(s)], 1ull);
+        atomicAdd(&local[SK_HIST_BINS + sk_hist_bin(s)], (unsigned long long)s);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * SK_HIST_BINS && local[threadIdx.x]) atomicAdd(histogram + threadIdx.x, local[threadIdx.x]);
     if (r < num_keys) {
         size = run_sizes[r];
         heavy = size > SK_INLINE_MAX;
@@ -407,11 +424,11 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
         tmp.release(scratch);
     }
     /* stats: 2 unplaced items, 3 slots used, 4 heavy keys, 5 their occurrences, 6 / 7 cursors of the heavy k-mer passes */
-    unsigned long long* stats = tmp.alloc<unsigned long long>(8);
-    HIP_CHECK(hipMemset(stats, 0, 64));
+    unsigned long long* stats = tmp.alloc<unsigned long long>(8 + 2 * SK_HIST_BINS);
+    HIP_CHECK(hipMemset(stats, 0, 8 * (8 + 2 * SK_HIST_BINS)));
     uint8_t* flags = tmp.alloc<uint8_t>(T);
     HIP_CHECK(hipMemset(flags, SK_ITEM_INLINE, T));
-    hipLaunchKernelGGL(sk_classify_kernel, dim3(uint32_t((K + 255) / 256)), block, 0, 0, K, run_sizes, run_begins, flags, stats);
+    hipLaunchKernelGGL(sk_classify_kernel, dim3(uint32_t((K + 255) / 256)), block, 0, 0, K, run_sizes, run_begins, flags, stats, stats + 8);
     HIP_CHECK(hipGetLastError());
     tmp.release(run_begins);
     tmp.release(run_sizes);
@@ -489,6 +506,13 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     tmp.keep(slots);
     rep.allocations.push_back(slots);
     rep.bytes += num_slots * slot_bytes;
+    {
+        unsigned long long hist[2 * SK_HIST_BINS];
+        HIP_CHECK(hipMemcpy(hist, stats + 8, sizeof(hist), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < 2 * SK_HIST_BINS; ++i) rep.sk_histogram[i] = hist[i];
+        rep.sk_histogram[18] = T;
+        rep.sk_histogram[19] = wanted;
+    }
     rep.sk_keys = K;
     rep.sk_heavy_keys = heavy_keys;
     rep.sk_heavy_kmers = heavy_kmers;

@@ -397,7 +397,8 @@ stream_encode_kernel(const char* __restrict__ bases, const uint64_t* __restrict_
 
 __global__ void __launch_bounds__(256)
 stream_classify_kernel(const uint8_t* __restrict__ flags, const uint64_t total_bases, const result_view out,
-                       const uint64_t* string_id, const int8_t* orientation /* may be out's own arrays */, uint64_t* __restrict__ report) {
+                       const uint64_t* string_id, const int8_t* orientation /* may be out's own arrays */, uint64_t* __restrict__ report,
+                       const bool has_predecessor /* the arrays continue below index 0: a later piece of one call */) {
     /* grid-stride: the six counters are accumulated in registers and reach `report` once per wave -- one hot set of
        atomics per wave of 64 k-mers would serialise at ~90 atomics/us */
     uint64_t c_kmer = 0, c_invalid = 0, c_negative = 0, c_search = 0, c_extension = 0;
@@ -407,7 +408,7 @@ stream_classify_kernel(const uint8_t* __restrict__ flags, const uint64_t total_b
     constexpr uint32_t PLACES = 4;
     const uint64_t stride = uint64_t(gridDim.x) * blockDim.x * PLACES;
     for (uint64_t p0 = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) * PLACES; p0 < total_bases; p0 += stride) {
-        const uint64_t q = p0 ? p0 - 1 : 0;
+        const int64_t q = (p0 || has_predecessor) ? int64_t(p0) - 1 : 0;  // only the call's very first place has no predecessor
         uint8_t f[PLACES + 1];
         uint64_t id[PLACES + 1], sid[PLACES + 1];
         int8_t ori[PLACES + 1];
@@ -468,18 +469,30 @@ void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t c
     dict_view const& d = rep->view;
     const uint32_t W = d.k <= 31 ? 1 : 2;
     const uint64_t chunk = std::min<uint64_t>(total_bases, uint64_t(1) << 27);
-    uint8_t* flags = nullptr;
-    uint64_t* kmers = nullptr;
+    /* stream-ordered temporaries, given back on every exit path (an exception between allocation and release must not
+       leak them: ADVICE r2) */
+    struct temporaries {
+        hipStream_t s;
+        std::vector<void*> owned;
+        void* get(uint64_t bytes) {
+            void* p = nullptr;
+            HIP_CHECK(hipMallocAsync(&p, std::max<uint64_t>(bytes, 8), s));
+            owned.push_back(p);
+            return p;
+        }
+        ~temporaries() {
+            for (void* p : owned) (void)hipFreeAsync(p, s);
+        }
+    } tmp{s, {}};
     uint64_t* sid = d_out.string_id;
     int8_t* ori = d_out.kmer_orientation;
     uint64_t* ids = d_out.kmer_id;  // null: counters only (streaming_query_host over reads too long for one lane each)
-    if (!ids) HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&ids), total_bases * sizeof(uint64_t), s));
-    HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&flags), total_bases, s));
-    HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&kmers), chunk * W * sizeof(uint64_t), s));
-    uint64_t* tile_read = nullptr;
-    HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tile_read), ((chunk + 255) / 256) * sizeof(uint64_t), s));
-    if (!sid) HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&sid), total_bases * sizeof(uint64_t), s));
-    if (!ori) HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&ori), total_bases, s));
+    if (!ids) ids = static_cast<uint64_t*>(tmp.get(total_bases * sizeof(uint64_t)));
+    uint8_t* flags = static_cast<uint8_t*>(tmp.get(total_bases));
+    uint64_t* kmers = static_cast<uint64_t*>(tmp.get(chunk * W * sizeof(uint64_t)));
+    uint64_t* tile_read = static_cast<uint64_t*>(tmp.get(((chunk + 255) / 256) * sizeof(uint64_t)));
+    if (!sid) sid = static_cast<uint64_t*>(tmp.get(total_bases * sizeof(uint64_t)));
+    if (!ori) ori = static_cast<int8_t*>(tmp.get(total_bases));
     result_view all = d_out;
     all.kmer_id = ids;
     all.string_id = sid;
@@ -512,15 +525,9 @@ void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t c
         if (part.string_end) part.string_end += first;
         if (part.kmer_orientation) part.kmer_orientation += first;
         hipLaunchKernelGGL(stream_classify_kernel, dim3(uint32_t(std::min<uint64_t>((count + 1023) / 1024, 2048))), dim3(256), 0, s, flags + first, count, part,
-                           sid + first, ori + first, d_report);
+                           sid + first, ori + first, d_report, first != 0);
         HIP_CHECK(hipGetLastError());
     }
-    if (!d_out.kmer_id) HIP_CHECK(hipFreeAsync(ids, s));
-    if (!d_out.kmer_orientation) HIP_CHECK(hipFreeAsync(ori, s));
-    if (!d_out.string_id) HIP_CHECK(hipFreeAsync(sid, s));
-    HIP_CHECK(hipFreeAsync(kmers, s));
-    HIP_CHECK(hipFreeAsync(tile_read, s));
-    HIP_CHECK(hipFreeAsync(flags, s));
 }
 
 /* Host buffers: pieces of whole reads (at most ~64 MiB of bases each) go through one stream: H2D, the device pipeline
@@ -582,8 +589,18 @@ streaming_report engine::streaming_lookup_host(char const* bases, uint64_t const
         for (uint64_t i = first; i <= last; ++i) rel[i - first] = read_offsets[i] - b0;
         HIP_CHECK(hipMemcpyAsync(d_offsets, rel.data(), (last - first + 1) * 8, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(d_bases, bases + b0, nb, hipMemcpyHostToDevice, s));
-        /* places without a k-mer keep what the caller's arrays hold: seed the device arrays with it */
-        HIP_CHECK(hipMemcpyAsync(d_out.kmer_id, h_out.kmer_id + b0, nb * 8, hipMemcpyHostToDevice, s));
+        /* places without a k-mer keep what the caller's arrays hold (sshash_amd.h: "left untouched"): EVERY requested
+           device array is seeded with the caller's (only kmer_id was, the others came back as stale device memory) */
+        auto seed = [&](auto* h, auto* dptr, uint64_t width) {
+            if (h) HIP_CHECK(hipMemcpyAsync(dptr, h + b0, nb * width, hipMemcpyHostToDevice, s));
+        };
+        seed(h_out.kmer_id, d_out.kmer_id, 8);
+        seed(h_out.kmer_id_in_string, d_out.kmer_id_in_string, 8);
+        seed(h_out.kmer_offset, d_out.kmer_offset, 8);
+        seed(h_out.string_id, d_out.string_id, 8);
+        seed(h_out.string_begin, d_out.string_begin, 8);
+        seed(h_out.string_end, d_out.string_end, 8);
+        seed(h_out.kmer_orientation, d_out.kmer_orientation, 1);
         streaming_lookup_device(device, d_bases, d_offsets, last - first, nb, d_out, d_report, s);
         HIP_CHECK(hipMemcpyAsync(h_out.kmer_id + b0, d_out.kmer_id, nb * 8, hipMemcpyDeviceToHost, s));
         auto back = [&](auto* h, auto* dptr, uint64_t width) {

@@ -81,3 +81,44 @@ def test_synthetic_spss_has_no_duplicate_kmers_and_all_bucket_classes():
     # positives really are k-mers of the set (either strand)
     qc = np.minimum(q, _revcomp_u64(q, k))
     assert 4900 <= int(np.isin(qc, canon).sum()) <= 5100
+
+
+def test_repeat_family_spss_is_a_set_and_reports_the_builders_statistics():
+    """sshash_amd/repeats.py: diverged families + cores, de-duplicated -- every canonical k-mer once -- and
+    sshash_bucket_stats agrees with a histogram computed here from the strings alone."""
+    import sshash_amd
+    from oracle.ground_truth import _revcomp_u64
+    from sshash_amd.repeats import make_repeat_spss, statistics_vs_target
+
+    k, m = 31, 21
+    classes = [{"copies": 2, "length": 300, "divergence": 0.02, "families": 300},
+               {"copies": 40, "length": 150, "divergence": 0.1, "families": 10},
+               {"copies": 300, "length": 120, "core": 23, "families": 3.5}]
+    words, ends = make_repeat_spss(1_500_000, k=k, classes=classes, reference_bases=1_500_000, seed=11, device="cpu")
+    w2, e2 = make_repeat_spss(1_500_000, k=k, classes=classes, reference_bases=1_500_000, seed=11, device="cpu")
+    assert (words == w2).all() and (ends == e2).all()  # deterministic
+    codes = ((words[:, None] >> (np.arange(32, dtype=np.uint64) * np.uint64(2))) & np.uint64(3)).reshape(-1)[: int(ends[-1])]
+    n = codes.size - k + 1
+    km = np.zeros(n, dtype=np.uint64)
+    for j in range(k):
+        km |= codes[j:j + n] << np.uint64(2 * j)
+    inner = ends[1:-1].astype(np.int64)
+    crossing = np.zeros(codes.size + 2, dtype=np.int32)
+    np.add.at(crossing, np.maximum(inner - k + 1, 0), 1)
+    np.add.at(crossing, inner, -1)
+    km = km[np.cumsum(crossing)[:n] == 0]
+    canon = np.minimum(km, _revcomp_u64(km, k))
+    assert np.unique(canon).size == km.size  # a spectrum-preserving string set
+    assert int((np.diff(ends.astype(np.int64)) < k).sum()) == 0
+    d = sshash_amd.Dictionary.build_from_packed(words, ends, k=k, m=m, num_threads=4)
+    s = d.bucket_stats()
+    assert s["num_kmers"] == km.size and s["num_strings"] == ends.size - 1 and s["num_bases"] == int(ends[-1])
+    assert s["num_minimizers"] == d.num_minimizers()
+    assert s["num_minimizers"] == s["buckets_with_n_positions"][0] + s["num_buckets_larger_than_1_not_in_skew_index"] + s["num_buckets_in_skew_index"]
+    assert s["num_buckets_in_skew_index"] >= 1 and s["max_bucket_size"] > 64  # the cores of 300 copies
+    assert s["buckets_with_n_positions"][1] > 100  # the pairs' shared m-mers around their substitutions
+    assert s["num_minimizer_positions"] == s["buckets_with_n_positions"][0] + s["num_minimizer_positions_of_buckets_larger_than_1"] + \
+        s["num_minimizer_positions_of_buckets_in_skew_index"]
+    assert sum(s["num_kmers_in_skew_partition"]) == s["num_kmers_in_skew_index"]
+    cmp = statistics_vs_target(s, "human_k31")  # the shipped recipe's targets load and scale
+    assert cmp["num_kmers"]["achieved"] == km.size and 0 < cmp["scale"] < 1e-2
