@@ -144,7 +144,7 @@ def make_standin(args):
     return out
 
 
-def measure_other_paths(args, index_path, device, dq, ids_of_table_path, W, bytes_per_lookup):
+def measure_other_paths(args, index_path, device, d, dq, W, bytes_per_lookup):
     """Side measurement, OUTSIDE the timed region: the same batch (its first 10^8 queries) through the replica layouts that
     have no super-k-mer table -- what a minimizer shard, a dictionary too large for a table, or SSHASH_AMD_SKTABLE=0 run:
       directory   minimizer -> one-atom directory -> bucket probe (lookup_device.hpp fast_probe_*)
@@ -157,8 +157,10 @@ def measure_other_paths(args, index_path, device, dq, ids_of_table_path, W, byte
     m = min(dq.numel() // W, 100_000_000)
     out = torch.empty(m, dtype=torch.int64, device=dq.device)
     stream = torch.cuda.current_stream()
+    ids_of_table_path = torch.empty(m, dtype=torch.int64, device=dq.device)
+    d.lookup_device(device, dq.data_ptr(), m, ids_of_table_path.data_ptr(), check_reverse_complement=True, stream=stream.cuda_stream)
     res = {}
-    for name, env in (("directory", {"SSHASH_AMD_SKTABLE": "0"}), ("mphf", {"SSHASH_AMD_SKTABLE": "0", "SSHASH_AMD_DIRECTORY": "0"})):
+    for name, env in (("directory", {"SSHASH_AMD_SKTABLE": "0", "SSHASH_AMD_DIRECTORY": "1"}), ("mphf", {"SSHASH_AMD_SKTABLE": "0", "SSHASH_AMD_DIRECTORY": "0"})):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -185,7 +187,7 @@ def measure_other_paths(args, index_path, device, dq, ids_of_table_path, W, byte
         e1.record(stream)
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
-        if not bool((out == ids_of_table_path[:m]).all().item()):
+        if not bool((out == ids_of_table_path).all().item()):
             raise SystemExit(f"PARITY FAILURE: the {name} path and the table path disagree")
         gbs = bytes_per_lookup * m / (ms * 1e-3) / 1e9
         res[name] = {"lookups_per_s": round(m / ms * 1e3, 1), "ms": round(ms, 3), "queries": m, "ids_equal_table_path": True,
@@ -454,7 +456,7 @@ def main():
                 del q2
         other_paths = None
         if world == 1 and sharded is None and not args.no_other_paths and stats["sk_slots"]:
-            other_paths = measure_other_paths(args, index_path, local_rank, dq, out, W, bytes_per_lookup)
+            other_paths = measure_other_paths(args, index_path, local_rank, d, dq, W, bytes_per_lookup)
         index_statistics = table_histogram = None
         if args.k <= 31:
             from sshash_amd.repeats import statistics_vs_target

@@ -34,6 +34,9 @@
 //      answered from the codeword's sector. Equal fingerprints still go through the exact check, so
 //      results are unchanged; only the number of sector fetches per miss drops (3.3 -> 2.1).
 //      The fingerprints are derived on the GPU at upload time from the strings themselves.
+//      A replica that holds the super-k-mer table (5) keeps the codewords bit-packed as the host index has them
+//      (dict_view::cw_packed) and builds no directory (4): with the table only the ~0.05 % deferred queries (and the
+//      `minimizer_found` byte of a miss) ever come this way, and 3.2 + 8.6 GB of a 50 GB human-scale replica served them.
 //
 //  (4) a *minimizer directory*: the minimizer -> codeword map once more, as a fingerprinted bucket
 //      table whose buckets are exactly one 32-byte DRAM atom: 4 x u64 entries,
@@ -356,8 +359,10 @@ struct dict_view {
     uint64_t const* endpoints;  // num_strings + 1
 
     mphf_view minimizers;
-    uint64_t const* codewords;  // one u64 per minimizer id: code | fingerprint << cw_width
+    uint64_t const* codewords;  // one u64 per minimizer id: code | fingerprint << cw_width -- or, cw_packed, the reference's
+                                // bit-packed control codewords as they are (no fingerprint: the strings settle a foreign minimizer)
     uint32_t cw_width;
+    uint32_t cw_packed;
     uint32_t off_width;  // width of the entries of mid_load / heavy_load
     uint32_t const* begin_buckets_of_size;  // 65 entries
     uint64_t const* mid_load;

@@ -254,7 +254,23 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
     v.mid_load = rep->put(idx.mid_load_buckets.words);
     v.heavy_load = rep->put(idx.heavy_load_buckets.words);
     v.heavy_size = idx.heavy_load_buckets.size;
-    {
+    /* the super-k-mer table first (it needs the atoms and the endpoints only): what else is built depends on it */
+    v.codewords = nullptr;
+    v.cw_packed = 0;
+    v.directory.buckets = nullptr;
+    v.directory.num_buckets = 0;
+    v.directory.enabled = 0;
+    build_sk_table(*rep, idx, table_shards, table_shard_id);
+    /* With the table resident only the deferred queries (ties, items that found no slot: ~0.05 %) and the
+       `minimizer_found` byte of a miss come through the minimizer structures: they keep the host index's form -- bit-packed
+       control codewords, no directory (device_layout.hpp (3), (4)); 11.8 GB of a human-scale replica. SSHASH_AMD_DIRECTORY=1
+       builds the directory (and the widened codewords) all the same, =0 never builds it. */
+    const char* dir_env = std::getenv("SSHASH_AMD_DIRECTORY");
+    const bool lean = v.sk.enabled && !(dir_env && dir_env[0] == '1');
+    if (lean) {
+        v.codewords = rep->put(idx.control_codewords.words);
+        v.cw_packed = 1;
+    } else {
         const uint64_t n = idx.control_codewords.size;
         uint64_t* packed = nullptr;
         uint64_t* wide = nullptr;
@@ -274,12 +290,8 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
         v.codewords = wide;
     }
     /* minimizer directory (device_layout.hpp (4)) */
-    v.directory.buckets = nullptr;
-    v.directory.num_buckets = 0;
-    v.directory.enabled = 0;
-    {
-        const char* env = std::getenv("SSHASH_AMD_DIRECTORY");
-        const bool want = !(env && env[0] == '0');
+    if (!lean) {
+        const bool want = !(dir_env && dir_env[0] == '0');
         const uint64_t n = idx.control_codewords.size;
         const uint64_t nb = uint64_t(double(n) / DIR_LOAD) + 1;
         if (want && n && nb < (uint64_t(1) << 32) && v.cw_width <= DIR_CODE_BITS) {
@@ -340,7 +352,6 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
         v.weight_starts = rep->put(idx.weight_starts);
         v.weight_values = rep->put(idx.weight_values);
     }
-    build_sk_table(*rep, idx, table_shards, table_shard_id);
     {
         /* the stream-ordered scratch of the batched calls (hipMallocAsync: streaming lookup, sharded lookup, neighbours)
            comes out of the device's default memory pool; by default the pool hands everything back to the driver at the
@@ -624,6 +635,16 @@ static uint32_t resume_capacity_divisor() {
     return 2;
 }
 
+/* tail passes on an auxiliary stream (launch()); SSHASH_AMD_OVERLAP=0: everything on the caller's stream, one piece after the other */
+static bool overlap_tail_passes() {
+    static const bool on = [] {
+        const char* e = std::getenv("SSHASH_AMD_OVERLAP");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+constexpr uint64_t OVERLAP_PIECES = 4, OVERLAP_MIN_QUERIES = uint64_t(1) << 22;
+
 template <int W, bool CANON, int MODE, bool ASCII>
 static void launch(device_replica const* rep, void const* q, uint64_t n, bool check_rc,
                    result_view const& out, uint8_t* member, hipStream_t stream, uint8_t const* lane_valid) {
@@ -638,22 +659,36 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
         const bool wants_flag = MODE == int(out_mode::full) && out.minimizer_found;
         if ((d.directory.enabled || d.sk.enabled) && !(wants_flag && !d.sk.enabled)) {
             /* multi-pass: at most 2^27 queries per launch sequence (queue entries are 32-bit; the scratch
-               queues stay below 1.3 GiB (2.1 for 128-bit k-mers)) */
+               queues stay below 1.3 GiB (2.1 for 128-bit k-mers) per set). A batch is cut into at least OVERLAP_PIECES pieces
+               once it is large enough for that to pay, because the tail passes (resume, deferred: few, dependent, latency-bound
+               reads) of piece i run on an auxiliary stream while the caller's stream already runs the first pass of piece
+               i + 1 -- two sets of queues, used in turn; events order first(i) -> tail(i) -> first(i + 2). The caller's stream
+               waits for the last tail before the call returns control of it. */
             const uint64_t piece_max = launch_piece_queries();
-            const uint64_t pieces = (n + piece_max - 1) / piece_max;
+            uint64_t pieces = (n + piece_max - 1) / piece_max;
+            if (overlap_tail_passes() && n >= OVERLAP_MIN_QUERIES) pieces = std::max<uint64_t>(pieces, OVERLAP_PIECES);
             const uint64_t piece = ((n + pieces - 1) / pieces + block - 1) / block * block;  // equal pieces, whole workgroups
+            pieces = (n + piece - 1) / piece;
+            const bool overlap = overlap_tail_passes() && pieces > 1;
             const size_t qbytes = size_t(W) * 8, kbytes = d.k;
-            for (uint64_t at = 0; at < n; at += piece) {
+            const uint32_t nblocks_max = uint32_t((std::min(piece, n) + block - 1) / block);
+            pass_queues shape{};
+            shape.defer_capacity = ((nblocks_max + DEFER_SHARDS - 1) / DEFER_SHARDS) * block;
+            shape.resume_capacity = d.sk.enabled ? (shape.defer_capacity + 1) / resume_capacity_divisor() : 0;
+            const uint64_t defer_places = uint64_t(DEFER_SHARDS) * shape.defer_capacity, resume_places = uint64_t(DEFER_SHARDS) * shape.resume_capacity;
+            const size_t set_bytes =
+                (2 * DEFER_SHARDS * sizeof(uint32_t) + (defer_places + resume_places) * sizeof(uint32_t) + resume_places * W * sizeof(uint64_t) + 255) & ~size_t(255);
+            std::lock_guard<std::mutex> enqueue(rep->launch_mutex);
+            device_replica::stream_scratch& sc = rep->scratch_for(stream, (overlap ? 2 : 1) * set_bytes, overlap);
+            uint64_t index = 0;
+            for (uint64_t at = 0; at < n; at += piece, ++index) {
                 const uint64_t m = std::min(piece, n - at);
                 const uint32_t nblocks = uint32_t((m + block - 1) / block);
-                pass_queues pq{};
+                const uint32_t set = overlap ? uint32_t(index & 1) : 0u;
+                pass_queues pq = shape;
                 pq.flag_misses = wants_flag ? 1u : 0u;
-                pq.defer_capacity = ((nblocks + DEFER_SHARDS - 1) / DEFER_SHARDS) * block;
-                pq.resume_capacity = d.sk.enabled ? (pq.defer_capacity + 1) / resume_capacity_divisor() : 0;
-                const uint64_t defer_places = uint64_t(DEFER_SHARDS) * pq.defer_capacity, resume_places = uint64_t(DEFER_SHARDS) * pq.resume_capacity;
-                std::lock_guard<std::mutex> enqueue(rep->launch_mutex);
-                char* scratch = static_cast<char*>(rep->scratch_for(
-                    stream, 2 * DEFER_SHARDS * sizeof(uint32_t) + (defer_places + resume_places) * sizeof(uint32_t) + resume_places * W * sizeof(uint64_t) + 64));
+                char* scratch = static_cast<char*>(sc.block) + set * set_bytes;
+                if (overlap && index >= 2) HIP_CHECK(hipStreamWaitEvent(stream, sc.tail_done[set], 0));  // the set's queues are free again
                 HIP_CHECK(hipMemsetAsync(scratch, 0, 2 * DEFER_SHARDS * sizeof(uint32_t), stream));
                 pq.defer_counts = reinterpret_cast<uint32_t*>(scratch);
                 pq.resume_counts = pq.defer_counts + DEFER_SHARDS;
@@ -663,19 +698,28 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 const void* qa = static_cast<const char*>(q) + at * (ASCII ? kbytes : qbytes);
                 const result_view ids = advance(out, at);
                 uint8_t* mem = member ? member + at : nullptr;
+                hipStream_t tail = stream;
                 if (d.sk.enabled) {
                     hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII, true>), dim3(nblocks), dim3(block), 0, stream, d, qa,
                                        m, check_rc, ids, mem, pq, lane_valid ? lane_valid + at : nullptr);
-                    hipLaunchKernelGGL((resume_lookup_kernel<W, CANON, MODE>), dim3(DEFER_SHARDS * RESUME_PARTS), dim3(block), 0, stream, d,
-                                       check_rc, ids, mem, pq);
                 } else {
                     hipLaunchKernelGGL((fast_lookup_kernel<W, CANON, MODE, ASCII, false>), dim3(nblocks), dim3(block), 0, stream, d, qa,
                                        m, check_rc, ids, mem, pq, lane_valid ? lane_valid + at : nullptr);
                 }
-                hipLaunchKernelGGL((deferred_lookup_kernel<W, CANON, MODE, ASCII>), dim3(DEFER_SHARDS * DEFER_BLOCKS_PER_SHARD), dim3(block), 0, stream, d,
+                if (overlap) {
+                    HIP_CHECK(hipEventRecord(sc.first_done[set], stream));
+                    HIP_CHECK(hipStreamWaitEvent(sc.aux, sc.first_done[set], 0));
+                    tail = sc.aux;
+                }
+                if (d.sk.enabled)
+                    hipLaunchKernelGGL((resume_lookup_kernel<W, CANON, MODE>), dim3(DEFER_SHARDS * RESUME_PARTS), dim3(block), 0, tail, d,
+                                       check_rc, ids, mem, pq);
+                hipLaunchKernelGGL((deferred_lookup_kernel<W, CANON, MODE, ASCII>), dim3(DEFER_SHARDS * DEFER_BLOCKS_PER_SHARD), dim3(block), 0, tail, d,
                                    skew, qa, check_rc, ids, mem, pq);
+                if (overlap) HIP_CHECK(hipEventRecord(sc.tail_done[set], sc.aux));
                 HIP_CHECK(hipGetLastError());
             }
+            if (overlap) HIP_CHECK(hipStreamWaitEvent(stream, sc.tail_done[(index - 1) & 1], 0));  // (aux is in order: the last tail is the last of all)
             return;
         }
     }

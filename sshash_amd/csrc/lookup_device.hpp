@@ -145,6 +145,10 @@ __device__ __forceinline__ bucket_t resolve_bucket_mphf(dict_view const& d, skew
                                                         uint64_t minimizer, kmer_w<W> const& skew_key) {
     bucket_t b = empty_bucket();
     const uint64_t id = mphf_eval(d.minimizers, city128_u64(minimizer, d.minimizers.seed));
+    if (d.cw_packed) {  // (uniform) no fingerprint: the m-mer comparison at the bucket's first offset decides, as in the reference
+        decode_codeword<W>(d, skew, packed_get(d.codewords, id, d.cw_width), skew_key, b);
+        return b;
+    }
     const uint64_t entry = d.codewords[id];
     const uint64_t code = entry & low_mask(d.cw_width);
     if ((entry >> d.cw_width) != minimizer_fingerprint(minimizer, d.m, d.canonical != 0, d.cw_width)) {

@@ -64,13 +64,31 @@ struct device_replica {
         void* block = nullptr;
         size_t bytes = 0;
         uint64_t last_use = 0;
+        /* the tail passes (resume, deferred) of one launch piece run on `aux` while the caller's stream already runs the
+           first pass of the next piece (engine.hip: launch): one auxiliary stream and two event pairs per caller stream */
+        hipStream_t aux = nullptr;
+        hipEvent_t first_done[2] = {nullptr, nullptr};
+        hipEvent_t tail_done[2] = {nullptr, nullptr};
+        void release() {
+            if (aux) (void)hipStreamSynchronize(aux);
+            for (int i = 0; i < 2; ++i) {
+                if (first_done[i]) (void)hipEventDestroy(first_done[i]);
+                if (tail_done[i]) (void)hipEventDestroy(tail_done[i]);
+                first_done[i] = tail_done[i] = nullptr;
+            }
+            if (aux) (void)hipStreamDestroy(aux);
+            aux = nullptr;
+            if (block) (void)hipFree(block);
+            block = nullptr;
+            bytes = 0;
+        }
     };
     mutable std::unordered_map<void*, stream_scratch> scratch;
     mutable uint64_t scratch_clock = 0;
     static constexpr size_t SCRATCH_STREAMS_MAX = 16;  // an application that makes a stream per request must not keep a
                                                        // gigabyte of queues per stream it ever used: the
                                                        // least recently used stream's block goes first
-    void* scratch_for(void* stream, size_t bytes) const {
+    stream_scratch& scratch_for(void* stream, size_t bytes, bool with_aux_stream) const {
         std::lock_guard<std::mutex> lock(scratch_mutex);
         auto it = scratch.find(stream);
         if (it == scratch.end()) {
@@ -78,7 +96,7 @@ struct device_replica {
                 auto oldest = scratch.begin();
                 for (auto jt = scratch.begin(); jt != scratch.end(); ++jt)
                     if (jt->second.last_use < oldest->second.last_use) oldest = jt;
-                if (oldest->second.block) HIP_CHECK(hipFree(oldest->second.block));  // (synchronises: nothing in flight still uses it)
+                oldest->second.release();  // (synchronises: nothing in flight still uses it)
                 scratch.erase(oldest);
             }
             it = scratch.emplace(stream, stream_scratch{}).first;
@@ -86,6 +104,7 @@ struct device_replica {
         stream_scratch& slot = it->second;
         slot.last_use = ++scratch_clock;
         if (slot.bytes < bytes) {
+            if (slot.aux) HIP_CHECK(hipStreamSynchronize(slot.aux));  // a tail pass of an earlier call may still read the old block
             if (slot.block) HIP_CHECK(hipFree(slot.block));
             slot.block = nullptr;
             slot.bytes = 0;
@@ -93,7 +112,14 @@ struct device_replica {
             HIP_CHECK(hipMalloc(&slot.block, want));
             slot.bytes = want;
         }
-        return slot.block;
+        if (with_aux_stream && !slot.aux) {
+            HIP_CHECK(hipStreamCreateWithFlags(&slot.aux, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                HIP_CHECK(hipEventCreateWithFlags(&slot.first_done[i], hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&slot.tail_done[i], hipEventDisableTiming));
+            }
+        }
+        return slot;
     }
 
     /* pooled lanes of the host-buffer path */
@@ -128,8 +154,7 @@ struct device_replica {
         if (hipGetDevice(&prev) != hipSuccess) return;
         (void)hipSetDevice(device);
         for (void* p : allocations) (void)hipFree(p);
-        for (auto& kv : scratch)
-            if (kv.second.block) (void)hipFree(kv.second.block);
+        for (auto& kv : scratch) kv.second.release();
         for (host_lane* lane : idle_lanes) {
             if (lane->pinned) (void)hipHostFree(lane->pinned);
             if (lane->device) (void)hipFree(lane->device);

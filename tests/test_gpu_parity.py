@@ -265,12 +265,14 @@ def test_batch_larger_than_one_launch_piece(case_se_regular):
     assert int((got == np.uint64(0xFFFFFFFFFFFFFFFD)).sum()) == 0  # nothing left unwritten
 
 
-@pytest.mark.parametrize("disabled", [("SSHASH_AMD_DIRECTORY", "SSHASH_AMD_SKTABLE"), ("SSHASH_AMD_SKTABLE",), ("SSHASH_AMD_DIRECTORY",)],
-                         ids=["mphf_only", "directory_only", "sktable_over_mphf"])
-def test_accelerators_disabled(tmp_path, disabled):
+@pytest.mark.parametrize("settings", [{"SSHASH_AMD_DIRECTORY": "0", "SSHASH_AMD_SKTABLE": "0"}, {"SSHASH_AMD_SKTABLE": "0"}, {},
+                                      {"SSHASH_AMD_DIRECTORY": "1"}],
+                         ids=["mphf_only", "directory_only", "sktable_lean", "sktable_over_directory"])
+def test_accelerators_disabled(tmp_path, settings):
     """The lookup structures are layered (device_layout.hpp (3)-(5)): with the super-k-mer table and/or
     the minimizer directory switched off (also what an over-wide dictionary gets) the remaining path must
-    give the same ids / membership as the oracle."""
+    give the same ids / membership / full results as the oracle. sktable_lean is the default replica: the table over
+    bit-packed codewords, no directory; sktable_over_directory forces the round-2 layout."""
     import os
     import subprocess
     import sys
@@ -291,20 +293,27 @@ def test_accelerators_disabled(tmp_path, disabled):
                 case = c.Case("layers%d" % seed, c.skewed_sequences(31, 11, seed=seed), 31, 11, canonical, tmp)
                 d = case.dict.to_device(0)
                 stats = d.device_stats()
-                assert (stats["directory_sectors"] == 0) == (os.environ.get("SSHASH_AMD_DIRECTORY") == "0"), stats
-                assert (stats["sk_slots"] == 0) == (os.environ.get("SSHASH_AMD_SKTABLE") == "0"), stats
+                table = os.environ.get("SSHASH_AMD_SKTABLE") != "0"
+                want_directory = os.environ.get("SSHASH_AMD_DIRECTORY") == "1" or (not table and os.environ.get("SSHASH_AMD_DIRECTORY") != "0")
+                assert (stats["directory_sectors"] != 0) == want_directory, stats
+                assert (stats["sk_slots"] != 0) == table, stats
                 q = case.queries(4000, 4000, seed=1)
                 want = case.oracle.lookup_ids(q)
                 assert (d.lookup(q).kmer_id == want).all()
                 assert (d.is_member(q) == (want != np.uint64(0xFFFFFFFFFFFFFFFF))).all()
+                full, ora = d.lookup(q, full=True), case.oracle.lookup_packed(q, True)
+                for f in ("kmer_id", "kmer_id_in_string", "kmer_offset", "string_id", "string_begin", "string_end", "minimizer_found"):
+                    assert (getattr(full, f) == ora[f]).all(), f
+                assert (full.kmer_orientation.astype(np.int64) == ora["kmer_orientation"]).all()
                 n = case.gt.num_kmers
                 allq = case.gt.kmers(np.arange(n))
                 assert (d.lookup(allq).kmer_id == np.arange(n, dtype=np.uint64)).all()
         print("LAYERS OK")
         """))
     env = dict(os.environ)
-    for name in disabled:
-        env[name] = "0"
+    env.pop("SSHASH_AMD_DIRECTORY", None)
+    env.pop("SSHASH_AMD_SKTABLE", None)
+    env.update(settings)
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "LAYERS OK" in p.stdout, p.stdout + p.stderr
 

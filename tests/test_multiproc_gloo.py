@@ -25,7 +25,8 @@ WORKER = textwrap.dedent(
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(backend="gloo")
-    args = argparse.Namespace(bases=300_000, k=31, m=15, canonical=False, seed=77, cache_dir=sys.argv[2], verbose=False)
+    args = argparse.Namespace(bases=300_000, k=31, m=15, canonical=False, seed=77, cache_dir=sys.argv[2], verbose=False, recipe="human_k31",
+                              repeat_scale=1.0)
     d, path = bench.get_index(args, rank, world, dist.barrier)
     # every rank sees the same dictionary
     sig = torch.tensor([d.num_kmers(), d.num_strings(), int(d.access_packed(np.arange(0, d.num_kmers(), 101)).sum() % (1 << 62))], dtype=torch.int64)
