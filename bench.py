@@ -136,7 +136,7 @@ def make_standin(args):
     background = r["background"]
     if args.repeat_scale != 1.0:
         background = None  # the background fills whatever the families leave of --bases
-    mean_len = max(b["mean_len"] for b in r["background"])
+    mean_len = max([b["mean_len"] for b in r["background"]] + [400.0])
     out = make_repeat_spss(args.bases, k=args.k, classes=classes, seed=args.seed, reference_bases=float(r["reference_bases"]),
                            background=background, mean_len=mean_len)
     if torch.cuda.is_available():

@@ -406,6 +406,7 @@ struct pass_queues {
     uint32_t* defer_index;
     uint32_t* resume_index;
     uint64_t* resume_kmers;
+    uint64_t* resume_meta;     // replicas without the table: scan_meta() of the entry (the bucket-scan pass reads it)
     uint32_t defer_capacity;   // places per shard
     uint32_t resume_capacity;
     /* the caller wants `minimizer_found`: a hit has it (true) and every other field of a miss is known as well, so the first
@@ -503,8 +504,22 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
         }
         if (!active) return;
     } else {
+        r = active ? fast_lookup_one<W, CANON>(d, x, check_rc) : fast_unsettled(false);
+        /* a MIDLOAD bucket whose first position did not settle the query: the rest of it is scanned by whole waves
+           (scan_lookup_kernel), not by this lane while its 63 neighbours wait */
+        const bool scan = active && r.outcome == FAST_SCAN;
+        const uint32_t place = wave_queue_place(scan, q.resume_counts + shard);
+        if (scan) {
+            if (place < q.resume_capacity) {
+                const uint64_t at = uint64_t(shard) * q.resume_capacity + place;
+                q.resume_index[at] = uint32_t(i);
+                q.resume_meta[at] = r.kmer_offset;
+                for (int j = 0; j < W; ++j) q.resume_kmers[at * W + j] = x.w[j];
+            } else {
+                r.outcome = FAST_DEFER;
+            }
+        }
         if (!active) return;
-        r = fast_lookup_one<W, CANON>(d, x, check_rc);
     }
     /* every remaining lane stores first (a deferred or resumed lane's value is a placeholder that a later pass
        overwrites), the deferred-queue push comes last */
@@ -563,6 +578,128 @@ resume_lookup_kernel(const dict_view d, const bool check_rc, const result_view o
             if (MODE == int(out_mode::full) && q.flag_misses && r.outcome == FAST_MISS)
                 q.defer_index[uint64_t(shard) * q.defer_capacity + atomicAdd(q.defer_counts + shard, 1u)] = uint32_t(i) | DEFER_FLAG_ONLY;
         }
+    }
+}
+
+/* Bucket-scan pass of a replica without the table (directory or MPHF path): the queries whose MIDLOAD bucket (2..64
+   minimizer positions, include/sparse_and_skew_index.hpp:122-132) did not settle at its first position. What the reference
+   does offset after offset (spectrum_preserving_string_set.hpp:41-44,68-70: copy the bucket's offsets, try one after the other)
+   a wave does at once: the 64 entries of a wave are laid out in LDS (k-mer, where the bucket's offsets lie, how many are left),
+   their candidates -- (entry, offset) pairs, a few hundred per wave -- are dealt to the lanes 64 at a time, every lane reads ITS
+   candidate's offset out of mid_load and the window it points at, compares, and the one lane whose window equals the entry's k-mer
+   (a k-mer occurs once in the strings) deposits the result in the entry's LDS place: two dependent reads for the whole bucket,
+   all candidates in flight together, instead of a chain of `size` reads on one lane with 63 lanes waiting. */
+template <int W, bool CANON, int MODE>
+__global__ void __launch_bounds__(256)
+scan_lookup_kernel(const dict_view d, const bool check_rc, const result_view out, uint8_t* __restrict__ member, const pass_queues q) {
+    struct entry_t {
+        uint64_t kmer[W];
+        uint64_t meta;
+        uint64_t offset;     // result: INVALID_U64 = not found (yet)
+        uint32_t string_id;
+        uint32_t incl;       // candidates of the wave's entries up to and including this one
+        int32_t orientation;
+        uint32_t pad;
+    };
+    __shared__ entry_t lds[256];
+    entry_t* E = lds + (threadIdx.x & ~63u);  // this wave's 64 entries
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t shard = blockIdx.x & (DEFER_SHARDS - 1), part = blockIdx.x / DEFER_SHARDS;
+    const uint32_t pushed = q.resume_counts[shard];
+    const uint32_t total = pushed < q.resume_capacity ? pushed : q.resume_capacity;
+    for (uint32_t base = part * blockDim.x; base < total; base += RESUME_PARTS * blockDim.x) {  // uniform over the workgroup
+        const uint32_t j = base + threadIdx.x;
+        const bool active = j < total;
+        const uint64_t at = uint64_t(shard) * q.resume_capacity + (active ? j : 0u);
+        const uint32_t i = q.resume_index[at];
+        const uint64_t meta = active ? q.resume_meta[at] : 0;
+        const bool rc_strand = (meta >> 44) & 1;
+        kmer_w<W> x;
+        for (int t = 0; t < W; ++t) x.w[t] = q.resume_kmers[at * W + t];
+        /* the k-mer as the probing strand reads it (regular dictionaries probe the reverse complement on its own) */
+        const kmer_w<W> y = (!CANON && rc_strand) ? kmer_revcomp<W>(x, d.k) : x;
+        const uint32_t mine = active ? uint32_t((meta >> 32) & 63u) : 0u;  // offsets left to try
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (int(lane) >= o) incl += up;
+        }
+        for (int t = 0; t < W; ++t) E[lane].kmer[t] = y.w[t];
+        E[lane].meta = meta;
+        E[lane].offset = INVALID_U64;
+        E[lane].string_id = 0;
+        E[lane].incl = incl;
+        E[lane].orientation = 1;
+        const uint32_t all = __shfl(incl, 63, 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t c0 = 0; c0 < all; c0 += 64) {  // uniform over the wave
+            const uint32_t t = c0 + lane;
+            if (t < all) {
+                /* the entry holding candidate t: the first whose inclusive count exceeds t */
+                uint32_t lo = 0, hi = 63;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (E[mid].incl > t) hi = mid;
+                    else lo = mid + 1;
+                }
+                const uint64_t em = E[lo].meta;
+                const uint32_t left = uint32_t((em >> 32) & 63u), pos = uint32_t((em >> 38) & 63u);
+                const uint32_t c = t - (E[lo].incl - left) + 1;  // 1 .. size - 1: position 0 was tried by the first pass
+                const uint64_t p = packed_get(d.mid_load, (em & 0xFFFFFFFFull) + c, d.off_width);
+                kmer_w<W> want;
+                for (int w = 0; w < W; ++w) want.w[w] = E[lo].kmer[w];
+                if constexpr (CANON) {
+                    /* both alignments, both orientations (spectrum_preserving_string_set.hpp:237-275) */
+                    const kmer_w<W> want_rc = kmer_revcomp<W>(want, d.k);
+                    const uint32_t pos2 = d.k - d.m - pos;
+                    const window_t<W> w1 = read_window<W>(d.granules, p >= pos ? p - pos : p, d.k);
+                    const window_t<W> w2 = read_window<W>(d.granules, p >= pos2 ? p - pos2 : p, d.k);
+                    const bool f1 = kmer_eq<W>(w1.kmer, want), b1 = kmer_eq<W>(w1.kmer, want_rc);
+                    const bool f2 = kmer_eq<W>(w2.kmer, want), b2 = kmer_eq<W>(w2.kmer, want_rc);
+                    if (p >= pos && (f1 || b1) && !w1.crosses) {
+                        E[lo].offset = p - pos;
+                        E[lo].string_id = w1.string_id;
+                        E[lo].orientation = b1 ? -1 : 1;
+                    } else if (p >= pos2 && (f2 || b2) && !w2.crosses) {
+                        E[lo].offset = p - pos2;
+                        E[lo].string_id = w2.string_id;
+                        E[lo].orientation = b2 ? -1 : 1;
+                    }
+                } else {
+                    if (p >= pos) {
+                        const window_t<W> w = read_window<W>(d.granules, p - pos, d.k);
+                        if (kmer_eq<W>(w.kmer, want) && !w.crosses) {
+                            E[lo].offset = p - pos;
+                            E[lo].string_id = w.string_id;
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (active) {
+            hit_t h;
+            h.kmer_offset = E[lane].offset;
+            h.string_id = E[lane].string_id;
+            h.found = h.kmer_offset != INVALID_U64;
+            h.minimizer_found = true;
+            h.orientation = CANON ? int8_t(E[lane].orientation) : (rc_strand ? int8_t(-1) : int8_t(1));
+            if (!h.found && !CANON && !rc_strand && check_rc) {
+                /* the forward strand's bucket does not hold it: the reverse complement is still to be probed (src/dictionary.cpp:
+                   70-75) -- rare enough (a positive on the other strand whose forward minimizer happens to be in the dictionary,
+                   in a MIDLOAD bucket) for the complete path */
+                q.defer_index[uint64_t(shard) * q.defer_capacity + atomicAdd(q.defer_counts + shard, 1u)] = i;
+            } else if constexpr (MODE == int(out_mode::member)) {
+                member[i] = h.found ? 1 : 0;
+            } else {
+                store_result<MODE == int(out_mode::full)>(d, out, i, h);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the entries are rewritten by the next turn
     }
 }
 
@@ -635,11 +772,17 @@ static uint32_t resume_capacity_divisor() {
     return 2;
 }
 
-/* tail passes on an auxiliary stream (launch()); SSHASH_AMD_OVERLAP=0: everything on the caller's stream, one piece after the other */
+/* Tail passes on an auxiliary stream (launch()): OFF unless SSHASH_AMD_OVERLAP=1. Measured on the calibrated C3 stand-in,
+   same box, alternating runs (profiles/r03/overlap_ab_c3.txt, overlap_ab_c2.txt): 35.90 / 35.95 / 35.81 G lookups/s without,
+   35.67 / 35.65 / 35.61 with; on C2 (10^8 queries, four pieces) 33.5 / 34.6 / 33.5 without, 32.9 / 31.6 / 31.6 with. The tail
+   passes are not idle latency waiting to be hidden: they are more random line fetches (and partial-line id writes) for a
+   memory system the first pass already saturates, so running them beside it only takes lines away from it, and the
+   smaller pieces add launch tails. (Walking the rest of a probe inside the first pass itself, by the lane that needs it,
+   SSHASH_AMD_INLINE_RESUME in profiles/r03/inline_resume_ab.txt: no gain on C3, -4 % on C2; removed.) */
 static bool overlap_tail_passes() {
     static const bool on = [] {
         const char* e = std::getenv("SSHASH_AMD_OVERLAP");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';
     }();
     return on;
 }
@@ -657,7 +800,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
        computes that one byte for them. Without a table such a caller gets the MPHF kernel for everything. */
     {
         const bool wants_flag = MODE == int(out_mode::full) && out.minimizer_found;
-        if ((d.directory.enabled || d.sk.enabled) && !(wants_flag && !d.sk.enabled)) {
+        if (!(wants_flag && !d.sk.enabled)) {
             /* multi-pass: at most 2^27 queries per launch sequence (queue entries are 32-bit; the scratch
                queues stay below 1.3 GiB (2.1 for 128-bit k-mers) per set). A batch is cut into at least OVERLAP_PIECES pieces
                once it is large enough for that to pay, because the tail passes (resume, deferred: few, dependent, latency-bound
@@ -674,10 +817,10 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
             const uint32_t nblocks_max = uint32_t((std::min(piece, n) + block - 1) / block);
             pass_queues shape{};
             shape.defer_capacity = ((nblocks_max + DEFER_SHARDS - 1) / DEFER_SHARDS) * block;
-            shape.resume_capacity = d.sk.enabled ? (shape.defer_capacity + 1) / resume_capacity_divisor() : 0;
+            shape.resume_capacity = (shape.defer_capacity + 1) / resume_capacity_divisor();  // (table: resumed probes; no table: bucket scans)
             const uint64_t defer_places = uint64_t(DEFER_SHARDS) * shape.defer_capacity, resume_places = uint64_t(DEFER_SHARDS) * shape.resume_capacity;
             const size_t set_bytes =
-                (2 * DEFER_SHARDS * sizeof(uint32_t) + (defer_places + resume_places) * sizeof(uint32_t) + resume_places * W * sizeof(uint64_t) + 255) & ~size_t(255);
+                (2 * DEFER_SHARDS * sizeof(uint32_t) + (defer_places + resume_places) * sizeof(uint32_t) + resume_places * (W + 1) * sizeof(uint64_t) + 255) & ~size_t(255);
             std::lock_guard<std::mutex> enqueue(rep->launch_mutex);
             device_replica::stream_scratch& sc = rep->scratch_for(stream, (overlap ? 2 : 1) * set_bytes, overlap);
             uint64_t index = 0;
@@ -693,7 +836,8 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 pq.defer_counts = reinterpret_cast<uint32_t*>(scratch);
                 pq.resume_counts = pq.defer_counts + DEFER_SHARDS;
                 pq.resume_kmers = reinterpret_cast<uint64_t*>(pq.resume_counts + DEFER_SHARDS);  // 8-byte aligned: 2 * 2048 * 4 bytes in
-                pq.defer_index = reinterpret_cast<uint32_t*>(pq.resume_kmers + resume_places * W);
+                pq.resume_meta = pq.resume_kmers + resume_places * W;
+                pq.defer_index = reinterpret_cast<uint32_t*>(pq.resume_meta + resume_places);
                 pq.resume_index = pq.defer_index + defer_places;
                 const void* qa = static_cast<const char*>(q) + at * (ASCII ? kbytes : qbytes);
                 const result_view ids = advance(out, at);
@@ -713,6 +857,9 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 }
                 if (d.sk.enabled)
                     hipLaunchKernelGGL((resume_lookup_kernel<W, CANON, MODE>), dim3(DEFER_SHARDS * RESUME_PARTS), dim3(block), 0, tail, d,
+                                       check_rc, ids, mem, pq);
+                if (!d.sk.enabled)
+                    hipLaunchKernelGGL((scan_lookup_kernel<W, CANON, MODE>), dim3(DEFER_SHARDS * RESUME_PARTS), dim3(block), 0, tail, d,
                                        check_rc, ids, mem, pq);
                 hipLaunchKernelGGL((deferred_lookup_kernel<W, CANON, MODE, ASCII>), dim3(DEFER_SHARDS * DEFER_BLOCKS_PER_SHARD), dim3(block), 0, tail, d,
                                    skew, qa, check_rc, ids, mem, pq);

@@ -365,7 +365,14 @@ __device__ __forceinline__ bool minimizer_found_of_a_miss(dict_view const& d, sk
    buckets, probes left open by an overflowed directory bucket, canonical minimizer ties); deferred
    queries are compacted into a queue and re-run through `lookup_one` by a second, small launch. */
 
-enum fast_outcome : int { FAST_MISS = 0, FAST_HIT = 1, FAST_DEFER = 2, FAST_CONTINUE = 3 /* table probe to be resumed; kmer_offset = queue-entry flags */ };
+enum fast_outcome : int {
+    FAST_MISS = 0,
+    FAST_HIT = 1,
+    FAST_DEFER = 2,
+    FAST_CONTINUE = 3,  // table probe to be resumed; kmer_offset = queue-entry flags
+    FAST_SCAN = 4       // MIDLOAD bucket whose first position did not hold the k-mer: the rest is scanned by the
+                        // wave-cooperative pass; kmer_offset = scan_meta()
+};
 
 struct fast_t {
     uint64_t kmer_offset;
@@ -374,7 +381,14 @@ struct fast_t {
     int8_t orientation;
 };
 
-/* directory answer -> SINGLETON / MIDLOAD bucket; false when the probe has to be deferred (HEAVYLOAD) */
+/* what the first pass hands to the bucket-scan pass: where the bucket's offsets lie in mid_load (the builder keeps that
+   array below 2^32 entries), how many are left to try (size - 1 <= 63), where the minimizer starts in the probing k-mer,
+   and which strand probes (regular dictionaries: 1 = the reverse complement of the query) */
+__device__ __forceinline__ uint64_t scan_meta(bucket_t const& b, uint32_t pos, bool rc_strand) {
+    return (b.begin & 0xFFFFFFFFull) | (uint64_t(b.size - 1) << 32) | (uint64_t(pos) << 38) | (uint64_t(rc_strand ? 1 : 0) << 44);
+}
+
+/* control codeword -> SINGLETON / MIDLOAD bucket; false when the probe has to be deferred (HEAVYLOAD) */
 __device__ __forceinline__ bool fast_bucket(dict_view const& d, uint64_t code, bucket_t& b) {
     b = empty_bucket();
     if ((code & 1) == 0) {
@@ -388,17 +402,6 @@ __device__ __forceinline__ bool fast_bucket(dict_view const& d, uint64_t code, b
     return true;
 }
 
-__device__ __forceinline__ fast_t fast_result(hit_t const& h, bool overflow) {
-    fast_t r;
-    r.kmer_offset = h.kmer_offset;
-    r.string_id = h.string_id;
-    r.orientation = h.orientation;
-    /* a miss whose minimizer check failed was a fingerprint false positive: final only if the
-       directory bucket never overflowed */
-    r.outcome = h.found ? FAST_HIT : ((!h.minimizer_found && overflow) ? FAST_DEFER : FAST_MISS);
-    return r;
-}
-
 __device__ __forceinline__ fast_t fast_unsettled(bool defer) {
     fast_t r;
     r.kmer_offset = 0;
@@ -408,23 +411,92 @@ __device__ __forceinline__ fast_t fast_unsettled(bool defer) {
     return r;
 }
 
+/* minimizer -> control codeword through whatever the replica holds: the one-atom directory, or MPHF pilot + codeword (two
+   dependent atoms; the codeword's fingerprint ends a probe with a foreign minimizer there). `settled`: the answer is
+   final (false: an overflowed directory bucket -- the complete path must have the last word). */
+struct resolve_t {
+    uint64_t code;
+    bool present;
+    bool settled;
+};
+
+__device__ __forceinline__ resolve_t fast_resolve(dict_view const& d, uint64_t minimizer) {
+    resolve_t r;
+    if (d.directory.enabled) {  // uniform
+        const dir_answer a = directory_probe(d, minimizer);
+        r.code = a.code;
+        r.present = a.present;
+        r.settled = !a.overflow;
+    } else {
+        const uint64_t id = mphf_eval(d.minimizers, city128_u64(minimizer, d.minimizers.seed));
+        const uint64_t entry = d.cw_packed ? packed_get(d.codewords, id, d.cw_width) : d.codewords[id];
+        r.code = entry & low_mask(d.cw_width);
+        r.present = d.cw_packed || (entry >> d.cw_width) == minimizer_fingerprint(minimizer, d.m, d.canonical != 0, d.cw_width);
+        r.settled = true;
+    }
+    return r;
+}
+
+/* the FIRST position of a bucket only: one read serves the minimizer check (spectrum_preserving_string_set.hpp:46-65) and
+   the first candidate (:68-70). A MIDLOAD bucket whose first position does not hold the k-mer is left to the scan pass. */
 template <int W>
-__device__ __forceinline__ fast_t fast_probe_regular(dict_view const& d, kmer_w<W> const& x, minimizer_t mini) {
-    const dir_answer a = directory_probe(d, mini.value);
-    if (!a.present) return fast_unsettled(a.overflow);
+__device__ __forceinline__ fast_t fast_probe_regular(dict_view const& d, kmer_w<W> const& x, minimizer_t mini, bool rc_strand,
+                                                     resolve_t const& a) {
+    if (!a.present) return fast_unsettled(!a.settled);
     bucket_t b;
     if (!fast_bucket(d, a.code, b)) return fast_unsettled(true);
-    return fast_result(scan_regular<W>(d, b, x, mini), a.overflow);
+    fast_t r = fast_unsettled(false);
+    const uint64_t p = b.first_offset;
+    const bool aligned = p >= mini.pos;
+    const window_t<W> w = read_window<W>(d.granules, aligned ? p - mini.pos : p, d.k);
+    const uint64_t mm = aligned ? mmer_at<W>(w.kmer, mini.pos, d.m) : (w.kmer.w[0] & low_mask(2 * d.m));
+    if (mm != mini.value) return fast_unsettled(!a.settled);  // a fingerprint's false positive: final only if the directory bucket never overflowed
+    if (aligned && kmer_eq<W>(w.kmer, x) && !w.crosses) {
+        r.outcome = FAST_HIT;
+        r.kmer_offset = p - mini.pos;
+        r.string_id = w.string_id;
+        return r;
+    }
+    if (b.size > 1) {
+        r.outcome = FAST_SCAN;
+        r.kmer_offset = scan_meta(b, mini.pos, rc_strand);
+    }
+    return r;
 }
 
 template <int W>
 __device__ __forceinline__ fast_t fast_probe_canonical(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc,
                                                        minimizer_t mini) {
-    const dir_answer a = directory_probe(d, mini.value);
-    if (!a.present) return fast_unsettled(a.overflow);
+    const resolve_t a = fast_resolve(d, mini.value);
+    if (!a.present) return fast_unsettled(!a.settled);
     bucket_t b;
     if (!fast_bucket(d, a.code, b)) return fast_unsettled(true);
-    return fast_result(scan_canonical<W>(d, b, x, x_rc, mini), a.overflow);
+    fast_t r = fast_unsettled(false);
+    const uint64_t p = b.first_offset;
+    /* both alignments of the first position (spectrum_preserving_string_set.hpp:237-247), issued together */
+    const uint32_t pos2 = d.k - d.m - mini.pos;
+    const window_t<W> w0 = read_window<W>(d.granules, p, d.k);
+    const window_t<W> w1 = read_window<W>(d.granules, p >= mini.pos ? p - mini.pos : p, d.k);
+    const window_t<W> w2 = read_window<W>(d.granules, p >= pos2 ? p - pos2 : p, d.k);
+    const uint64_t mm = w0.kmer.w[0] & low_mask(2 * d.m);
+    if (mm != mini.value && mm != mmer_revcomp(mini.value, d.m)) return fast_unsettled(!a.settled);
+    auto attempt = [&](window_t<W> const& w, uint32_t pos) {
+        if (p < pos || r.outcome == FAST_HIT) return;
+        const bool fwd = kmer_eq<W>(w.kmer, x), bwd = kmer_eq<W>(w.kmer, x_rc);
+        if ((fwd || bwd) && !w.crosses) {
+            r.outcome = FAST_HIT;
+            r.kmer_offset = p - pos;
+            r.string_id = w.string_id;
+            r.orientation = bwd ? -1 : 1;
+        }
+    };
+    attempt(w1, mini.pos);
+    attempt(w2, pos2);
+    if (r.outcome != FAST_HIT && b.size > 1) {
+        r.outcome = FAST_SCAN;
+        r.kmer_offset = scan_meta(b, mini.pos, false);
+    }
+    return r;
 }
 
 template <int W, bool CANON>
@@ -436,10 +508,27 @@ __device__ __forceinline__ fast_t fast_lookup_one(dict_view const& d, kmer_w<W> 
         if (mf.value == mr.value) return fast_unsettled(true);  // tie: both alignments (src/dictionary.cpp:35-40)
         return fast_probe_canonical<W>(d, x, x_rc, mf.value < mr.value ? mf : mr);
     } else {
-        fast_t r = fast_probe_regular<W>(d, x, compute_minimizer<W>(x, d.k, d.m, d.hash_magic));
+        const minimizer_t mf = compute_minimizer<W>(x, d.k, d.m, d.hash_magic);
+        if (d.directory.enabled && check_rc) {  // uniform
+            /* both strands' directory buckets are asked for at once: three of four queries of the benchmark mix (negatives,
+               positives indexed on the other strand) need the second answer anyway, and with it in flight beside the first
+               their chain of dependent reads is one read shorter; a forward hit wastes one line. (Not with the MPHF: there
+               a resolve is two dependent reads, that path already runs at its line rate, and the wasted pair costs more.) */
+            const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
+            const minimizer_t mr = compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic);
+            const resolve_t af = fast_resolve(d, mf.value), ar = fast_resolve(d, mr.value);
+            fast_t r = fast_probe_regular<W>(d, x, mf, false, af);
+            if (r.outcome == FAST_MISS) {
+                r = fast_probe_regular<W>(d, x_rc, mr, true, ar);
+                r.orientation = -1;
+            }
+            return r;
+        }
+        fast_t r = fast_probe_regular<W>(d, x, mf, false, fast_resolve(d, mf.value));
         if (r.outcome == FAST_MISS && check_rc) {
             const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
-            r = fast_probe_regular<W>(d, x_rc, compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic));
+            const minimizer_t mr = compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic);
+            r = fast_probe_regular<W>(d, x_rc, mr, true, fast_resolve(d, mr.value));
             r.orientation = -1;
         }
         return r;

@@ -272,3 +272,96 @@ def draw_queries_device(d, device: int, n: int, positive_fraction: float = 0.5, 
         is_pos = torch.rand(m, generator=g, device=dev) < positive_fraction
         out[at:at + m] = torch.where(is_pos.unsqueeze(1), pos, neg)
     return out.reshape(-1)
+
+
+# ---- synthetic FASTQ of reads drawn from a dictionary (BASELINE.json configs[3]) -----------------
+
+def make_reads_device(d, device: int, n_reads: int, read_len: int = 150, positive_fraction: float = 0.5, substitution_rate: float = 0.01,
+                      n_rate: float = 1e-3, seed: int = 0x5555AAAA):
+    """-> uint8 torch tensor (n_reads, read_len) of ASCII bases on cuda:`device`. A positive read spells read_len - k + 1
+    consecutive k-mers of the dictionary (ids id .. id + read_len - k: a read that runs past the end of its string continues in
+    the next one, as a chimeric read would), every other one reverse-complemented, then gets substitutions at `substitution_rate`
+    per base; the other reads are uniformly random; 'N' replaces a base at `n_rate`. k <= 31."""
+    import torch
+
+    dev = torch.device("cuda", device)
+    k, nk = d.k(), d.num_kmers()
+    if d.words_per_kmer() != 1:
+        raise ValueError("make_reads_device: k <= 31")
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    span = read_len - k + 1
+    out = torch.empty((n_reads, read_len), dtype=torch.uint8, device=dev)
+    chunk = max(1, (1 << 26) // span)
+    alphabet = torch.tensor(list(b"ACTG"), dtype=torch.uint8, device=dev)  # the reference's 2-bit codes (include/kmer.hpp:118)
+    comp = torch.tensor([2, 3, 0, 1], dtype=torch.int64, device=dev)       # A<->T, C<->G as codes
+    for at in range(0, n_reads, chunk):
+        m = min(chunk, n_reads - at)
+        first = torch.randint(0, max(1, nk - span), (m,), generator=g, device=dev, dtype=torch.int64)
+        ids = (first[:, None] + torch.arange(span, device=dev, dtype=torch.int64)[None, :]).reshape(-1).contiguous()
+        km = torch.empty(m * span, dtype=torch.int64, device=dev)
+        d.access_packed_device(device, ids.data_ptr(), m * span, km.data_ptr(), stream=stream)
+        km = km.reshape(m, span)
+        codes = torch.empty((m, read_len), dtype=torch.int64, device=dev)
+        codes[:, :span] = km & 3
+        last = km[:, span - 1]
+        for j in range(1, k):
+            codes[:, span - 1 + j] = (last >> (2 * j)) & 3
+        flip = torch.rand(m, generator=g, device=dev) < 0.5
+        codes = torch.where(flip[:, None], comp[codes.flip(1)], codes)
+        sub = torch.rand((m, read_len), generator=g, device=dev) < substitution_rate
+        codes = torch.where(sub, (codes + torch.randint(1, 4, (m, read_len), generator=g, device=dev)) & 3, codes)
+        rnd = torch.randint(0, 4, (m, read_len), generator=g, device=dev)
+        positive = torch.rand(m, generator=g, device=dev) < positive_fraction
+        codes = torch.where(positive[:, None], codes, rnd)
+        text = alphabet[codes]
+        text = torch.where(torch.rand((m, read_len), generator=g, device=dev) < n_rate, torch.full_like(text, ord("N")), text)
+        out[at:at + m] = text
+    return out
+
+
+def write_fastq(reads, path: str, gzip_level: int | None = None, workers: int = 8) -> int:
+    """reads: uint8 array/tensor (n, L) of ASCII bases -> a FASTQ file (4 lines per read); gzip_level: also compress -- the
+    file is written as independent gzip members by `workers` processes (a multi-member .gz is what `cat a.gz b.gz` makes;
+    zlib's gzread, the reference's zip_istream and gunzip all read it as one stream). Returns the bytes written."""
+    import os
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    a = reads.cpu().numpy() if hasattr(reads, "cpu") else np.asarray(reads)
+    n, L = a.shape
+
+    def records(lo, hi):
+        m = hi - lo
+        idx = np.arange(lo, hi)
+        rec = np.empty((m, 11 + 1 + L + 1 + 2 + L + 1), dtype=np.uint8)
+        rec[:, 0] = ord("@")
+        rec[:, 1] = ord("r")
+        for j in range(9):  # nine decimal digits of the read's number
+            rec[:, 2 + j] = ord("0") + (idx // 10 ** (8 - j)) % 10
+        rec[:, 11] = 10
+        rec[:, 12:12 + L] = a[lo:hi]
+        rec[:, 12 + L] = 10
+        rec[:, 13 + L] = ord("+")
+        rec[:, 14 + L] = 10
+        rec[:, 15 + L:15 + 2 * L] = ord("I")
+        rec[:, 15 + 2 * L] = 10
+        return rec.tobytes()
+
+    step = 1 << 18
+    pieces = [(lo, min(n, lo + step)) for lo in range(0, n, step)]
+
+    def make(p):
+        raw = records(*p)
+        if gzip_level is None:
+            return raw
+        c = zlib.compressobj(gzip_level, zlib.DEFLATED, 31)  # 31: gzip container
+        return c.compress(raw) + c.flush()
+
+    total = 0
+    with open(path, "wb") as f, ThreadPoolExecutor(max_workers=workers) as ex:  # (zlib and numpy release the GIL)
+        for blob in ex.map(make, pieces):
+            f.write(blob)
+            total += len(blob)
+    return total
