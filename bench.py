@@ -196,6 +196,59 @@ def measure_other_paths(args, index_path, device, d, dq, W, bytes_per_lookup):
     return res
 
 
+def measure_streaming_from_file(d, index_path, reads_tensor, directory, tag, oracle_sample=100_000, gzip_level=1, log=lambda *a: None):
+    """`sshash query` end to end (sshash_streaming_query_from_file: decompress, split, H2D, streaming kernels), wall clock, on a
+    FASTQ written from `reads_tensor` -- plain and gzipped --, with the reader alone (tools/reader_rate.cpp: no GPU) and the CPU
+    oracle's streaming state machine on the first reads of the same file beside it; counters checked against the oracle."""
+    from sshash_amd.synthetic import write_fastq
+
+    k = d.k()
+    n, L = reads_tensor.shape
+    res = {"reads": int(n), "read_length": int(L), "kmers": int(n) * (L - k + 1)}
+    exe = os.path.join(directory, "reader_rate")
+    have_exe = subprocess.call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tools", "reader_rate.cpp"),
+                                os.path.join(ROOT, "sshash_amd", "csrc", "reads.cpp"), "-lz", "-o", exe]) == 0
+    for flavour, level in (("fastq", None), ("fastq.gz", gzip_level)):
+        path = os.path.join(directory, f"sshash_amd_{tag}.{flavour}")
+        t0 = time.perf_counter()
+        size = write_fastq(reads_tensor, path, gzip_level=level, workers=max(1, (os.cpu_count() or 8) // 2))
+        log(f"{path}: {size / 1e9:.2f} GB written in {time.perf_counter() - t0:.1f}s")
+        d.streaming_query_from_file(path)  # (page cache warm, pools sized: the reference's numbers are warm-cache too)
+        t0 = time.perf_counter()
+        rep = d.streaming_query_from_file(path)
+        dt = time.perf_counter() - t0
+        entry = {"file_bytes": size, "seconds": round(dt, 3), "kmers_per_s": round(rep.num_kmers / dt, 1),
+                 "ns_per_kmer": round(dt / max(1, rep.num_kmers) * 1e9, 3),
+                 "report": {f: int(getattr(rep, f)) for f in ("num_kmers", "num_positive_kmers", "num_negative_kmers", "num_invalid_kmers",
+                                                              "num_searches", "num_extensions")}}
+        if have_exe:
+            out = subprocess.run([exe, path, str(k)], capture_output=True, text=True)
+            if out.returncode == 0:
+                entry["reader_alone"] = json.loads(out.stdout)
+        res[flavour] = entry
+        os.remove(path)
+    # the CPU oracle's streaming state machine on the first reads of the same file (1 thread, as the reference's query tool)
+    from oracle import oracle as O
+
+    ora = O.OracleIndex(index_path)
+    m = min(n, oracle_sample)
+    sample = reads_tensor[:m].cpu().numpy()
+    reads = [bytes(r) for r in sample]
+    t0 = time.perf_counter()
+    want = ora.streaming_query(reads)
+    dt = time.perf_counter() - t0
+    res["cpu_oracle"] = {"kind": "port", "cores": 1, "reads": m, "seconds": round(dt, 3), "ns_per_kmer": round(dt / max(1, want["num_kmers"]) * 1e9, 2),
+                         "kmers_per_s": round(want["num_kmers"] / dt, 1)}
+    got = d.streaming_query(reads)
+    for f, v in want.items():
+        if int(getattr(got, f)) != v:
+            raise SystemExit(f"PARITY FAILURE: streaming counter {f}: GPU {getattr(got, f)} vs oracle {v}")
+    res["counters_equal_oracle_on_sample"] = True
+    res["published_reference"] = {"ns_per_kmer": 89.5, "what": "human k=31 regular, SRR5833294 (91.6 % positive), gzipped FASTQ, one 5.4 GHz core, "
+                                  "benchmarks/results-21-01-26/k31/regular-streaming-queries-high-hit.json:3"}
+    return res
+
+
 def traffic_record(d, n_local: int, args):
     """HBM bytes per step from the PMC passes of THIS workload (profiles/traffic.json, written by
     tools/jobs/*traffic*.sh from rocprofv3 --pmc runs of this very command); None when the tracked record is of
@@ -225,6 +278,8 @@ def main():
     ap.add_argument("--m", type=int, default=21)
     ap.add_argument("--recipe", default=None, help="sshash_amd/recipes/<name>.json (default: the workload's)")
     ap.add_argument("--repeat-scale", type=float, default=1.0, help="multiply the amount of every repeat family of the recipe")
+    ap.add_argument("--no-file-query", action="store_true", help="skip the end-to-end FASTQ query (side measurement, outside the timed region)")
+    ap.add_argument("--file-reads", type=int, default=2_000_000, help="reads of the end-to-end FASTQ query (tools/bench_streaming_file.py runs 10^8)")
     ap.add_argument("--no-other-paths", action="store_true", help="skip the table-less paths (side measurement, outside the timed region)")
     ap.add_argument("--canonical", action="store_true")
     ap.add_argument("--positive", type=float, default=0.5, help="fraction of positive queries in the batch")
@@ -457,6 +512,15 @@ def main():
         other_paths = None
         if world == 1 and sharded is None and not args.no_other_paths and stats["sk_slots"]:
             other_paths = measure_other_paths(args, index_path, local_rank, d, dq, W, bytes_per_lookup)
+        from_file = None
+        if world == 1 and sharded is None and not args.no_file_query and args.k <= 31:
+            from sshash_amd.synthetic import make_reads_device
+
+            reads = make_reads_device(d, local_rank, args.file_reads, 150, positive_fraction=0.9, seed=args.seed + 5).cpu()
+            from_file = measure_streaming_from_file(d, index_path, reads, args.cache_dir, f"bench{os.getpid()}", oracle_sample=50_000, log=log)
+            from_file["workload"] = (f"{args.file_reads} reads x 150 bp, 90 % drawn from the dictionary with 1 % substitutions, N at 1e-3 per base; "
+                                     "tools/bench_streaming_file.py runs 10^8 reads (profiles/r03/)")
+            del reads
         index_statistics = table_histogram = None
         if args.k <= 31:
             from sshash_amd.repeats import statistics_vs_target
@@ -497,6 +561,7 @@ def main():
             "cpu_baseline": cpu,
             "other_mixes": extra,
             "other_paths": other_paths,
+            "streaming_from_file": from_file,
         }
     barrier()
     if use_dist:

@@ -361,6 +361,9 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
         uint64_t keep = ~uint64_t(0);
         if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     }
+    if (const uint64_t budget = hbm_budget(); budget && rep->bytes > budget)
+        throw error(error_kind::no_device, "the replica needs " + std::to_string(rep->bytes) + " bytes of HBM, SSHASH_AMD_HBM_BUDGET allows " +
+                                               std::to_string(budget) + ": partition the dictionary (minimizer shards, table shards)");
     std::unique_lock<std::shared_mutex> lock(m_replicas_mutex);
     m_replicas.push_back(std::move(rep));
 }

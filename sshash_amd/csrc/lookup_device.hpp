@@ -509,21 +509,9 @@ __device__ __forceinline__ fast_t fast_lookup_one(dict_view const& d, kmer_w<W> 
         return fast_probe_canonical<W>(d, x, x_rc, mf.value < mr.value ? mf : mr);
     } else {
         const minimizer_t mf = compute_minimizer<W>(x, d.k, d.m, d.hash_magic);
-        if (d.directory.enabled && check_rc) {  // uniform
-            /* both strands' directory buckets are asked for at once: three of four queries of the benchmark mix (negatives,
-               positives indexed on the other strand) need the second answer anyway, and with it in flight beside the first
-               their chain of dependent reads is one read shorter; a forward hit wastes one line. (Not with the MPHF: there
-               a resolve is two dependent reads, that path already runs at its line rate, and the wasted pair costs more.) */
-            const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
-            const minimizer_t mr = compute_minimizer<W>(x_rc, d.k, d.m, d.hash_magic);
-            const resolve_t af = fast_resolve(d, mf.value), ar = fast_resolve(d, mr.value);
-            fast_t r = fast_probe_regular<W>(d, x, mf, false, af);
-            if (r.outcome == FAST_MISS) {
-                r = fast_probe_regular<W>(d, x_rc, mr, true, ar);
-                r.orientation = -1;
-            }
-            return r;
-        }
+        /* (Asking for both strands' directory buckets at once -- three of four queries of the benchmark mix need the second
+           answer anyway -- shortens the chain by one read and wastes a line on every forward hit: measured 12.1 against 13.0 G
+           lookups/s on the C3 stand-in, profiles/r03/; the strands stay one after the other.) */
         fast_t r = fast_probe_regular<W>(d, x, mf, false, fast_resolve(d, mf.value));
         if (r.outcome == FAST_MISS && check_rc) {
             const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);

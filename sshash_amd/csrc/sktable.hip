@@ -328,6 +328,11 @@ static void absent(device_replica& rep, uint32_t reason) {
     if (std::getenv("SSHASH_AMD_VERBOSE")) fprintf(stderr, "[sshash_amd] device %d: no super-k-mer table (reason %u, sshash_amd.h)\n", rep.device, reason);
 }
 
+uint64_t hbm_budget() {
+    if (const char* e = std::getenv("SSHASH_AMD_HBM_BUDGET")) return std::strtoull(e, nullptr, 10);
+    return 0;
+}
+
 void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_shards, uint32_t table_shard_id) {
     dict_view& v = rep.view;
     v.sk.slots = nullptr;
@@ -470,6 +475,10 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
         size_t free_bytes = 0, total_bytes = 0;
         HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
         if (num_slots * slot_bytes > free_bytes / 2) return absent(rep, SK_ABSENT_NO_MEMORY);  // leave HBM for the caller's batches
+        /* SSHASH_AMD_HBM_BUDGET (bytes): what ONE replica may hold -- how a deployment keeps room for several dictionaries,
+           and how the tests make a dictionary "larger than the HBM" on a box whose HBM it would fit many times over */
+        const uint64_t budget = hbm_budget();
+        if (budget && rep.bytes + num_slots * slot_bytes > budget) return absent(rep, SK_ABSENT_NO_MEMORY);
     }
     uint32_t* slots = tmp.alloc<uint32_t>(num_slots * slot_bytes / 4);
     uint8_t* placed = tmp.alloc<uint8_t>(T + heavy_kmers);

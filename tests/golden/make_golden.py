@@ -13,6 +13,10 @@
   salmonella_enterica_k31_ust.fa.gz, SRR5833294.10K.fastq.gz; se.ust.k63.head.fa.gz = the first 24
   records of se.ust.k63.fa.gz; salmonella_enterica.weighted.ust.k31.fa.gz =
   data/unitigs_stitched/with_weights/salmonella_enterica.ust.k31.fa.gz (headers carry the abundances).
+  Round 3, copied verbatim as well: se.ust.k63.fa.gz (all 238 records: the reference's own k = 63 input),
+  se.ust.k47.fa.gz (k = 47: two-word k-mers whose second word is half used), ecoli1_k31_ust.fa.gz,
+  penicillium_chrysogenum_k31_ust.fa.gz (a eukaryote's repeat content), and data/queries/salmonella_enterica.fasta.gz -- a genome
+  as MULTILINE FASTA, the input of the reference's multiline reader (src/query.cpp:9-47).
 """
 import gzip
 import json
@@ -40,6 +44,11 @@ def main():
     json.dump(vec, open(os.path.join(HERE, "xxh64_vectors.json"), "w"), indent=0)
 
     for rel in ["data/unitigs_stitched/salmonella_enterica_k31_ust.fa.gz", "data/queries/SRR5833294.10K.fastq.gz"]:
+        dst = os.path.join(HERE, os.path.basename(rel))
+        if not os.path.exists(dst):
+            shutil.copy(os.path.join(REF, rel), dst)
+    for rel in ["data/unitigs_stitched/se.ust.k63.fa.gz", "data/unitigs_stitched/se.ust.k47.fa.gz", "data/unitigs_stitched/ecoli1_k31_ust.fa.gz",
+                "data/unitigs_stitched/penicillium_chrysogenum_k31_ust.fa.gz", "data/queries/salmonella_enterica.fasta.gz"]:
         dst = os.path.join(HERE, os.path.basename(rel))
         if not os.path.exists(dst):
             shutil.copy(os.path.join(REF, rel), dst)

@@ -15,7 +15,7 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-SMALL = ["--workload", "c2", "--bases", "30000000", "--queries", "4000000", "--steps", "3", "--warmup", "1", "--cpu-sample", "100000"]
+SMALL = ["--workload", "c2", "--bases", "30000000", "--queries", "4000000", "--steps", "3", "--warmup", "1", "--cpu-sample", "100000", "--file-reads", "200000"]
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
             "data", "config", "roofline", "cpu_baseline")
 
@@ -45,6 +45,21 @@ def test_one_gpu_line_carries_the_contract(tmp_path):
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu
     assert abs(r["config"]["positive_fraction_found"] - 0.5) < 0.01
     assert set(r["other_mixes"]) == {"positive100", "negative100_random", "mix50_mutated_negatives"}
+    # round 3: the stand-in's statistics next to the published ones, the table-side histogram, the table-less paths, `sshash query` end to end
+    stats = r["config"]["index_statistics"]
+    assert stats["source"].startswith("benchmarks/results-10-11-25/k31/regular-build.log") and stats["num_kmers"]["achieved"] == r["config"]["num_kmers"]
+    assert {"target", "achieved", "ratio"} <= set(stats["num_minimizer_positions_of_buckets_in_skew_index"])
+    hist = r["config"]["table_histogram"]
+    assert sum(hist["keys_by_occurrences"].values()) == r["config"]["device_stats"]["sk_keys"]
+    assert sum(hist["super_kmers_by_occurrences_of_their_key"].values()) == hist["super_kmers"]
+    assert set(r["other_paths"]) == {"directory", "mphf"} and all(v["ids_equal_table_path"] and v["lookups_per_s"] > 0 for v in r["other_paths"].values())
+    f = r["streaming_from_file"]
+    assert f["counters_equal_oracle_on_sample"] is True and f["kmers"] == 200000 * 120
+    for flavour in ("fastq", "fastq.gz"):
+        rep = f[flavour]["report"]
+        assert rep["num_kmers"] == f["kmers"] == rep["num_positive_kmers"] + rep["num_negative_kmers"] + rep["num_invalid_kmers"]
+        assert f[flavour]["ns_per_kmer"] > 0 and f[flavour]["reader_alone"]["reads"] == 200000
+    assert f["fastq"]["report"] == f["fastq.gz"]["report"]
 
 
 def test_two_ranks_split_one_batch(tmp_path):
@@ -55,3 +70,12 @@ def test_two_ranks_split_one_batch(tmp_path):
     assert r["ms_per_step"] >= max(p["ms_per_step"] for p in r["per_rank"]) * 0.98  # the MAX over the ranks
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".sshash")]) == 1  # built once, by rank 0
     assert r["cpu_baseline"] is None and r["config"]["index_replicated_per_gpu"] is True
+
+
+@pytest.mark.parametrize("how", ["table", "minimizer"])
+def test_two_ranks_route_one_batch_over_a_partitioned_dictionary(how, tmp_path):
+    """`bench.py --sharded ... --gpus 2`: the N > 1 ROUTED path (route -> all-to-all -> lookup -> return -> combine), both ranks on
+    the one GPU of the test box and the exchange over gloo; ids are checked against the oracle inside bench.py."""
+    r = run_bench(["--gpus", "2", "--no-cpu-baseline", "--sharded", how], {"SSHASH_BENCH_TEST_ALL_RANKS_ON_DEVICE": "0"}, tmp_path)
+    assert r["n_gpus"] == 2 and r["config"]["sharded"] == how and r["config"]["index_replicated_per_gpu"] is False
+    assert sum(p["queries"] for p in r["per_rank"]) == 4000000 and abs(r["config"]["positive_fraction_found"] - 0.5) < 0.01

@@ -197,3 +197,119 @@ def test_sharded_lookup_over_the_nccl_backend(tmp_path):
                         "--master-port", "29577", str(script), ROOT, SE_FASTA], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert f"NCCL SHARDED OK {n}" in p.stdout
+
+
+BUDGET_WORKER = textwrap.dedent(
+    """
+    import os, sys, time
+    import numpy as np
+    sys.path.insert(0, sys.argv[1])
+    import torch, torch.distributed as dist
+    import sshash_amd
+    from sshash_amd.sharded import ShardedDictionary
+    from sshash_amd.synthetic import draw_queries_device
+    from oracle import oracle as O
+
+    index_path, by, budget, n_queries = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    whole = sshash_amd.Dictionary.load(index_path)
+    # the queries are drawn from an unrestricted replica of the whole dictionary, one rank at a time (they time-share ONE GPU)
+    for turn in range(world):
+        if turn == rank:
+            whole.to_device(0)
+            dq = draw_queries_device(whole, 0, n_queries, 0.5, seed=1000 + rank).clone()
+            whole.close()
+            torch.cuda.synchronize(); torch.cuda.empty_cache()
+        dist.barrier()
+    os.environ["SSHASH_AMD_HBM_BUDGET"] = str(budget)
+    # 1. a whole replica does not fit the budget ...
+    whole = sshash_amd.Dictionary.load(index_path)
+    try:
+        whole.to_device(0)
+        stats = whole.device_stats(0)
+        # (a budget between "everything but the table" and "everything": the replica is there, without its table, and says why)
+        assert stats["sk_slots"] == 0 and stats["sk_absent_reason"] == "not enough free HBM", stats
+        fits_without_table = True
+    except sshash_amd.SSHashError as e:
+        assert "SSHASH_AMD_HBM_BUDGET" in str(e), str(e)
+        fits_without_table = False
+    whole.close()
+    # 2. ... its partition over the ranks does
+    if by == "table":
+        sd = ShardedDictionary(sshash_amd.Dictionary.load(index_path), 0, by="table")
+        stats = sd.shard.device_stats(0)
+        assert stats["sk_slots"] > 0 and stats["sk_absent_reason"] is None and stats["bytes"] <= budget, stats
+    else:
+        shard = sshash_amd.Dictionary.load(sys.argv[6] % rank)
+        sd = ShardedDictionary(shard, 0, by="minimizer")
+        stats = shard.device_stats(0)
+        assert stats["sk_absent_reason"] == "minimizer shard" and stats["bytes"] <= budget, stats
+    t0 = time.time()
+    got = sd.lookup_device(dq).cpu().numpy().view(np.uint64)
+    dt = time.time() - t0
+    want = O.OracleIndex(index_path).lookup_ids(dq.cpu().numpy().view(np.uint64), num_threads=max(1, (os.cpu_count() or 4) // world))
+    assert (got == want).all(), f"rank {rank}: {int((got != want).sum())} ids differ from the oracle"
+    found = torch.tensor([int((got != np.uint64(0xFFFFFFFFFFFFFFFF)).sum())]); dist.all_reduce(found)
+    if rank == 0:
+        print("BUDGET OK", by, world, int(found), "fits_without_table" if fits_without_table else "does_not_fit", f"{dt:.2f}s", flush=True)
+    dist.barrier(); dist.destroy_process_group()
+    """
+)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("by", ["table", "minimizer"])
+def test_a_dictionary_that_needs_sharding(by, tmp_path):
+    """BASELINE.json configs[4] on the one-GPU box: SSHASH_AMD_HBM_BUDGET caps what a replica may hold, so that
+    a C2-like dictionary (the S. enterica recipe at 1/12 of its size: 75 M k-mers) CANNOT get a whole replica -- the table is
+    refused, or the replica altogether, and device_stats says why -- and must be partitioned: FOUR ranks time-sharing the GPU,
+    table shards or minimizer shards, 10^7 queries of the bench mix per rank through the routed lookup, every id against the oracle."""
+    from sshash_amd.repeats import make_recipe_spss
+
+    world, n_queries = 4, 10_000_000
+    words, ends = make_recipe_spss("se_k31", 115_000_000, seed=3)
+    whole = sshash_amd.Dictionary.build_from_packed(words, ends, k=31, m=21, num_threads=0)
+    index = str(tmp_path / "whole.sshash")
+    whole.save(index)
+    shard_pattern = str(tmp_path / "shard%d.sshash")
+    if by == "minimizer":
+        for r in range(world):
+            s = sshash_amd.Dictionary.build_from_packed(words, ends, k=31, m=21, num_threads=0, num_shards=world, shard_id=r)
+            s.save(shard_pattern % r)
+            s.close()
+    # budgets from the layout itself: a whole replica (table included) measured without a limit
+    whole.to_device(0)
+    st = whole.device_stats(0)
+    whole.close()
+    full, table = st["bytes"], st["sk_bytes"]
+    # table shards: everything but the table in full + a quarter of the table (+ slack) fits, the whole table does not;
+    # minimizer shards: not even the table-less replica fits (strings + a quarter of the minimizer structures do)
+    if by == "table":
+        budget = (full - table) + table // world + table // 8
+    else:
+        os.environ["SSHASH_AMD_SKTABLE"] = "0"
+        try:
+            w2 = sshash_amd.Dictionary.load(index).to_device(0)
+            without_table = w2.device_bytes(0)
+            w2.close()
+        finally:
+            del os.environ["SSHASH_AMD_SKTABLE"]
+        s0 = sshash_amd.Dictionary.load(shard_pattern % 0).to_device(0)
+        one_shard = s0.device_bytes(0)
+        s0.close()
+        assert one_shard * 1.1 < without_table, (one_shard, without_table)
+        budget = int((one_shard * 1.1 + without_table) / 2)
+    script = tmp_path / "budget_worker.py"
+    script.write_text(BUDGET_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29560 + (by == "table")), WORLD_SIZE=str(world))
+    env.pop("SSHASH_AMD_HBM_BUDGET", None)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, index, by, str(budget), str(n_queries), shard_pattern],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=1500)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    assert f"BUDGET OK {by} {world}" in outs[0]
+    assert ("fits_without_table" if by == "table" else "does_not_fit") in outs[0], outs[0][-500:]

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 NAME=$1; VAR=$2; A=$3; B=$4; ROUNDS=$5; shift 5
 OUT=gpurun_out/$NAME
 mkdir -p $OUT
-BENCH="python bench.py --no-cpu-baseline --no-extra-mixes --no-other-paths --steps 20 --warmup 3 $*"
+BENCH="python bench.py --no-cpu-baseline --no-extra-mixes --no-other-paths --no-file-query --steps 20 --warmup 3 $*"
 for r in $(seq 1 $ROUNDS); do
   for v in $A $B; do
     env $VAR=$v $BENCH 2>> $OUT/bench.err | python3 -c "
