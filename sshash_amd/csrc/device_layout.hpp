@@ -42,12 +42,12 @@
 //      table whose buckets are exactly one 32-byte DRAM atom: 4 x u64 entries,
 //          entry = codeword (40 bits) | fingerprint (16 bits) << 40 | meta << 56
 //          meta: bit 0 = slot valid; bit 7 of entry 0 = bucket overflowed
-//      bucket = hash(minimizer) range-reduced, average load 1.5 keys. What bounds this workload is
+//      bucket = hash(minimizer) range-reduced, average load 1.0 keys. What bounds this workload is
 //      the number of 32-byte atoms fetched from HBM per lookup (~50 G random atoms/s):
 //      MPHF + codeword array cost two dependent atoms per probe (pilot, then codeword); the
 //      directory answers the same question with ONE. It is an accelerator over the MPHF, not a
 //      replacement: every key stays reachable through the MPHF; a bucket whose keys did not all fit
-//      (Poisson tail, ~1.9 % of buckets) or that held two keys with equal fingerprints carries the
+//      (Poisson tail, ~0.4 % of buckets) or that held two keys with equal fingerprints carries the
 //      overflow flag, and probes that are not settled there fall back to the MPHF path. A key absent
 //      from a non-overflowed bucket is absent from the dictionary. Used by the ids-only / is_member
 //      / streaming kernels; the full-result kernel keeps the MPHF path because for an absent
@@ -142,7 +142,8 @@ SSH_HD uint64_t minimizer_fingerprint(uint64_t minimizer, uint32_t m, bool canon
 
 constexpr uint32_t DIR_SLOTS = 4;         // entries per 32-byte bucket
 constexpr uint32_t DIR_CODE_BITS = 40;    // widest control codeword the directory can hold
-constexpr double DIR_LOAD = 1.5;          // average keys per bucket
+constexpr double DIR_LOAD = 1.0;          // average keys per bucket (1.5 until round 3: 1.9 % of the buckets overflowed and every probe they left
+                                          // open went to the complete path -- 0.64 of the directory path's 7.4 ms per 10^8 queries; at 1.0: 0.4 %)
 
 struct directory_view {
     uint64_t const* buckets;  // 4 words per bucket

@@ -89,10 +89,15 @@ def _family_strings(gen, device, families: int, copies: int, length: int, diverg
         F = min(per, families - done)
         done += F
         if core > 0:
-            rows = torch.randint(0, 4, (F, copies, length), generator=gen, device=device, dtype=torch.uint8)
+            # drawn on the CPU whatever the device: which cores become the largest buckets is a matter of their hash, the few
+            # large core families were chosen seed by seed for that (calibrate_repeats.py TAIL_TUNING), and a CUDA generator
+            # would draw other cores from the same seed
+            cpu_gen = torch.Generator()
+            cpu_gen.manual_seed(gen.initial_seed() + 31 * done)
+            rows = torch.randint(0, 4, (F, copies, length), generator=cpu_gen, dtype=torch.uint8)
             at = (length - core) // 2
-            rows[:, :, at:at + core] = torch.randint(0, 4, (F, 1, core), generator=gen, device=device, dtype=torch.uint8)
-            rows = rows.reshape(F * copies, length)
+            rows[:, :, at:at + core] = torch.randint(0, 4, (F, 1, core), generator=cpu_gen, dtype=torch.uint8)
+            rows = rows.reshape(F * copies, length).to(device)
         else:
             cons = torch.randint(0, 4, (F, 1, length), generator=gen, device=device, dtype=torch.uint8)
             rows = cons.expand(F, copies, length).reshape(F * copies, length).clone()

@@ -42,10 +42,14 @@ class SyntheticCase:
     def __init__(self, tmpdir, name, bases, k, m, canonical, mean_len):
         import sshash_amd
         from oracle import oracle as O
+        from sshash_amd.repeats import make_recipe_spss
         from sshash_amd.synthetic import make_spss
 
         self.k, self.m, self.W = k, m, 1 if k <= 31 else 2
-        self.words, self.endpoints = make_spss(bases, k=k, m=m, mean_len=mean_len, seed=4242)
+        if k <= 31:  # the bench's own stand-ins (repeat families fitted to the published bucket statistics), at reduced size
+            self.words, self.endpoints = make_recipe_spss("se_k31" if mean_len < 100 else "human_k31", bases, seed=4242)
+        else:
+            self.words, self.endpoints = make_spss(bases, k=k, m=m, mean_len=mean_len, seed=4242)
         self.dict = sshash_amd.Dictionary.build_from_packed(self.words, self.endpoints, k=k, m=m, canonical=canonical, num_threads=0)
         self.path = os.path.join(tmpdir, name + ".sshash")
         self.dict.save(self.path)
@@ -181,8 +185,8 @@ def test_full_size_human_scale_dictionary_properties():
     import bench
     from sshash_amd.synthetic import revcomp_device
 
-    bases, mean_len, _, _ = bench.WORKLOADS["c3"]
-    args = argparse.Namespace(bases=bases, k=31, m=21, mean_len=mean_len, canonical=False, seed=0x5555AAAA,
+    bases, recipe, _, _ = bench.WORKLOADS["c3"]
+    args = argparse.Namespace(bases=bases, k=31, m=21, recipe=recipe, repeat_scale=1.0, canonical=False, seed=0x5555AAAA,
                               cache_dir=os.environ.get("SSHASH_BENCH_CACHE", "/tmp"), verbose=False)
     d, _ = bench.get_index(args, 0, 1, lambda: None)
     d.to_device(0)
