@@ -417,6 +417,8 @@ struct pass_queues {
        reference's flag depends on which arbitrary bucket the MPHF lands on): misses are queued with DEFER_FLAG_ONLY set
        and the last pass stores that one byte for them */
     uint32_t flag_misses;
+    /* k <= 31: the first pass finishes every probe itself (sk_lookup_in_wave); the resume queue stays empty */
+    uint32_t finish_in_wave;
 };
 constexpr uint32_t DEFER_FLAG_ONLY = 1u << 31;  // in a deferred-queue entry (query indices stay below 2^27)
 
@@ -490,8 +492,14 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
     const uint32_t shard = blockIdx.x & (DEFER_SHARDS - 1);  // the queues are sharded by workgroup: one hot counter would
                                                              // serialise at ~90 atomics/us
     if constexpr (SK) {
-        r = sk_first_pass_wave<W>(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1),
-                                  lds + (threadIdx.x >> 6) * (64 * 4));
+        bool whole = false;
+        if constexpr (W == 1) whole = q.finish_in_wave != 0;  // uniform
+        if constexpr (W == 1) {
+            if (whole) r = sk_lookup_in_wave(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1), lds + (threadIdx.x >> 6) * (64 * 4));
+        }
+        if (!whole)
+            r = sk_first_pass_wave<W>(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1),
+                                      lds + (threadIdx.x >> 6) * (64 * 4));
         /* whatever needs a second dependent read joins the compacted second pass, with its packed k-mer (no lane leaves
            before this: the queue places are handed out per wave) */
         bool resume = active && r.outcome == FAST_CONTINUE;
@@ -791,6 +799,16 @@ static bool overlap_tail_passes() {
 }
 constexpr uint64_t OVERLAP_PIECES = 4, OVERLAP_MIN_QUERIES = uint64_t(1) << 22;
 
+/* k <= 31: probes that need more than their first bucket are finished inside the first pass (lookup_device.hpp:
+   sk_finish_in_wave); SSHASH_AMD_INWAVE=0 sends them to the resume pass instead (the round-2 form; k <= 63 always does) */
+static bool finish_in_wave() {
+    static const bool on = [] {
+        const char* e = std::getenv("SSHASH_AMD_INWAVE");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 template <int W, bool CANON, int MODE, bool ASCII>
 static void launch(device_replica const* rep, void const* q, uint64_t n, bool check_rc,
                    result_view const& out, uint8_t* member, hipStream_t stream, uint8_t const* lane_valid) {
@@ -833,6 +851,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 const uint32_t set = overlap ? uint32_t(index & 1) : 0u;
                 pass_queues pq = shape;
                 pq.flag_misses = wants_flag ? 1u : 0u;
+                pq.finish_in_wave = (W == 1 && d.sk.enabled && finish_in_wave()) ? 1u : 0u;
                 char* scratch = static_cast<char*>(sc.block) + set * set_bytes;
                 if (overlap && index >= 2) HIP_CHECK(hipStreamWaitEvent(stream, sc.tail_done[set], 0));  // the set's queues are free again
                 HIP_CHECK(hipMemsetAsync(scratch, 0, 2 * DEFER_SHARDS * sizeof(uint32_t), stream));
@@ -858,7 +877,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                     HIP_CHECK(hipStreamWaitEvent(sc.aux, sc.first_done[set], 0));
                     tail = sc.aux;
                 }
-                if (d.sk.enabled)
+                if (d.sk.enabled && !pq.finish_in_wave)
                     hipLaunchKernelGGL((resume_lookup_kernel<W, CANON, MODE>), dim3(DEFER_SHARDS * RESUME_PARTS), dim3(block), 0, tail, d,
                                        check_rc, ids, mem, pq);
                 if (!d.sk.enabled)

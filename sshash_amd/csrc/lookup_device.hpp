@@ -882,6 +882,76 @@ __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<
     return r;
 }
 
+/* The lanes of a wave that need ANOTHER bucket after the first (a twentieth of them: the key's first bucket was full when it
+   was placed, or the key is heavy), served inside the wave that owns them -- k <= 31. The quads of the wave become fetch units: the
+   needy lanes are ranked with a ballot, needy lane number q (up to 16 a turn) posts its bucket's index for quad q, ONE load
+   instruction of all 64 lanes fetches those lines (16 bytes a lane: one request and one translation a line, as in the first
+   fetch; quads without a customer fetch bucket 0, an L2 hit), the pieces land in LDS and the owners examine their lines. No
+   queue entry written and read back, no second kernel, and above all no placeholder id that a later pass rewrites: an 8-byte
+   store into a line that has left the caches costs the DRAM a masked write -- a random access of its own, one of the 2.5 a
+   resumed query cost in the resume pass. */
+__device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<1> const& x, kmer_w<1> const& x_rc, sk_key_t const& kk, sk_walk_t& w,
+                                                  sk_query_t<1>& Q, fast_t& r, bool need, uint4* wave_stage) {
+    const uint32_t lane = threadIdx.x & 63u;
+    char const* slots = static_cast<char const*>(d.sk.slots);
+    uint32_t* posted = reinterpret_cast<uint32_t*>(wave_stage + 64);  // 16 bucket indices, behind the 64 pieces of the fetched lines
+#pragma unroll 1
+    for (;;) {
+        const uint64_t mask = __ballot(need);
+        if (mask == 0) break;  // wave-uniform
+        const uint32_t rank = uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
+        const bool served = need && rank < 16;
+        if (lane < 16) posted[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (served) posted[rank] = sk_choice(w.h, w.c);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t b = posted[lane >> 2];
+        wave_stage[lane] = sk_load_piece(slots + uint64_t(b) * 64 + 16 * (lane & 3u));  // quad q's line at wave_stage[4q .. 4q+3]
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (served) {
+            const uint4* mine = wave_stage + 4 * rank;
+            sk_bucket_flags flags;
+            flags.go_on = 0;
+            flags.second_used = false;
+            bool marker = false, key_seen = false;
+            sk_examine_slot<1, true>(d, Q, w.c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
+            sk_examine_slot<1, false>(d, Q, w.c, [mine](uint32_t i) { return mine[2 + i]; }, r, key_seen, marker, flags);
+            const uint32_t go_on = flags.go_on;
+            need = sk_walk_step<1>(d, x, x_rc, kk, w, Q, r, go_on, marker);
+        }
+        __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next turn
+    }
+}
+
+/* The whole table lookup of a wave in one call: the first bucket by all lanes (sk_probe_bucket_wave), whatever is left by
+   sk_finish_in_wave. Returns FAST_HIT / FAST_MISS (final) / FAST_DEFER; same arguments as sk_first_pass_wave. */
+__device__ __forceinline__ fast_t sk_lookup_in_wave(dict_view const& d, kmer_w<1> const& x, bool active, bool allow_rc, int8_t miss_orientation,
+                                                    uint4* wave_stage) {
+    const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
+    const sk_key_t kk = sk_key<1>(x, x_rc, d.k, d.m);
+    const bool usable = active && sk_usable(d, kk);
+    sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), 0);
+    sk_query_t<1> Q = sk_make_query<1>(x, x_rc, kk, w.h.fingerprint);
+    fast_t r = fast_unsettled(active && !usable);
+    uint32_t go_on = 0;
+    bool marker = false, key_seen = false;
+    sk_probe_bucket_wave<1>(d, Q, usable ? w.h.bucket[0] : 0u, 0u, usable, wave_stage, r, key_seen, marker, go_on);
+    bool need = false;
+    if (usable) need = sk_walk_step<1>(d, x, x_rc, kk, w, Q, r, go_on, marker);
+    sk_finish_in_wave(d, x, x_rc, kk, w, Q, r, need, wave_stage);
+    if (usable && (r.outcome == FAST_MISS || (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc))) {
+        r = fast_unsettled(false);
+        r.orientation = miss_orientation;
+    }
+    return r;
+}
+
 /* Second pass: a queue entry of the first pass, walked to the end. Same contract; never returns FAST_CONTINUE. */
 template <int W>
 __device__ __forceinline__ fast_t sk_second_pass_wave(dict_view const& d, kmer_w<W> const& x, bool active, uint32_t entry, bool allow_rc,

@@ -76,7 +76,7 @@ def _canonical_kmers(codes, k: int):
 
 
 def _family_strings(gen, device, families: int, copies: int, length: int, divergence: float, k: int, core: int = 0,
-                    max_kmers: int = 1 << 25):
+                    max_kmers: int = 1 << 25, salt: int = 0):
     """-> (codes uint8 1-D, lengths int64 1-D): the strings left of `families` families after de-duplication.
     core > 0: the copies of a family are unrelated random strings sharing only `core` consecutive bases (in the middle)
     instead of diverged copies of one consensus."""
@@ -93,7 +93,9 @@ def _family_strings(gen, device, families: int, copies: int, length: int, diverg
             # large core families were chosen seed by seed for that (calibrate_repeats.py TAIL_TUNING), and a CUDA generator
             # would draw other cores from the same seed
             cpu_gen = torch.Generator()
-            cpu_gen.manual_seed(gen.initial_seed() + 31 * done)
+            # (`salt` tells the calls of one class apart: the whole families and the fractional one must not draw the same
+            # flanks -- they did at --repeat-scale 0.5, and bench.py's oracle check found the duplicated k-mers)
+            cpu_gen.manual_seed((gen.initial_seed() * 4 + salt) * 1009 + 31 * done)
             rows = torch.randint(0, 4, (F, copies, length), generator=cpu_gen, dtype=torch.uint8)
             at = (length - core) // 2
             rows[:, :, at:at + core] = torch.randint(0, 4, (F, 1, core), generator=cpu_gen, dtype=torch.uint8)
@@ -196,11 +198,11 @@ def make_repeat_spss(num_bases: int, k: int = 31, classes=(), seed: int = 0x5555
         part = int(round((want - int(want)) * copies))
         if part >= 2:
             todo.append((1, part))
-        for F, n in todo:
+        for call, (F, n) in enumerate(todo):
             if F == 0:
                 continue
             codes, lens = _family_strings(gen, dev, F, n, int(c["length"]), float(c.get("divergence", 0.0)), k,
-                                          core=int(c.get("core", 0)))
+                                          core=int(c.get("core", 0)), salt=call)
             parts_codes.append(codes.cpu())
             parts_lens.append(lens.cpu())
             used += int(codes.numel())

@@ -93,7 +93,8 @@ def test_repeat_family_spss_is_a_set_and_reports_the_builders_statistics():
     k, m = 31, 21
     classes = [{"copies": 2, "length": 300, "divergence": 0.02, "families": 300},
                {"copies": 40, "length": 150, "divergence": 0.1, "families": 10},
-               {"copies": 300, "length": 120, "core": 23, "families": 3.5}]
+               {"copies": 300, "length": 120, "core": 23, "families": 3.5},
+               {"copies": 200, "length": 120, "core": 21, "families": 1.8}]  # one whole family + a fractional one: distinct flanks
     words, ends = make_repeat_spss(1_500_000, k=k, classes=classes, reference_bases=1_500_000, seed=11, device="cpu")
     w2, e2 = make_repeat_spss(1_500_000, k=k, classes=classes, reference_bases=1_500_000, seed=11, device="cpu")
     assert (words == w2).all() and (ends == e2).all()  # deterministic

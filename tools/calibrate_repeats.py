@@ -58,11 +58,11 @@ TARGETS = {
 # dozen class seeds each (tools/tune_repeat_tail.py) and the combination closest to the published tail was written down here.
 TAIL_TUNING = {
     "human_k31": {
-        "class_seeds": {(11264, 21): 106, (15930, 21): 104, (22528, 21): 109},
-        "extra_classes": [{"copies": 30000, "length": 120, "core": 21, "families": 1.0, "seed": 318,
-                           "note": "the largest bucket: one family whose core wins its windows (max bucket 25 040 alone)"}],
+        "class_seeds": {(11264, 21): 106, (15930, 21): 105, (22528, 21): 111},
+        "extra_classes": [{"copies": 30000, "length": 120, "core": 21, "families": 1.0, "seed": 305,
+                           "note": "the largest bucket: one family whose core wins its windows (max bucket 21 087 alone)"}],
     },
-    "se_k31": {"class_seeds": {(11264, 26): 104, (22528, 23): 107}},
+    "se_k31": {"class_seeds": {(11264, 26): 104, (22528, 23): 103}},
 }
 
 
