@@ -535,6 +535,16 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
     /* every remaining lane stores first (a deferred or resumed lane's value is a placeholder that a later pass
        overwrites), the deferred-queue push comes last */
     if constexpr (MODE == int(out_mode::member)) {
+        {
+            /* The position fields are dead here, and hipcc 7.2 builds a wrong kernel once it may drop them: with the probes
+               finished inside the first pass (sk_finish_in_wave) this instance reported 0.15 % of the indexed k-mers absent,
+               differently from launch to launch, while the id-returning instance of the very same code never did
+               (tools/debug/member_mismatch.py; round 2 met the same ghost in its is_member instances and blamed the
+               LDS-DMA path it was trying). Keeping the fields alive up to here costs three registers and cures it; the
+               parity tests run every k-mer of every fixture through this instance. */
+            uint32_t lo = uint32_t(r.kmer_offset), hi = uint32_t(r.kmer_offset >> 32), sid = r.string_id;
+            asm volatile("" : : "v"(lo), "v"(hi), "v"(sid));
+        }
         __builtin_nontemporal_store(uint8_t(r.outcome == FAST_HIT ? 1 : 0), member + i);
     } else {
         hit_t h;

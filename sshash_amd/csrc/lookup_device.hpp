@@ -925,7 +925,10 @@ __device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<1> 
             const uint32_t go_on = flags.go_on;
             need = sk_walk_step<1>(d, x, x_rc, kk, w, Q, r, go_on, marker);
         }
-        __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next turn
+        /* the staging area is rewritten by the next turn */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -942,6 +945,9 @@ __device__ __forceinline__ fast_t sk_lookup_in_wave(dict_view const& d, kmer_w<1
     uint32_t go_on = 0;
     bool marker = false, key_seen = false;
     sk_probe_bucket_wave<1>(d, Q, usable ? w.h.bucket[0] : 0u, 0u, usable, wave_stage, r, key_seen, marker, go_on);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     bool need = false;
     if (usable) need = sk_walk_step<1>(d, x, x_rc, kk, w, Q, r, go_on, marker);
     sk_finish_in_wave(d, x, x_rc, kk, w, Q, r, need, wave_stage);
