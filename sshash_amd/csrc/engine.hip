@@ -493,8 +493,8 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
                                                              // serialise at ~90 atomics/us
     if constexpr (SK) {
         bool whole = false;
-        if constexpr (W == 1) whole = q.finish_in_wave != 0;  // uniform
         if constexpr (W == 1) {
+            whole = q.finish_in_wave != 0;  // uniform
             if (whole) r = sk_lookup_in_wave(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1), lds + (threadIdx.x >> 6) * (64 * 4));
         }
         if (!whole)
@@ -539,9 +539,10 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
             /* The position fields are dead here, and hipcc 7.2 builds a wrong kernel once it may drop them: with the probes
                finished inside the first pass (sk_finish_in_wave) this instance reported 0.15 % of the indexed k-mers absent,
                differently from launch to launch, while the id-returning instance of the very same code never did
-               (tools/debug/member_mismatch.py; round 2 met the same ghost in its is_member instances and blamed the
-               LDS-DMA path it was trying). Keeping the fields alive up to here costs three registers and cures it; the
-               parity tests run every k-mer of every fixture through this instance. */
+               (tools/debug/member_mismatch.py; explicit s_waitcnt at every LDS hand-over changed nothing; round 2 met the same
+               ghost in its is_member instances and blamed the LDS-DMA path it was trying). Keeping the fields alive up to
+               here costs three registers and cures it; the parity tests run every k-mer of every fixture and of both bench
+               stand-ins through this instance. */
             uint32_t lo = uint32_t(r.kmer_offset), hi = uint32_t(r.kmer_offset >> 32), sid = r.string_id;
             asm volatile("" : : "v"(lo), "v"(hi), "v"(sid));
         }

@@ -883,13 +883,26 @@ __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<
 }
 
 /* The lanes of a wave that need ANOTHER bucket after the first (a twentieth of them: the key's first bucket was full when it
-   was placed, or the key is heavy), served inside the wave that owns them -- k <= 31. The quads of the wave become fetch units: the
+   was placed, or the key is heavy), served inside the wave that owns them. The quads of the wave become fetch units: the
    needy lanes are ranked with a ballot, needy lane number q (up to 16 a turn) posts its bucket's index for quad q, ONE load
    instruction of all 64 lanes fetches those lines (16 bytes a lane: one request and one translation a line, as in the first
    fetch; quads without a customer fetch bucket 0, an L2 hit), the pieces land in LDS and the owners examine their lines. No
    queue entry written and read back, no second kernel, and above all no placeholder id that a later pass rewrites: an 8-byte
    store into a line that has left the caches costs the DRAM a masked write -- a random access of its own, one of the 2.5 a
    resumed query cost in the resume pass. */
+/* Between two phases of a wave that talk through LDS: everything this lane has issued has completed, and the compiler moves
+   no memory operation across. (The "wavefront" fences used elsewhere in this file order the accesses for the compiler and rely on
+   the hardware executing a wave's DS instructions in order; here an LDS word written by one lane steers a GLOBAL load of another
+   and the loaded line goes back through LDS -- the explicit wait is what made every instance of these kernels agree with the
+   oracle launch after launch, tools/debug/member_mismatch.py.) */
+__device__ __forceinline__ void sk_wave_sync() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+/* k <= 31 only: at k <= 63 the first pass is bound by its instructions, not by memory, and carrying this loop cost it 6 %
+   (28.3 -> 26.7 G lookups/s, profiles/r03/inwave_ab_k63.txt): there the stragglers keep their own pass. */
 __device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<1> const& x, kmer_w<1> const& x_rc, sk_key_t const& kk, sk_walk_t& w,
                                                   sk_query_t<1>& Q, fast_t& r, bool need, uint4* wave_stage) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -902,18 +915,12 @@ __device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<1> 
         const uint32_t rank = uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
         const bool served = need && rank < 16;
         if (lane < 16) posted[lane] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sk_wave_sync();
         if (served) posted[rank] = sk_choice(w.h, w.c);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sk_wave_sync();
         const uint32_t b = posted[lane >> 2];
         wave_stage[lane] = sk_load_piece(slots + uint64_t(b) * 64 + 16 * (lane & 3u));  // quad q's line at wave_stage[4q .. 4q+3]
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sk_wave_sync();
         if (served) {
             const uint4* mine = wave_stage + 4 * rank;
             sk_bucket_flags flags;
@@ -925,10 +932,7 @@ __device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<1> 
             const uint32_t go_on = flags.go_on;
             need = sk_walk_step<1>(d, x, x_rc, kk, w, Q, r, go_on, marker);
         }
-        /* the staging area is rewritten by the next turn */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sk_wave_sync();  // the staging area is rewritten by the next turn
     }
 }
 
@@ -945,9 +949,7 @@ __device__ __forceinline__ fast_t sk_lookup_in_wave(dict_view const& d, kmer_w<1
     uint32_t go_on = 0;
     bool marker = false, key_seen = false;
     sk_probe_bucket_wave<1>(d, Q, usable ? w.h.bucket[0] : 0u, 0u, usable, wave_stage, r, key_seen, marker, go_on);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    sk_wave_sync();
     bool need = false;
     if (usable) need = sk_walk_step<1>(d, x, x_rc, kk, w, Q, r, go_on, marker);
     sk_finish_in_wave(d, x, x_rc, kk, w, Q, r, need, wave_stage);
