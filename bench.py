@@ -447,9 +447,11 @@ def main():
         traffic, provenance = traffic_record(d, n, args)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_provenance": provenance,
-                    "kernel": "fast_lookup_kernel<W=%d,canonical=%d,ids,%s> + resume_lookup_kernel + deferred_lookup_kernel (%d launch "
+                    "kernel": "fast_lookup_kernel<W=%d,canonical=%d,ids,%s> (%s) + deferred_lookup_kernel (%d launch "
                               "sequence(s) of equal size per step; avg_kernel_ms = HIP-event time around one step, on the launch stream)"
-                              % (W, int(d.canonical()), "super-k-mer table" if stats["sk_slots"] else "directory", pieces),
+                              % (W, int(d.canonical()), "super-k-mer table" if stats["sk_slots"] else "directory / MPHF",
+                                 ("every probe finished inside the first pass" if W == 1 else "+ resume_lookup_kernel") if stats["sk_slots"]
+                                 else "+ scan_lookup_kernel", pieces),
                     "launches_per_step": pieces,
                     "algorithmic_bytes_per_lookup": round(bytes_per_lookup, 2),
                     "algorithmic_bytes_rule": "SURVEY 8(d): 8 B per distinct 64-bit index word the REFERENCE algorithm dereferences "

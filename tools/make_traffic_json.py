@@ -11,6 +11,8 @@ import sys
 src, kept = sys.argv[1], sys.argv[2]
 s = json.load(open(src + "/summary.json"))
 bench = json.loads(open(src + "/bench.jsonl").read().strip().splitlines()[-1])
+if len(sys.argv) <= 3:
+    sys.argv.append(str(bench["config"].get("num_bases", 2_813_192_630)))
 pl, ks = s["per_launch_counter_averages"], s["kernel_stats"]
 launches = bench["roofline"]["launches_per_step"]
 
@@ -19,17 +21,17 @@ def bytes_of(d):
     return d["TCC_EA0_RDREQ_sum"] * 64 + d["TCC_EA0_WRREQ_64B_sum"] * 64 + (d["TCC_EA0_WRREQ_sum"] - d["TCC_EA0_WRREQ_64B_sum"]) * 32
 
 
-per_seq = {k: bytes_of(pl[k]) for k in ("fast", "resume", "deferred")}
+per_seq = {k: bytes_of(pl[k]) for k in ("fast", "resume", "deferred") if k in pl and "TCC_EA0_RDREQ_sum" in pl[k]}  # (no resume pass since round 3)
 total = int(sum(per_seq.values()) * launches)
 n = bench["config"]["queries_per_gpu"]
 requests = sum(pl[k]["TCC_EA0_RDREQ_sum"] + pl[k]["TCC_EA0_WRREQ_sum"] for k in per_seq) * launches
 rec = {
     "workload": bench["config"]["workload"],
-    "queries": n, "bases": int(sys.argv[3]) if len(sys.argv) > 3 else 2_813_553_873,  # bench.py --bases (default: the C3 workload's)
+    "queries": n, "bases": int(sys.argv[3]) if len(sys.argv) > 3 else 2_813_192_630,  # bench.py --bases (default: the C3 workload's)
     "canonical": bench["config"]["canonical"], "k": bench["config"]["k"],
     "hbm_bytes_per_launch": total,
     "hbm_requests_per_lookup": round(requests / n, 4),
-    "unit_note": "bytes per STEP (%d launch sequences) = %d x sum over the first / resume / deferred kernels of [TCC_EA0_RDREQ_sum x 64 B + "
+    "unit_note": "bytes per STEP (%d launch sequences) = %d x sum over the lookup kernels of one launch sequence (first pass, deferred pass; a resume pass until round 2) of [TCC_EA0_RDREQ_sum x 64 B + "
                  "TCC_EA0_WRREQ_64B_sum x 64 B + (TCC_EA0_WRREQ_sum - TCC_EA0_WRREQ_64B_sum) x 32 B], averages per launch; TCC_EA0_RDREQ_32B_sum = 0 "
                  "(every read request is 64 bytes); random 64-byte requests are counted once (calibrated with tools/tlb_probe: 2^27 random lines -> "
                  "1.342e8 RDREQ), so no x2 correction for this access pattern; the coalesced query/id streams (16 B per lookup) may be under-counted "
@@ -37,7 +39,7 @@ rec = {
     "per_launch_sequence_bytes": {k: int(v) for k, v in per_seq.items()},
     "per_launch_counters": {k: {c: int(v) for c, v in pl[k].items() if c.startswith(("TCC", "TCP"))} for k in pl},
     "kernel_avg_ns": {k: ks[k]["avg_ns"] for k in ks},
-    "counters": "rocprofv3 --pmc, one group per pass (tools/jobs/r02_profile.sh)",
+    "counters": "rocprofv3 --pmc, one group per pass (tools/jobs/r03_profile.sh)",
     "commit": subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip(),
     "source": kept,
 }
