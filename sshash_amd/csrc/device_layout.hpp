@@ -222,7 +222,11 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_buckets) {
     const uint64_t c = (a + b) * 0xD6E8FEB86659FD93ULL;
     h.bucket[3] = mulhi32(uint32_t(c), num_buckets);
     h.bucket[4] = mulhi32(uint32_t((c ^ (c >> 31)) * 0x9E3779B1u + uint32_t(a)), num_buckets);
-    h.fingerprint = uint32_t(c >> 40);
+    /* out of `a` alone (its low 24 bits; bucket[0] comes out of its high 32): the first pass needs bucket[0] and the fingerprint
+       only, and with the fingerprint taken from `c` (rounds 1-2) it had to compute b and c -- three 64-bit multiplies, a dozen
+       VALU instructions each -- for every query, although only the twentieth that goes on ever looks at the other buckets. At
+       k <= 63 the first pass is bound by its instructions. */
+    h.fingerprint = uint32_t(a) & 0xFFFFFFu;
     return h;
 }
 

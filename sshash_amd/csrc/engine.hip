@@ -352,15 +352,7 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
         v.weight_starts = rep->put(idx.weight_starts);
         v.weight_values = rep->put(idx.weight_values);
     }
-    {
-        /* the stream-ordered scratch of the batched calls (hipMallocAsync: streaming lookup, sharded lookup, neighbours)
-           comes out of the device's default memory pool; by default the pool hands everything back to the driver at the
-           next synchronisation, and every other call then pays for gigabytes of fresh allocation (13 vs 190-260 ms per
-           3 x 10^8-base streaming lookup). Keep what has been used. */
-        hipMemPool_t pool = nullptr;
-        uint64_t keep = ~uint64_t(0);
-        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    }
+    rep->create_scratch_pool();
     if (const uint64_t budget = hbm_budget(); budget && rep->bytes > budget)
         throw error(error_kind::no_device, "the replica needs " + std::to_string(rep->bytes) + " bytes of HBM, SSHASH_AMD_HBM_BUDGET allows " +
                                                std::to_string(budget) + ": partition the dictionary (minimizer shards, table shards)");
@@ -989,7 +981,7 @@ void engine::neighbours_packed_device(int device, uint64_t const* d_kmers, uint6
     const uint32_t W = rep->view.k <= 31 ? 1 : 2;
     check_single_launch(8 * n, "kmer_neighbours");
     uint64_t* expanded = nullptr;
-    HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&expanded), 8 * n * W * sizeof(uint64_t), s));
+    expanded = static_cast<uint64_t*>(rep->stream_alloc(8 * n * W * sizeof(uint64_t), s));
     const dim3 grid(uint32_t((8 * n + 255) / 256)), block(256);
     if (W == 1) hipLaunchKernelGGL(expand_neighbours_kernel<1>, grid, block, 0, s, d_kmers, n, rep->view.k, expanded);
     else hipLaunchKernelGGL(expand_neighbours_kernel<2>, grid, block, 0, s, d_kmers, n, rep->view.k, expanded);

@@ -52,6 +52,32 @@ struct device_replica {
        [0..9) keys per bin, [9..18) occurrences (= super-k-mers) per bin; [18] super-k-mers, [19] slots asked for */
     uint64_t sk_histogram[20] = {0};
     std::vector<void*> allocations;
+    /* Stream-ordered scratch of the batched calls (streaming lookup, sharded lookup, neighbours) comes out of a memory pool of
+       this replica's own, which keeps what it has used (a pool hands everything back to the driver at the next
+       synchronisation by default: 13 vs 190-260 ms per 3 x 10^8-base streaming lookup). Round 2 raised the threshold of the
+       DEVICE'S DEFAULT pool instead -- a process-wide side effect on the embedding application, whose own hipMallocAsync
+       blocks were then never returned either. */
+    hipMemPool_t scratch_pool = nullptr;
+    void create_scratch_pool() {
+        hipMemPoolProps props{};
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = device;
+        if (hipMemPoolCreate(&scratch_pool, &props) != hipSuccess) {
+            scratch_pool = nullptr;  // (fall back to the default pool with its default behaviour)
+            (void)hipGetLastError();
+            return;
+        }
+        uint64_t keep = ~uint64_t(0);
+        (void)hipMemPoolSetAttribute(scratch_pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    void* stream_alloc(size_t bytes, hipStream_t s) const {
+        void* p = nullptr;
+        if (scratch_pool) HIP_CHECK(hipMallocFromPoolAsync(&p, bytes ? bytes : 8, scratch_pool, s));
+        else HIP_CHECK(hipMallocAsync(&p, bytes ? bytes : 8, s));
+        return p;
+    }
 
     /* Per-stream scratch for the resume and deferred queues of the multi-pass lookup (engine.hip). Work on one stream is
        ordered, so a buffer keyed by the stream can be reused without synchronisation; it only grows
@@ -154,6 +180,10 @@ struct device_replica {
         if (hipGetDevice(&prev) != hipSuccess) return;
         (void)hipSetDevice(device);
         for (void* p : allocations) (void)hipFree(p);
+        if (scratch_pool) {
+            (void)hipDeviceSynchronize();  // (stream-ordered frees of this pool must have run)
+            (void)hipMemPoolDestroy(scratch_pool);
+        }
         for (auto& kv : scratch) kv.second.release();
         for (host_lane* lane : idle_lanes) {
             if (lane->pinned) (void)hipHostFree(lane->pinned);

@@ -19,13 +19,13 @@ namespace sshash_amd {
 
 namespace {
 
-struct stream_buffers {  // stream-ordered scratch, released on every exit path
+struct stream_buffers {  // stream-ordered scratch out of the replica's own pool, released on every exit path
     hipStream_t s;
+    device_replica const* rep;
     std::vector<void*> owned;
     template <typename T>
     T* get(uint64_t n) {
-        void* p = nullptr;
-        HIP_CHECK(hipMallocAsync(&p, std::max<uint64_t>(n, 1) * sizeof(T), s));
+        void* p = rep->stream_alloc(std::max<uint64_t>(n, 1) * sizeof(T), s);
         owned.push_back(p);
         return static_cast<T*>(p);
     }
@@ -48,7 +48,7 @@ void engine::sharded_lookup_device(int device, uint32_t num_ranks, bool by_table
     device_guard guard(device);
     hipStream_t s = hipStream_t(stream);
     const uint32_t W = rep->view.k <= 31 ? 1 : 2, R = num_ranks;
-    stream_buffers buf{s, {}};
+    stream_buffers buf{s, rep, {}};
 
     /* 1. route: messages per owner, then the messages themselves in per-owner regions (engine.hip: route_bucket_kernel) */
     uint64_t* d_cursors = buf.get<uint64_t>(R);

@@ -473,17 +473,17 @@ void engine::streaming_lookup_device(int device, char const* d_bases, uint64_t c
        leak them: ADVICE r2) */
     struct temporaries {
         hipStream_t s;
+        device_replica const* rep;
         std::vector<void*> owned;
         void* get(uint64_t bytes) {
-            void* p = nullptr;
-            HIP_CHECK(hipMallocAsync(&p, std::max<uint64_t>(bytes, 8), s));
+            void* p = rep->stream_alloc(std::max<uint64_t>(bytes, 8), s);
             owned.push_back(p);
             return p;
         }
         ~temporaries() {
             for (void* p : owned) (void)hipFreeAsync(p, s);
         }
-    } tmp{s, {}};
+    } tmp{s, rep, {}};
     uint64_t* sid = d_out.string_id;
     int8_t* ori = d_out.kmer_orientation;
     uint64_t* ids = d_out.kmer_id;  // null: counters only (streaming_query_host over reads too long for one lane each)
