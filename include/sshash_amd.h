@@ -146,15 +146,16 @@ sshash_status sshash_device_table_histogram(const sshash_dict* d, int device, ui
  * *_device: `kmers` and every non-NULL array of `out` are DEVICE pointers in the HBM of `device`;
  *           the launch is asynchronous on `hip_stream` (hipStream_t as void*, NULL = default stream).
  * host variants: caller-owned host buffers; the batch is sharded over all resident devices. Page-locked buffers (hipHostMalloc /
- *           hipHostRegister; input AND every requested output) are copied from and to directly: 4.5 G lookups/s over PCIe
+ *           hipHostRegister; input AND every requested output) are copied from and to directly: 4.3 G lookups/s over PCIe
  *           against 1.5 G/s for pageable memory, which is staged through the library's own pinned lanes.
  * Cost of the fields: NULL arrays are skipped. kmer_id alone is answered by the device's super-k-mer table at full speed (DESIGN.md
- * section 6: 35-39 G lookups/s); the position fields come from the same probe (all seven: 22 G/s at 50 % positives -- seven output
+ * section 6: 38-40 G lookups/s); the position fields come from the same probe (all seven: 25 G/s at 50 % positives -- seven output
  * streams, and string_begin / string_end cost a hit one more random read). `minimizer_found` is true for a hit; for a miss only the
  * MPHF can reproduce it -- the flag of an absent minimizer depends on which bucket the MPHF maps that minimizer to
  * (include/spectrum_preserving_string_set.hpp:46-65) --, so the misses of a batch that asks for it go through the MPHF path in a
- * last pass that stores that one byte (one probe: the reference's result for a miss is that of its last probe): 17 G/s at 100 %
- * positives, 15 at 50 %, 14 at 0 % (everything through the MPHF path, as a replica without the table does it: 9 / 10 / 12).                                                                            */
+ * last pass that stores that one byte (one probe: the reference's result for a miss is that of its last probe): 20 G/s at 100 %
+ * positives, 14 at 50 %, 11 at 0 %. The eight-field result is an extension: the reference's own comparator of lookup results ignores
+ * that flag (include/util.hpp:107-141), and for an absent minimizer its value is an artefact of this build's MPHF. */
 sshash_status sshash_lookup_packed_device(const sshash_dict* d, int device, const uint64_t* kmers, uint64_t n,
                                           int check_reverse_complement, const sshash_results* out, void* hip_stream);
 sshash_status sshash_lookup_ascii_device(const sshash_dict* d, int device, const char* kmers, uint64_t n,
