@@ -94,7 +94,7 @@ def _family_strings(gen, device, families: int, copies: int, length: int, diverg
             # would draw other cores from the same seed
             cpu_gen = torch.Generator()
             # (`salt` tells the calls of one class apart: the whole families and the fractional one must not draw the same
-            # flanks -- they did at --repeat-scale 0.5, and bench.py's oracle check found the duplicated k-mers)
+            # flanks -- they did at --repeat-scale 0.5, and bench.py's parity check found the duplicated k-mers)
             cpu_gen.manual_seed((gen.initial_seed() * 4 + salt) * 1009 + 31 * done)
             rows = torch.randint(0, 4, (F, copies, length), generator=cpu_gen, dtype=torch.uint8)
             at = (length - core) // 2
