@@ -893,8 +893,8 @@ __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<
 /* Between two phases of a wave that talk through LDS: everything this lane has issued has completed, and the compiler moves
    no memory operation across. (The "wavefront" fences used elsewhere in this file order the accesses for the compiler and rely on
    the hardware executing a wave's DS instructions in order; here an LDS word written by one lane steers a GLOBAL load of another
-   and the loaded line goes back through LDS -- the explicit wait is what made every instance of these kernels agree with the
-   oracle launch after launch, tools/debug/member_mismatch.py.) */
+   and the loaded line goes back through LDS -- the explicit wait keeps the hand-over independent of what the compiler infers about it,
+   tools/debug/member_mismatch.py.) */
 __device__ __forceinline__ void sk_wave_sync() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
