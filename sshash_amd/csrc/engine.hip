@@ -535,8 +535,10 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
                ghost in its is_member instances and blamed the LDS-DMA path it was trying). Keeping the fields alive up to
                here costs three registers and cures it; the parity tests run every k-mer of every fixture and of both bench
                stand-ins through this instance. */
+#ifndef SSHASH_DEBUG_NO_KEEPALIVE  // (tools/debug: build the failing variant)
             uint32_t lo = uint32_t(r.kmer_offset), hi = uint32_t(r.kmer_offset >> 32), sid = r.string_id;
             asm volatile("" : : "v"(lo), "v"(hi), "v"(sid));
+#endif
         }
         __builtin_nontemporal_store(uint8_t(r.outcome == FAST_HIT ? 1 : 0), member + i);
     } else {

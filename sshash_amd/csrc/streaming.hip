@@ -379,7 +379,9 @@ stream_encode_kernel(const char* __restrict__ bases, const uint64_t* __restrict_
     }
     uint8_t f = 0;
     kmer_w<W> x = kmer_zero<W>();
-    if (p + k <= end) {
+    /* (a place behind the last read's end -- the caller's total_bases exceeds read_offsets[num_reads] -- belongs to no read: no
+       k-mer starts there; ADVICE r2: it used to be looked up as part of one endless read) */
+    if (end != ~uint64_t(0) && p + k <= end) {
         const uint32_t cw = tid >> 4, cs = 2 * (tid & 15u);
         uint32_t word[2 * W];
         for (int j = 0; j < 2 * W; ++j) word[j] = __builtin_amdgcn_alignbit(codes[cw + j + 1], codes[cw + j], cs);

@@ -210,3 +210,66 @@ def test_counters_of_reads_too_long_for_one_lane(case_se_regular):
     got = _as_dict(d.streaming_query(reads))
     assert got == case.oracle.streaming_query(reads)
     assert got["num_extensions"] > 100000 and got["num_invalid_kmers"] > 0
+
+
+def test_streaming_lookup_host_keeps_every_array_at_places_without_a_kmer(case_se_regular):
+    """sshash_streaming_lookup copies every requested array back whole; at the places where no k-mer starts
+    (the last k - 1 bases of a read, reads shorter than k) the caller's values must survive for ALL fields, not for kmer_id only."""
+    import ctypes as C
+
+    from sshash_amd import _binding as B
+
+    case = case_se_regular
+    d = case.dict.to_device(0)
+    k = case.k
+    reads = [case.sequences[0][:150], "ACGTACGT", case.sequences[1][:k + 3], case.sequences[2][:90].lower()]
+    blob = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(r) for r in reads])
+    total = int(offsets[-1])
+    sentinel64, sentinel8 = np.uint64(0x1234567890ABCDEF), np.int8(77)
+    arrays = {f: np.full(total, sentinel64, dtype=np.uint64) for f in ("kmer_id", "kmer_id_in_string", "kmer_offset", "string_id", "string_begin", "string_end")}
+    arrays["kmer_orientation"] = np.full(total, sentinel8, dtype=np.int8)
+    r = B._Results()
+    for f, a in arrays.items():
+        setattr(r, f, a.ctypes.data)
+    rep = B._Report()
+    B._check(B._load().sshash_streaming_lookup(d._h, blob.ctypes.data, offsets.ctypes.data, len(reads), C.byref(r), C.byref(rep)))
+    places = np.zeros(total, dtype=bool)
+    for i, read in enumerate(reads):
+        lo, n = int(offsets[i]), max(0, len(read) - k + 1)
+        places[lo:lo + n] = True
+        want = case.oracle.streaming_read(read)
+        for f in ("kmer_id", "kmer_id_in_string", "kmer_offset", "string_id", "string_begin", "string_end"):
+            assert (arrays[f][lo:lo + n] == want[f]).all(), f
+    assert places.sum() == rep.num_kmers and (~places).sum() > 0
+    for f, a in arrays.items():
+        keep = sentinel8 if f == "kmer_orientation" else sentinel64
+        assert (a[~places] == keep).all(), f"{f}: a place without a k-mer was overwritten"
+
+
+def test_streaming_lookup_device_ignores_bases_behind_the_last_read(case_se_regular):
+    """total_bases larger than read_offsets[num_reads] -- the tail belongs to no read: no k-mer is looked up there,
+    nothing is counted, the caller's values stay."""
+    import torch
+
+    case = case_se_regular
+    d = case.dict.to_device(0)
+    k = case.k
+    reads = [case.sequences[0][:120], case.sequences[1][:80]]
+    tail = case.sequences[2][:300]  # perfectly good bases, but behind the last read's end
+    blob = ("".join(reads) + tail).encode()
+    offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(r) for r in reads])
+    dev = torch.device("cuda", 0)
+    d_bases = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    ids = torch.full((len(blob),), 4242, dtype=torch.int64, device=dev)
+    rep = torch.zeros(6, dtype=torch.int64, device=dev)
+    d.streaming_lookup_device(0, d_bases.data_ptr(), d_off.data_ptr(), len(reads), len(blob), ids.data_ptr(), d_report=rep.data_ptr())
+    torch.cuda.synchronize()
+    got = ids.cpu().numpy()
+    expect = sum(len(r) - k + 1 for r in reads)
+    assert int(rep[0].item()) == expect
+    assert (got[int(offsets[-1]):] == 4242).all()
+    assert (got[int(offsets[1]) - (k - 1):int(offsets[1])] == 4242).all()

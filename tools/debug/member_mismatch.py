@@ -1,5 +1,10 @@
 #!/usr/bin/env python
-"""Debug aid: is_member / lookup over EVERY k-mer of a stand-in, several launches, under the current environment switches."""
+"""Debug aid: is_member / lookup over EVERY k-mer of a stand-in, several launches, under the current environment switches.
+
+The hazard it was written for: with the probes finished inside the first pass, the is_member instance of
+fast_lookup_kernel -- whose position fields are dead -- reported 0.15 % of the indexed k-mers absent, differently from launch to
+launch. To reproduce, build the library with -DSSHASH_DEBUG_NO_KEEPALIVE (make -C sshash_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC
+-DSSHASH_DEBUG_NO_KEEPALIVE") and run:  python tools/debug/member_mismatch.py se_k31 20000000"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
