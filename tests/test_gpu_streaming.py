@@ -240,8 +240,10 @@ def test_streaming_lookup_host_keeps_every_array_at_places_without_a_kmer(case_s
         lo, n = int(offsets[i]), max(0, len(read) - k + 1)
         places[lo:lo + n] = True
         want = case.oracle.streaming_read(read)
-        for f in ("kmer_id", "kmer_id_in_string", "kmer_offset", "string_id", "string_begin", "string_end"):
+        for f in ("kmer_id", "kmer_id_in_string", "string_id", "string_begin", "string_end"):  # (equal_lookup_result's fields, as above)
             assert (arrays[f][lo:lo + n] == want[f]).all(), f
+        found = want["kmer_id"] != np.uint64(0xFFFFFFFFFFFFFFFF)
+        assert (arrays["kmer_offset"][lo:lo + n][found] == (want["string_begin"] + want["kmer_id_in_string"])[found]).all()
     assert places.sum() == rep.num_kmers and (~places).sum() > 0
     for f, a in arrays.items():
         keep = sentinel8 if f == "kmer_orientation" else sentinel64
