@@ -279,7 +279,10 @@ sshash_status sshash_route_combine_device(const sshash_dict* d, int device, cons
  *                send_counts[p] / recv_counts[p] elements of elem_bytes each (host arrays); it must be complete, or ordered
  *                on hip_stream, when it returns.
  *      sshash_sharded_lookup_rccl supplies them over an RCCL communicator (grouped ncclSend/ncclRecv: the all-to-all
- *      over xGMI); `nccl_comm` is an ncclComm_t whose rank r holds shard r. RCCL is resolved when first used. ---- */
+ *      over xGMI); `nccl_comm` is an ncclComm_t whose rank r holds shard r. RCCL is resolved when first used.
+ *      Like any collective, the call completes only if every rank makes it: a rank that fails before the exchange (an argument
+ *      error, an allocation failure: it returns its status without having called `counts`) leaves its peers waiting in theirs --
+ *      the host application's job control has to take the group down, as it would for a failed ncclAllReduce. ---- */
 typedef struct sshash_exchange {
     void* ctx;
     int (*counts)(void* ctx, const uint64_t* send, uint64_t* recv);

@@ -140,3 +140,58 @@ def test_malformed_weight_headers_are_rejected(tmp_path):
     p.write_text(">0 LN:i:35 ab:Z:7 7 9 9 7\n" + seq + "\n")
     d = sshash_amd.Dictionary.build(str(p), k=31, m=11, weighted=True)
     assert list(d.weight(range(5))) == [7, 7, 9, 9, 7]
+
+
+def test_bucket_statistics_against_an_independent_count(case_skew_regular, case_small_k):
+    """A7 pinned from outside the builder: minimizers recomputed here with numpy straight from the sequences (the reference's rule:
+    hash = (m-mer * 0x517cc1b727220a95) ^ magic, leftmost minimum, include/util.hpp:262-283, include/hash_util.hpp:91), a bucket =
+    the DISTINCT positions of one minimizer (include/builder/util.hpp:61-78), classes by size (1 / 2..64 / > 64, partitions
+    (64,128], (128,256] ...: src/builder/build_sparse_and_skew_index.cpp:141-147) -- against sshash_bucket_stats of the built index."""
+    from oracle import oracle as O
+    from oracle.ground_truth import encode_bases
+
+    for case in (case_skew_regular, case_small_k):
+        k, m = case.k, case.m
+        magic = O.xxh64_u64(1, 0)
+        positions = {}  # minimizer value -> set of absolute positions
+        kmers_of = {}   # minimizer value -> number of k-mers
+        base = 0
+        mask = (1 << (2 * m)) - 1
+        for s in case.sequences:
+            codes = encode_bases(s).astype(object)
+            mm = []
+            v = 0
+            for i, c in enumerate(codes):  # m-mers, first base in the low bits
+                v |= int(c) << (2 * min(i, m - 1)) if i < m else 0
+                if i >= m:
+                    v = (v >> 2) | (int(c) << (2 * (m - 1)))
+                if i >= m - 1:
+                    mm.append(v & mask)
+            hashes = [((x * 0x517CC1B727220A95) & ((1 << 64) - 1)) ^ magic for x in mm]
+            w = k - m + 1
+            for start in range(len(s) - k + 1):
+                window = hashes[start:start + w]
+                j = min(range(w), key=lambda t: (window[t], t))  # leftmost minimum
+                mini = mm[start + j]
+                positions.setdefault(mini, set()).add(base + start + j)
+                kmers_of[mini] = kmers_of.get(mini, 0) + 1
+            base += len(s)
+        sizes = {mini: len(p) for mini, p in positions.items()}
+        st = case.dict.bucket_stats()
+        assert st["num_minimizers"] == len(sizes)
+        assert st["num_minimizer_positions"] == sum(sizes.values())
+        assert st["buckets_with_n_positions"] == [sum(1 for v in sizes.values() if v == n) for n in range(1, 17)]
+        mid = [v for v in sizes.values() if 2 <= v <= 64]
+        heavy = {mini: v for mini, v in sizes.items() if v > 64}
+        assert st["num_buckets_larger_than_1_not_in_skew_index"] == len(mid) and st["num_minimizer_positions_of_buckets_larger_than_1"] == sum(mid)
+        assert st["num_buckets_in_skew_index"] == len(heavy) and st["num_minimizer_positions_of_buckets_in_skew_index"] == sum(heavy.values())
+        assert st["max_bucket_size"] == max(sizes.values())
+        assert st["num_kmers_in_skew_index"] == sum(kmers_of[mini] for mini in heavy)
+        if heavy:
+            parts = [0] * len(st["num_kmers_in_skew_partition"])
+            for mini, v in heavy.items():
+                p = 0
+                while p + 1 < len(parts) and v > (128 << p):
+                    p += 1
+                parts[p] += kmers_of[mini]
+            assert st["num_kmers_in_skew_partition"] == parts
