@@ -1,6 +1,7 @@
 // capi.cpp -- the C ABI declared in include/sshash_amd.h (thin shim over engine / index).
 #include <condition_variable>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -386,13 +387,21 @@ sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char*
                 t.join();
             }
         } join_reader{reader, mu, cv, abandon};
+        double waited = 0, worked = 0;  // SSHASH_AMD_VERBOSE: where the wall clock of the file query went
+        uint64_t batches = 0;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         for (int at = 0;; at ^= 1) {
+            const double t0 = now();
             {
                 std::unique_lock<std::mutex> lock(mu);
                 cv.wait(lock, [&] { return filled[at] != 0; });
                 if (filled[at] == 2) break;
             }
+            const double t1 = now();
             const streaming_report r = d->eng->streaming_query_host(slot[at].bases.data(), slot[at].offsets.data(), slot[at].num_reads());
+            waited += t1 - t0;
+            worked += now() - t1;
+            ++batches;
             report->num_kmers += r.num_kmers;
             report->num_positive_kmers += r.num_positive_kmers;
             report->num_negative_kmers += r.num_negative_kmers;
@@ -403,6 +412,9 @@ sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char*
             filled[at] = 0;
             cv.notify_all();
         }
+        if (std::getenv("SSHASH_AMD_VERBOSE"))
+            fprintf(stderr, "[sshash_amd] file query: %llu batches; waiting for the reader %.3f s, devices at work %.3f s\n",
+                    (unsigned long long)batches, waited, worked);
         if (reader_error) std::rethrow_exception(reader_error);
     });
 }
