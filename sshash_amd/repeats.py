@@ -186,10 +186,14 @@ def make_repeat_spss(num_bases: int, k: int = 31, classes=(), seed: int = 0x5555
     parts_codes, parts_lens = [], []
     used = 0
     for ci, c in enumerate(classes):
-        # every class draws from its own generator (seed, the class's "seed" field or its index): the realisation of a
+        # every class draws from its own generator (seed, the class's "seed" field or a number made of its parameters): the realisation of a
         # class does not depend on the classes before it, so the few largest families -- whose luck with the minimizer order
         # decides the largest buckets -- can be examined, and chosen, on their own (tools/calibrate_repeats.py --tune-tail)
-        gen.manual_seed((int(seed) * 1000003 + int(c.get("seed", ci)) * 7919 + 17) & 0x7FFFFFFFFFFFFFFF)
+        own = c.get("seed")
+        if own is None:  # from the class's parameters, not from its place in the list: a recipe refitted with one class more or
+            # less keeps the realisations of the others
+            own = (int(c["copies"]) * 131 + int(c["length"]) * 7 + int(round(float(c.get("divergence", 0.0)) * 1000)) * 3 + int(c.get("core", 0)) * 17) % 100003
+        gen.manual_seed((int(seed) * 1000003 + int(own) * 7919 + 17) & 0x7FFFFFFFFFFFFFFF)
         want = float(c["families"]) * scale
         copies = int(c["copies"])
         # floor(want) whole families, and the remaining fraction as ONE family with that fraction of the copies (a class

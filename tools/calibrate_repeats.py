@@ -174,6 +174,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("name", choices=sorted(TARGETS))
     ap.add_argument("--check-scale", type=float, default=0.1)
+    ap.add_argument("--feedback", default=None,
+                    help="a bench.py JSON line of the CURRENT recipe at full size: every target row is multiplied by target / achieved "
+                         "before the fit (one step of a fixed-point iteration: the per-class vectors are measured on one or a few "
+                         "families each, the stand-in holds other realisations of them)")
+    ap.add_argument("--freeze-cores", action="store_true",
+                    help="with --feedback: the core classes keep the amounts (and class seeds) of the current recipe -- the tail they "
+                         "realise was chosen seed by seed and must not move -- and only the diverged families and the background are refitted")
     ap.add_argument("--cache", default=os.path.join(ROOT, "tools", "calibrate_repeats_cache.json"))
     args = ap.parse_args()
     from scipy.optimize import nnls
@@ -182,6 +189,31 @@ def main():
     k, m = t["k"], t["m"]
     tv = target_vector(t)
     names = list(tv)
+    aim = dict(tv)  # what the fit aims at: the published numbers, corrected by what the last stand-in achieved
+    if args.feedback:
+        line = json.loads(open(args.feedback).read().strip().splitlines()[-1])
+        st = line["config"]["index_statistics"]
+        ach = {"num_kmers": st["num_kmers"]["achieved"], "num_strings": st["num_strings"]["achieved"],
+               "num_minimizers": st["num_minimizers"]["achieved"], "num_minimizer_positions": st["num_minimizer_positions"]["achieved"],
+               "num_buckets_larger_than_1_not_in_skew_index": st["num_buckets_larger_than_1_not_in_skew_index"]["achieved"],
+               "num_minimizer_positions_of_buckets_larger_than_1": st["num_minimizer_positions_of_buckets_larger_than_1"]["achieved"],
+               "num_buckets_in_skew_index": st["num_buckets_in_skew_index"]["achieved"],
+               "num_minimizer_positions_of_buckets_in_skew_index": st["num_minimizer_positions_of_buckets_in_skew_index"]["achieved"],
+               "num_kmers_in_skew_partition": [st[f"num_kmers_in_skew_partition_{p}"]["achieved"] for p in range(8)],
+               "buckets_with_n_positions": [st[f"buckets_with_{n}_positions"]["achieved"] for n in range(1, 17)]}
+        av = stats_vector(ach)
+        scale = st["scale"]
+        for n in names:
+            if av[n] > 0:
+                ratio = tv[n] * scale / av[n]
+                aim[n] = tv[n] * min(1.5, max(0.67, ratio))
+        # the recipe being corrected is the starting point: its own aim is carried along (corrections accumulate)
+        prev = os.path.join(ROOT, "sshash_amd", "recipes", args.name + ".json")
+        if os.path.exists(prev):
+            old = json.load(open(prev)).get("aim")
+            if old:
+                for n in names:
+                    aim[n] = old[n] * (aim[n] / tv[n])
     cache = {}
     if os.path.exists(args.cache):
         cache = json.load(open(args.cache))
@@ -208,7 +240,7 @@ def main():
         cols.append([cache[key]["v"][n] * 1e6 for n in names])  # unit: 10^6 bases
         meta.append({"background_mean_len": ml})
     A = np.array(cols, dtype=np.float64).T  # rows x classes
-    b = np.array([tv[n] for n in names], dtype=np.float64)
+    b = np.array([aim[n] for n in names], dtype=np.float64)
     # relative errors; the totals weigh more (they are what "the same size" means), the thin tail rows less
     wgt = np.ones(len(names))
     for i, n in enumerate(names):
@@ -216,12 +248,27 @@ def main():
             wgt[i] = 4.0
     Aw = A / b[:, None] * wgt[:, None]
     # (fractional amounts: the generator makes floor(x) whole families and one more with the remaining fraction of the copies)
-    x, rnorm = nnls(Aw, wgt, maxiter=50000)
+    frozen = {}
+    if args.freeze_cores:
+        old = json.load(open(os.path.join(ROOT, "sshash_amd", "recipes", args.name + ".json")))
+        frozen = {(c["copies"], c["length"], c["core"]): c["families"] for c in old["classes"] if "core" in c and "note" not in c}
+    fixed = np.zeros(A.shape[1])
+    is_fixed = np.zeros(A.shape[1], dtype=bool)
+    for i, mt in enumerate(meta):
+        if "core" in mt:
+            is_fixed[i] = bool(args.freeze_cores)
+            fixed[i] = frozen.get((mt["copies"], mt["length"], mt["core"]), 0.0)
+    if is_fixed.any():
+        xf, rnorm = nnls(Aw[:, ~is_fixed], wgt - Aw[:, is_fixed] @ fixed[is_fixed], maxiter=50000)
+        x = fixed.copy()
+        x[~is_fixed] = xf
+    else:
+        x, rnorm = nnls(Aw, wgt, maxiter=50000)
     # classes the fit left at zero drop out; whatever else is small was rounded above
     fit = A @ x
     print(f"NNLS residual {rnorm:.4f}; classes in use: {int((x > 0).sum())} of {len(x)}", file=sys.stderr)
     for n, tt, ff in zip(names, b, fit):
-        print(f"  {n:18s} target {tt:14.0f} fit {ff:14.0f} ({ff / tt - 1:+.1%})", file=sys.stderr)
+        print(f"  {n:18s} aim {tt:14.0f} (published {tv[n]:14.0f}) fit {ff:14.0f} ({ff / tt - 1:+.1%})", file=sys.stderr)
     recipe_classes, bg = [], []
     for xi, mt in zip(x, meta):
         if xi <= 0:
@@ -238,7 +285,7 @@ def main():
             c["seed"] = sd
     recipe_classes += tune.get("extra_classes", [])
     recipe = {"name": args.name, "k": k, "m": m, "target": t, "reference_bases": t["num_bases"], "classes": recipe_classes,
-              "background": bg, "fit": {n: float(f) for n, f in zip(names, fit)}}
+              "background": bg, "fit": {n: float(f) for n, f in zip(names, fit)}, "aim": {n: float(aim[n]) for n in names}}
     os.makedirs(os.path.join(ROOT, "sshash_amd", "recipes"), exist_ok=True)
     path = os.path.join(ROOT, "sshash_amd", "recipes", args.name + ".json")
     json.dump(recipe, open(path, "w"), indent=1)
