@@ -43,6 +43,9 @@ WORKLOADS = {
     "c3": (2_813_192_630, "human_k31", 1_000_000_000,
            "C3 stand-in: synthetic SPSS fitted to the bucket statistics the reference printed for human.k31 (repeat families + "
            "de-duplication, sshash_amd/repeats.py; target vs achieved in config.index_statistics)"),
+    "c4": (2_935_176_947, "human_k63", 1_000_000_000,
+           "C4-scale dictionary (BASELINE.json configs[3] is its streaming query): synthetic SPSS fitted to the bucket statistics the reference "
+           "printed for human.k63 (k=63 m=25: two-word k-mers)"),
     "c2": (1_387_536_274, "se_k31", 100_000_000,
            "C2 stand-in: synthetic SPSS fitted to the bucket statistics the reference printed for the S. enterica pangenome "
            "(sshash_amd/repeats.py; target vs achieved in config.index_statistics)"),
@@ -127,11 +130,11 @@ def make_standin(args):
     import torch
     from sshash_amd.repeats import load_recipe, make_repeat_spss
 
-    if args.k > 31:  # (the recipes are fitted at k = 31; the two-word k-mer runs keep the planted-motif generator)
+    r = load_recipe(args.recipe)
+    if (args.k > 31) != (int(r["k"]) > 31):  # (no recipe for this k-mer width: the planted-motif generator of rounds 1-2)
         from sshash_amd.synthetic import make_spss
 
         return make_spss(args.bases, k=args.k, m=args.m, seed=args.seed, mean_len=274.0)
-    r = load_recipe(args.recipe)
     classes = [dict(c, families=c["families"] * args.repeat_scale) for c in r["classes"]]
     background = r["background"]
     if args.repeat_scale != 1.0:
@@ -274,8 +277,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--bases", type=int, default=None, help="bases in the synthetic SPSS (default: the workload's)")
     ap.add_argument("--queries", type=int, default=None, help="queries in the batch, ALL GPUs together (default: the workload's)")
-    ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--m", type=int, default=21)
+    ap.add_argument("--k", type=int, default=None, help="default: the recipe's (31; 63 for --workload c4)")
+    ap.add_argument("--m", type=int, default=None, help="default: the recipe's (21; 25 for --workload c4)")
     ap.add_argument("--recipe", default=None, help="sshash_amd/recipes/<name>.json (default: the workload's)")
     ap.add_argument("--repeat-scale", type=float, default=1.0, help="multiply the amount of every repeat family of the recipe")
     ap.add_argument("--no-file-query", action="store_true", help="skip the end-to-end FASTQ query (side measurement, outside the timed region)")
@@ -301,6 +304,14 @@ def main():
         args.bases = bases
     if args.recipe is None:
         args.recipe = recipe
+    if args.k is None or args.m is None:
+        from sshash_amd.repeats import load_recipe
+
+        r = load_recipe(args.recipe)
+        args.k = r["k"] if args.k is None else args.k
+        args.m = r["m"] if args.m is None else args.m
+    if args.k > 31 and args.recipe.endswith("_k31") and os.path.exists(os.path.join(ROOT, "sshash_amd", "recipes", "human_k63.json")):
+        args.recipe = "human_k63"  # (`--k 63` on a k = 31 workload: the k = 63 recipe at that workload's size)
     if args.queries is None:
         args.queries = queries
 
@@ -524,7 +535,9 @@ def main():
                                      "tools/bench_streaming_file.py runs 10^8 reads (profiles/r03/)")
             del reads
         index_statistics = table_histogram = None
-        if args.k <= 31:
+        from sshash_amd.repeats import load_recipe
+
+        if int(load_recipe(args.recipe)["k"]) == d.k():
             from sshash_amd.repeats import statistics_vs_target
 
             index_statistics = statistics_vs_target(d.bucket_stats(), args.recipe)

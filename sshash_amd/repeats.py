@@ -54,25 +54,66 @@ def _reverse_pairs64(x):
 
 
 def _canonical_kmers(codes, k: int):
-    """codes: (R, L) uint8 tensor -> (R, L-k+1) int64 canonical k-mers (k <= 31): min(x, revcomp(x)),
-    2-bit packed with the first base in the low bits (reference include/kmer.hpp:80,159-165)."""
+    """codes: (R, L) uint8 tensor -> the canonical k-mers of every row, 2-bit packed with the first base in the low bits
+    (reference include/kmer.hpp:80,159-165): k <= 31: one (R, L-k+1) int64 tensor, min(x, revcomp(x)); k <= 63: the pair
+    (high word, low word) of whichever of x and revcomp(x) comes first in (high, low) order -- any total order does, the
+    pair only has to be the same for a k-mer and its reverse complement."""
     import torch
 
     R, L = codes.shape
     n = L - k + 1
-    half = min(16, k)
-    # (zero columns behind the row: the 16-base word starting `half` bases into the last k-mer runs past the row's end)
-    c = torch.cat([codes, torch.zeros((R, half), dtype=codes.dtype, device=codes.device)], dim=1).to(torch.int64)
-    h = torch.zeros((R, L + 1), dtype=torch.int64, device=codes.device)
-    for t in range(half):
-        h |= c[:, t:t + L + 1] << (2 * t)
-    if k > half:
-        rest = k - half
-        x = h[:, :n] | ((h[:, half:half + n] & ((1 << (2 * rest)) - 1)) << (2 * half))
-    else:
-        x = h[:, :n]
-    rc = _shr(_reverse_pairs64(x ^ _s64(0xAAAAAAAAAAAAAAAA)), 64 - 2 * k)
-    return torch.minimum(x, rc)
+    # (zero columns behind the row: the 16-base words of the last k-mers run past the row's end)
+    c = torch.cat([codes, torch.zeros((R, 64), dtype=codes.dtype, device=codes.device)], dim=1).to(torch.int64)
+    h = torch.zeros((R, L + 48), dtype=torch.int64, device=codes.device)  # h[j] = the 16 bases starting at j
+    for t in range(16):
+        h |= c[:, t:t + L + 48] << (2 * t)
+    comp = _s64(0xAAAAAAAAAAAAAAAA)
+
+    def word(at, bases):  # `bases` (<= 32) bases starting `at` bases into every k-mer, as one int64
+        lo = h[:, at:at + n]
+        if bases <= 16:
+            return lo & ((1 << (2 * bases)) - 1)
+        hi = h[:, at + 16:at + 16 + n]
+        if bases < 32:
+            hi = hi & ((1 << (2 * (bases - 16))) - 1)
+        return lo | (hi << 32)
+
+    if k <= 31:
+        x = word(0, k)
+        rc = _shr(_reverse_pairs64(x ^ comp), 64 - 2 * k)
+        return torch.minimum(x, rc)
+    lo, hi = word(0, 32), word(32, k - 32)
+    r_hi, r_lo = _reverse_pairs64(lo ^ comp), _reverse_pairs64(hi ^ comp)  # the words swap (kmer.hpp:162)
+    s = 128 - 2 * k  # 2 <= s <= 62
+    rc_lo = _shr(r_lo, s) | (r_hi << (64 - s))
+    rc_hi = _shr(r_hi, s)
+    first = (rc_hi < hi) | ((rc_hi == hi) & (rc_lo < lo))
+    return torch.where(first, rc_hi, hi), torch.where(first, rc_lo, lo)
+
+
+def _first_occurrences(canon):
+    """-> bool tensor over the flattened k-mer starts: True where a canonical k-mer occurs for the first time (lowest row, then
+    lowest position: stable sorts)."""
+    import torch
+
+    if not isinstance(canon, tuple):
+        flat = canon.reshape(-1)
+        order = torch.sort(flat, stable=True)
+        first = torch.ones_like(order.values, dtype=torch.bool)
+        first[1:] = order.values[1:] != order.values[:-1]
+        keep = torch.zeros(flat.numel(), dtype=torch.bool, device=flat.device)
+        keep[order.indices] = first
+        return keep
+    hi, lo = canon[0].reshape(-1), canon[1].reshape(-1)
+    by_lo = torch.sort(lo, stable=True).indices
+    by_hi = torch.sort(hi[by_lo], stable=True).indices
+    perm = by_lo[by_hi]  # (high, low) order, ties in input order
+    h, l = hi[perm], lo[perm]
+    first = torch.ones(perm.numel(), dtype=torch.bool, device=perm.device)
+    first[1:] = (h[1:] != h[:-1]) | (l[1:] != l[:-1])
+    keep = torch.zeros(perm.numel(), dtype=torch.bool, device=perm.device)
+    keep[perm] = first
+    return keep
 
 
 def _family_strings(gen, device, families: int, copies: int, length: int, divergence: float, k: int, core: int = 0,
@@ -109,15 +150,7 @@ def _family_strings(gen, device, families: int, copies: int, length: int, diverg
             del mut, delta
         R = rows.shape[0]
         n = length - k + 1
-        canon = _canonical_kmers(rows, k).reshape(-1)
-        # keep the first occurrence of every canonical k-mer (stable sort: lowest row, then lowest position)
-        order = torch.sort(canon, stable=True)
-        first = torch.ones_like(order.values, dtype=torch.bool)
-        first[1:] = order.values[1:] != order.values[:-1]
-        keep = torch.zeros(R * n, dtype=torch.bool, device=device)
-        keep[order.indices] = first
-        del order, first, canon
-        keep = keep.reshape(R, n)
+        keep = _first_occurrences(_canonical_kmers(rows, k)).reshape(R, n)  # every canonical k-mer once
         # maximal runs of kept k-mer starts inside a row
         pad = torch.zeros((R, 1), dtype=torch.bool, device=device)
         a = torch.cat([pad, keep, pad], dim=1).to(torch.int8)
@@ -176,8 +209,8 @@ def make_repeat_spss(num_bases: int, k: int = 31, classes=(), seed: int = 0x5555
     num_bases. Deterministic for (arguments, device type)."""
     import torch
 
-    if k > 31:
-        raise ValueError("make_repeat_spss: k <= 31")
+    if k > 63:
+        raise ValueError("make_repeat_spss: k <= 63")
     dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
     gen = torch.Generator(device=dev)
     gen.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)

@@ -43,13 +43,11 @@ class SyntheticCase:
         import sshash_amd
         from oracle import oracle as O
         from sshash_amd.repeats import make_recipe_spss
-        from sshash_amd.synthetic import make_spss
 
         self.k, self.m, self.W = k, m, 1 if k <= 31 else 2
-        if k <= 31:  # the bench's own stand-ins (repeat families fitted to the published bucket statistics), at reduced size
-            self.words, self.endpoints = make_recipe_spss("se_k31" if mean_len < 100 else "human_k31", bases, seed=4242)
-        else:
-            self.words, self.endpoints = make_spss(bases, k=k, m=m, mean_len=mean_len, seed=4242)
+        # the bench's own stand-ins (repeat families fitted to the published bucket statistics), at reduced size
+        recipe = "human_k63" if k > 31 else ("se_k31" if mean_len < 100 else "human_k31")
+        self.words, self.endpoints = make_recipe_spss(recipe, bases, seed=4242)
         self.dict = sshash_amd.Dictionary.build_from_packed(self.words, self.endpoints, k=k, m=m, canonical=canonical, num_threads=0)
         self.path = os.path.join(tmpdir, name + ".sshash")
         self.dict.save(self.path)

@@ -123,3 +123,35 @@ def test_repeat_family_spss_is_a_set_and_reports_the_builders_statistics():
     assert sum(s["num_kmers_in_skew_partition"]) == s["num_kmers_in_skew_index"]
     cmp = statistics_vs_target(s, "human_k31")  # the shipped recipe's targets load and scale
     assert cmp["num_kmers"]["achieved"] == km.size and 0 < cmp["scale"] < 1e-2
+
+
+def test_repeat_family_spss_k63_is_a_set():
+    """The same generator at k = 63 (two-word canonical forms): every canonical 63-mer once, strings >= k,
+    cores shorter than k shared by hundreds of strings give a skew-index bucket at m = 25."""
+    import sshash_amd
+    from sshash_amd.repeats import make_repeat_spss, statistics_vs_target
+
+    k, m = 63, 25
+    classes = [{"copies": 2, "length": 400, "divergence": 0.02, "families": 200},
+               {"copies": 30, "length": 300, "divergence": 0.1, "families": 6},
+               {"copies": 200, "length": 200, "core": 45, "families": 2.5}]
+    words, ends = make_repeat_spss(800_000, k=k, classes=classes, reference_bases=800_000, seed=5, device="cpu")
+    codes = ((words[:, None] >> (np.arange(32, dtype=np.uint64) * np.uint64(2))) & np.uint64(3)).reshape(-1)[: int(ends[-1])]
+    text = "".join("ACGT"[c] for c in codes.tolist())
+    comp = str.maketrans("ACGT", "TGCA")
+    seen = set()
+    total = 0
+    e = ends.astype(np.int64)
+    for b, t in zip(e[:-1].tolist(), e[1:].tolist()):
+        assert t - b >= k
+        for i in range(b, t - k + 1):
+            s = text[i:i + k]
+            r = s.translate(comp)[::-1]
+            seen.add(s if s < r else r)
+            total += 1
+    assert len(seen) == total  # a spectrum-preserving string set
+    d = sshash_amd.Dictionary.build_from_packed(words, ends, k=k, m=m, num_threads=4)
+    s = d.bucket_stats()
+    assert s["num_kmers"] == total and s["num_buckets_in_skew_index"] >= 1 and s["max_bucket_size"] > 64
+    cmp = statistics_vs_target(s, "human_k63")
+    assert cmp["num_kmers"]["achieved"] == total and 0 < cmp["scale"] < 1e-2

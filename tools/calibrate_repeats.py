@@ -38,6 +38,17 @@ TARGETS = {
         "bucket_percent": [97.1918, 1.69205, 0.442612, 0.201662, 0.114623, 0.0734475, 0.0506719, 0.0368406, 0.0280203, 0.0218197,
                            0.0175108, 0.0142045, 0.0116337, 0.00980818, 0.00832637, 0.00717712],
     },
+    "human_k63": {  # benchmarks/results-10-11-25/k63/regular-build.log, block from line 323: human.k63.eulertigs.fa.gz, k=63 m=25 regular
+        "source": "benchmarks/results-10-11-25/k63/regular-build.log:323-496", "k": 63, "m": 25,
+        "num_kmers": 2771316093, "num_strings": 2642917, "num_bases": 2935176947,
+        "num_minimizers": 122838669, "num_minimizer_positions": 140756047,
+        "num_buckets_larger_than_1_not_in_skew_index": 3097190, "num_minimizer_positions_of_buckets_larger_than_1": 12724460,
+        "num_buckets_in_skew_index": 28203, "num_minimizer_positions_of_buckets_in_skew_index": 8318311,
+        "num_kmers_in_skew_index": 145458128, "max_bucket_size": 147936,
+        "num_kmers_in_skew_partition": [25196923, 21919654, 19634878, 18051454, 17018125, 14085569, 9296403, 20255122],
+        "bucket_percent": [97.4557, 1.46862, 0.405135, 0.185188, 0.10523, 0.0680771, 0.0480598, 0.0352926, 0.0271502, 0.0217871,
+                           0.0176866, 0.014607, 0.0121411, 0.0105985, 0.00909811, 0.00794457],
+    },
     "se_k31": {  # block from line 1834: se.k31.eulertigs.fa.gz (S. enterica pangenome), k=31 m=21 regular
         "source": "benchmarks/results-10-11-25/k31/regular-build.log:1834-2022", "k": 31, "m": 21,
         "num_kmers": 894310084, "num_strings": 16440873, "num_bases": 1387536274,
@@ -63,6 +74,12 @@ TAIL_TUNING = {
                            "note": "the largest bucket: one family whose core wins its windows (max bucket 21 087 alone)"}],
     },
     "se_k31": {"class_seeds": {(11264, 26): 104, (22528, 23): 103}},
+    "human_k63": {
+        "extra_classes": [{"copies": 160000, "length": 250, "core": 45, "families": 1.0, "seed": 100,
+                           "note": "the largest bucket: 148 015 alone, 5.0 M k-mers in the last skew partition"}],
+        # ... which the fit had given to the 63 719-copy cores (1.9 M k-mers of that partition per family)
+        "families_delta": {(63719, 45): -2.5},
+    },
 }
 
 
@@ -106,6 +123,34 @@ def stats_vector(s):
     rows["strings"] = s["num_strings"]
     rows["kmers"] = s["num_kmers"]
     return rows
+
+
+def candidate_classes_k63(max_bucket):
+    """the same idea at k = 63, m = 25: longer copies (a string must hold 63-mers), divergences at which 25-mers survive in many
+    copies and 63-mers in few, cores of 25..60 bases; the diverged classes stop at 128 k copies (the largest buckets are left
+    to the cores: a k = 63 family of a million 600-base copies is a third of the collection)"""
+    copies = [2, 3, 4, 6, 8]
+    n = 11.0
+    while n < 300000:
+        copies.append(int(round(n)))
+        n *= 2 ** 0.5
+    out = []
+    for c in copies:
+        if c <= 8:
+            opts = [(1000, 0.002), (1000, 0.01), (2000, 0.03), (2000, 0.06)]
+        elif c <= 256:
+            opts = [(400, 0.015), (600, 0.04), (800, 0.08)]
+        elif c <= 130000:
+            opts = [(300, 0.03), (400, 0.06), (600, 0.10)]
+        else:
+            opts = []
+        for L, dv in opts:
+            out.append({"copies": c, "length": L, "divergence": dv})
+        for core in (25, 31, 45, 60):
+            out.append({"copies": c, "length": 250, "core": core})
+            if c <= 16:
+                out.append({"copies": c, "length": 3000, "core": core})
+    return out
 
 
 def candidate_classes(max_bucket):
@@ -181,6 +226,10 @@ def main():
     ap.add_argument("--freeze-cores", action="store_true",
                     help="with --feedback: the core classes keep the amounts (and class seeds) of the current recipe -- the tail they "
                          "realise was chosen seed by seed and must not move -- and only the diverged families and the background are refitted")
+    ap.add_argument("--strings-weight", type=float, default=None,
+                    help="weight of the number of strings in the fit (default 4 like the other totals at k <= 31; 1 at k = 63, where "
+                         "the published collection's strings are long unitigs holding many repeated m-mers each and the families' "
+                         "are one copy each: the bucket classes matter to the lookup, the string count hardly does)")
     ap.add_argument("--cache", default=os.path.join(ROOT, "tools", "calibrate_repeats_cache.json"))
     args = ap.parse_args()
     from scipy.optimize import nnls
@@ -217,7 +266,7 @@ def main():
     cache = {}
     if os.path.exists(args.cache):
         cache = json.load(open(args.cache))
-    classes = candidate_classes(t["max_bucket_size"])
+    classes = candidate_classes_k63(t["max_bucket_size"]) if k > 31 else candidate_classes(t["max_bucket_size"])
     cols, meta = [], []
     t0 = time.time()
     for c in classes:
@@ -231,7 +280,7 @@ def main():
             continue  # this class alone would exceed the largest published bucket
         cols.append([cache[key]["v"][n] for n in names])
         meta.append(dict(c, max_bucket=cache[key]["max"], bases_per_family=cache[key]["bases"]))
-    backgrounds = [80.0, 400.0, 4000.0]
+    backgrounds = [80.0, 400.0, 4000.0] if k <= 31 else [150.0, 1000.0, 20000.0]
     for ml in backgrounds:
         key = f"{k}-{m}-bg-{ml}"
         if key not in cache:
@@ -246,6 +295,8 @@ def main():
     for i, n in enumerate(names):
         if n in ("minimizers", "positions", "strings", "kmers"):
             wgt[i] = 4.0
+        if n == "strings":
+            wgt[i] = args.strings_weight if args.strings_weight is not None else (4.0 if k <= 31 else 1.0)
     Aw = A / b[:, None] * wgt[:, None]
     # (fractional amounts: the generator makes floor(x) whole families and one more with the remaining fraction of the copies)
     frozen = {}
@@ -283,6 +334,7 @@ def main():
         sd = tune.get("class_seeds", {}).get((c["copies"], c.get("core", 0)))
         if sd is not None:
             c["seed"] = sd
+        c["families"] = max(0.0, c["families"] + tune.get("families_delta", {}).get((c["copies"], c.get("core", 0)), 0.0))
     recipe_classes += tune.get("extra_classes", [])
     recipe = {"name": args.name, "k": k, "m": m, "target": t, "reference_bases": t["num_bases"], "classes": recipe_classes,
               "background": bg, "fit": {n: float(f) for n, f in zip(names, fit)}, "aim": {n: float(aim[n]) for n in names}}

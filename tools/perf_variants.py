@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
     # the bench's own stand-ins (bench.get_index): the S. enterica recipe at C2 size by default, the human one for larger --bases
-    args.recipe = "se_k31" if args.bases < 2_000_000_000 else "human_k31"
+    args.recipe = "human_k63" if args.k > 31 else ("se_k31" if args.bases < 2_000_000_000 else "human_k31")
     args.repeat_scale = 1.0
 
     import torch

@@ -16,7 +16,7 @@ r = load_recipe(sys.argv[1])
 seed = 0x5555AAAA
 if len(sys.argv) > 2:
     n, core, first, count = (int(v) for v in sys.argv[2:6])
-    todo = [({"copies": n, "length": 120, "core": core, "families": 1.0}, range(first, first + count))]
+    todo = [({"copies": n, "length": 120 if r["k"] <= 31 else 250, "core": core, "families": 1.0}, range(first, first + count))]
 else:
     todo = [(c, range(100, 112)) for c in r["classes"] if "core" in c and c["copies"] >= 11000]
 for c, seeds in todo:
