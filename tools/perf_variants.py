@@ -40,7 +40,7 @@ def main():
     import torch
 
     import bench
-    from sshash_amd.synthetic import draw_queries, make_spss
+    from sshash_amd.synthetic import draw_queries
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -131,7 +131,7 @@ def main():
     if not args.skip_streaming:
         from oracle import oracle as O  # checker for the counters of a sample
 
-        words, endpoints = make_spss(args.bases, k=args.k, m=args.m, seed=args.seed, mean_len=args.mean_len)
+        words, endpoints = bench.make_standin(args)  # the strings the index was built from (deterministic): reads are drawn from them
         total = int(endpoints[-1])
         rng = np.random.default_rng(99)
         L, R = args.read_len, args.reads
