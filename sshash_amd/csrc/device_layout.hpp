@@ -183,14 +183,21 @@ static_assert(SK_CHOICES == 5, "sk_hash and sk_choice spell out five choices");
 constexpr uint32_t SK_INLINE_MAX = 4;         // a key with up to this many occurrences holds one inline slot per occurrence;
                                               // a heavier key holds a marker and its k-mers are keyed one by one
 constexpr double SK_SLOTS_PER_KEY = 2.5;  // slots per item: load factor 0.4 (1.6 ... 4.0 measured)
+constexpr double SK_SLOTS_PER_KMER = 2.5; // the same for the region of the heavy keys' k-mers (sk_view::kmer_buckets)
 /* why a replica was given no table (sshash_device_stats) */
 constexpr uint32_t SK_ABSENT_DISABLED = 1, SK_ABSENT_MINIMIZER_SHARD = 2, SK_ABSENT_TOO_MANY_BASES = 3, SK_ABSENT_TOO_MANY_ITEMS = 4,
                    SK_ABSENT_NO_MEMORY = 5;
 
 struct sk_view {
-    void const* slots;    // num_buckets x 2 slots of 32 bytes (k <= 31) or of 64 bytes (k <= 63)
-    uint32_t num_buckets;
+    void const* slots;    // (num_buckets + kmer_buckets) x 2 slots of 32 bytes (k <= 31) or of 64 bytes (k <= 63)
+    uint32_t num_buckets; // the region the keys hash into: inline slots and markers
     uint32_t enabled;
+    /* the heavy keys' k-mers (keyed by sk_kmer_key) have a region of their own behind the keys' -- buckets num_buckets ..
+       num_buckets + kmer_buckets - 1, same bucket format, same go-on flags -- so that it can be packed at its own load
+       factor (SK_SLOTS_PER_KMER): a probe gets there only after its key's marker, one positive lookup in ten or twenty,
+       and what a fuller region costs (more second choices) is paid by those alone */
+    uint32_t kmer_buckets;
+    uint32_t spare;
     /* table shard (multi-GPU, sharded.py): this replica's table holds only the keys with
        sk_owner(key, num_shards) == shard_id; lookups of other keys take the complete path */
     uint32_t num_shards;
@@ -227,6 +234,13 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_buckets) {
        VALU instructions each -- for every query, although only the twentieth that goes on ever looks at the other buckets. At
        k <= 63 the first pass is bound by its instructions. */
     h.fingerprint = uint32_t(a) & 0xFFFFFFu;
+    return h;
+}
+
+/* bucket sequence of a heavy key's k-mer: hashed into the k-mers' region */
+SSH_HD sk_hash_t sk_hash_kmer_region(uint64_t kmer_key, uint32_t first_bucket, uint32_t kmer_buckets) {
+    sk_hash_t h = sk_hash(kmer_key, kmer_buckets);
+    for (uint32_t c = 0; c < SK_CHOICES; ++c) h.bucket[c] += first_bucket;
     return h;
 }
 

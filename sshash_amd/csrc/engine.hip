@@ -180,7 +180,7 @@ void engine::device_stats(int device, uint64_t out[16]) const {
     out[1] = r->view.directory.enabled ? r->view.directory.num_buckets : 0;
     out[2] = r->directory_overflowed;
     out[3] = r->directory_entries;
-    out[4] = r->view.sk.enabled ? uint64_t(r->view.sk.num_buckets) * SK_BUCKET_SLOTS : 0;
+    out[4] = r->view.sk.enabled ? (uint64_t(r->view.sk.num_buckets) + r->view.sk.kmer_buckets) * SK_BUCKET_SLOTS : 0;
     out[5] = r->sk_keys;
     out[6] = r->sk_keys - r->sk_heavy_keys;
     out[7] = r->sk_unplaced;

@@ -664,7 +664,7 @@ template <int W>
 __device__ __forceinline__ void sk_walk_to_kmer_sequence(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_walk_t& w,
                                                          sk_query_t<W>& Q, bool go_on) {
     w.back_to = go_on ? w.c + 1 : SK_NO_RETURN;
-    w.h = sk_hash(sk_kmer_key<W>(x, x_rc), d.sk.num_buckets);
+    w.h = sk_hash_kmer_region(sk_kmer_key<W>(x, x_rc), d.sk.num_buckets, d.sk.kmer_buckets);
     w.c = 0;
     w.on_kmer_sequence = true;
     Q.fingerprint = w.h.fingerprint;

@@ -337,6 +337,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     dict_view& v = rep.view;
     v.sk.slots = nullptr;
     v.sk.num_buckets = 0;
+    v.sk.kmer_buckets = 0;
     v.sk.enabled = 0;
     v.sk.num_shards = table_shards;  // read by the scan kernel's filter
     v.sk.shard_id = table_shard_id;
@@ -465,9 +466,17 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
         HIP_CHECK(hipMemcpy(h_stats, stats, 64, hipMemcpyDeviceToHost));
         if (h_stats[7] != heavy_kmers) throw error(error_kind::hip, "super-k-mer table: the two passes over the heavy keys disagree");
     }
-    /* slots asked for: one per occurrence of a light key, one marker per heavy key, one per k-mer of a heavy key */
+    /* slots asked for: one per occurrence of a light key, one marker per heavy key -- the keys' region -- and one per k-mer of
+       a heavy key, in the region behind it (sk_view::kmer_buckets) */
+    double slots_per_kmer = SK_SLOTS_PER_KMER;
+    if (const char* e = std::getenv("SSHASH_AMD_SK_SLOTS_PER_KMER")) {  // measurement knob
+        const double want = std::atof(e);
+        if (want >= 1.2 && want <= 16.0) slots_per_kmer = want;
+    }
     const uint64_t wanted = (T - heavy_occurrences) + heavy_keys + heavy_kmers;
-    const uint64_t num_buckets = uint64_t(double(wanted) * slots_per_key / SK_BUCKET_SLOTS) + 8;
+    const uint64_t key_buckets = uint64_t(double(wanted - heavy_kmers) * slots_per_key / SK_BUCKET_SLOTS) + 8;
+    const uint64_t kmer_buckets = heavy_kmers ? uint64_t(double(heavy_kmers) * slots_per_kmer / SK_BUCKET_SLOTS) + 8 : 0;
+    const uint64_t num_buckets = key_buckets + kmer_buckets;
     const uint64_t num_slots = num_buckets * SK_BUCKET_SLOTS;
     const uint64_t slot_bytes = wide ? 64 : 32;
     if (num_buckets >= (uint64_t(1) << 32)) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);
@@ -491,18 +500,19 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
        k-mers instead of 7.2 % -- that many fewer positive queries need a second bucket (resume pass). */
     const uint32_t most = idx.k - idx.m + 1;
     const uint32_t turns[3][2] = {{(7 * most + 9) / 10, 63u}, {(35 * most + 99) / 100, (7 * most + 9) / 10 - 1}, {0u, (35 * most + 99) / 100 - 1}};
+    uint32_t* kmer_slots = slots + key_buckets * SK_BUCKET_SLOTS * (slot_bytes / 4);  // the k-mers' region
     auto place = [&](uint32_t choice, uint32_t lo, uint32_t hi, bool with_heavy_kmers) {
         const dim3 g1(uint32_t((T + 255) / 256)), g2(uint32_t((heavy_kmers + 255) / 256));
         if (wide) {
-            hipLaunchKernelGGL(sk_place_kernel<2>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(num_buckets), placed, stats, lo, hi);
+            hipLaunchKernelGGL(sk_place_kernel<2>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(key_buckets), placed, stats, lo, hi);
             if (heavy_kmers && with_heavy_kmers)
-                hipLaunchKernelGGL(sk_place_kernel<2>, g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, slots,
-                                   uint32_t(num_buckets), placed + T, stats, 0u, 63u);
+                hipLaunchKernelGGL(sk_place_kernel<2>, g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, kmer_slots,
+                                   uint32_t(kmer_buckets), placed + T, stats, 0u, 63u);
         } else {
-            hipLaunchKernelGGL(sk_place_kernel<1>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(num_buckets), placed, stats, lo, hi);
+            hipLaunchKernelGGL(sk_place_kernel<1>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(key_buckets), placed, stats, lo, hi);
             if (heavy_kmers && with_heavy_kmers)
-                hipLaunchKernelGGL(sk_place_kernel<1>, g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, slots,
-                                   uint32_t(num_buckets), placed + T, stats, 0u, 63u);
+                hipLaunchKernelGGL(sk_place_kernel<1>, g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, kmer_slots,
+                                   uint32_t(kmer_buckets), placed + T, stats, 0u, 63u);
         }
         HIP_CHECK(hipGetLastError());
     };
@@ -530,7 +540,8 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     rep.sk_bytes = num_slots * slot_bytes;
     rep.sk_absent_reason = 0;
     v.sk.slots = slots;
-    v.sk.num_buckets = uint32_t(num_buckets);
+    v.sk.num_buckets = uint32_t(key_buckets);
+    v.sk.kmer_buckets = uint32_t(kmer_buckets);
     v.sk.enabled = 1;
 }
 
