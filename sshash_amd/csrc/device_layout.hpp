@@ -91,6 +91,8 @@
 //               key's marker switches to the k-mer's own bucket sequence and finds the k-mer after one more read,
 //               however many thousand occurrences the key has (what the reference's skew index does for its heavy
 //               buckets, include/sparse_and_skew_index.hpp:34-44, with the table's own machinery).
+//               The k-mers' copies live in a range of buckets of their own behind the keys' (sk_view::kmer_buckets), packed
+//               tighter: only the probes that met a marker pay for its second choices.
 //        flags  go-on flag c of a bucket says "a key whose c-th choice is this bucket lives further along its
 //               sequence"; a probe that finds neither its k-mer nor that flag is a final miss -- negative
 //               queries end after ~1.1 line reads. The last choice's flag (a key or k-mer that found no slot at all)
@@ -183,7 +185,11 @@ static_assert(SK_CHOICES == 5, "sk_hash and sk_choice spell out five choices");
 constexpr uint32_t SK_INLINE_MAX = 4;         // a key with up to this many occurrences holds one inline slot per occurrence;
                                               // a heavier key holds a marker and its k-mers are keyed one by one
 constexpr double SK_SLOTS_PER_KEY = 2.5;  // slots per item: load factor 0.4 (1.6 ... 4.0 measured)
-constexpr double SK_SLOTS_PER_KMER = 2.5; // the same for the region of the heavy keys' k-mers (sk_view::kmer_buckets)
+/* the same for the region of the heavy keys' k-mers (sk_view::kmer_buckets): fuller, since only the probes that met a marker pay for it.
+   Same-box sweep (profiles/r03/kmer_region_load_ab.txt): C3 2.5 -> 2.0 -> 1.75 -> 1.5 slots per k-mer = 47.9 -> 45.7 -> 44.6 -> 43.5 GB and
+   37.8 -> 37.6 -> 37.25 -> 36.6 G lookups/s; C4 (k = 63, 64-byte slots, 9.9 % of the k-mers under heavy keys) 66.7 -> 58.0 -> 53.6 ->
+   49.3 GB with every rate inside the box's +-3 % run-to-run spread (the first pass is bound by instructions there, not by lines). */
+constexpr double SK_SLOTS_PER_KMER_NARROW = 2.0, SK_SLOTS_PER_KMER_WIDE = 1.75;  // k <= 31, k <= 63
 /* why a replica was given no table (sshash_device_stats) */
 constexpr uint32_t SK_ABSENT_DISABLED = 1, SK_ABSENT_MINIMIZER_SHARD = 2, SK_ABSENT_TOO_MANY_BASES = 3, SK_ABSENT_TOO_MANY_ITEMS = 4,
                    SK_ABSENT_NO_MEMORY = 5;

@@ -468,7 +468,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     }
     /* slots asked for: one per occurrence of a light key, one marker per heavy key -- the keys' region -- and one per k-mer of
        a heavy key, in the region behind it (sk_view::kmer_buckets) */
-    double slots_per_kmer = SK_SLOTS_PER_KMER;
+    double slots_per_kmer = wide ? SK_SLOTS_PER_KMER_WIDE : SK_SLOTS_PER_KMER_NARROW;
     if (const char* e = std::getenv("SSHASH_AMD_SK_SLOTS_PER_KMER")) {  // measurement knob
         const double want = std::atof(e);
         if (want >= 1.2 && want <= 16.0) slots_per_kmer = want;
