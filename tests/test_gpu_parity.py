@@ -266,13 +266,15 @@ def test_batch_larger_than_one_launch_piece(case_se_regular):
 
 
 @pytest.mark.parametrize("settings", [{"SSHASH_AMD_DIRECTORY": "0", "SSHASH_AMD_SKTABLE": "0"}, {"SSHASH_AMD_SKTABLE": "0"}, {},
-                                      {"SSHASH_AMD_DIRECTORY": "1"}],
-                         ids=["mphf_only", "directory_only", "sktable_lean", "sktable_over_directory"])
+                                      {"SSHASH_AMD_DIRECTORY": "1"}, {"SSHASH_AMD_SK_SLOTS_PER_KEY": "1.2", "SSHASH_AMD_SK_SLOTS_PER_KMER": "1.2"}],
+                         ids=["mphf_only", "directory_only", "sktable_lean", "sktable_over_directory", "sktable_packed_tight"])
 def test_accelerators_disabled(tmp_path, settings):
     """The lookup structures are layered (device_layout.hpp (3)-(5)): with the super-k-mer table and/or
     the minimizer directory switched off (also what an over-wide dictionary gets) the remaining path must
     give the same ids / membership / full results as the oracle. sktable_lean is the default replica: the table over
-    bit-packed codewords, no directory; sktable_over_directory forces the round-2 layout."""
+    bit-packed codewords, no directory; sktable_over_directory forces the round-2 layout; sktable_packed_tight fills both
+    regions of the table (the keys', the heavy keys' k-mers') to a load factor of 0.83: long bucket sequences, and items
+    that find no slot and are left to the complete path."""
     import os
     import subprocess
     import sys
@@ -297,6 +299,8 @@ def test_accelerators_disabled(tmp_path, settings):
                 want_directory = os.environ.get("SSHASH_AMD_DIRECTORY") == "1" or (not table and os.environ.get("SSHASH_AMD_DIRECTORY") != "0")
                 assert (stats["directory_sectors"] != 0) == want_directory, stats
                 assert (stats["sk_slots"] != 0) == table, stats
+                if os.environ.get("SSHASH_AMD_SK_SLOTS_PER_KMER"):
+                    assert stats["sk_heavy_kmers"] > 0 and stats["sk_load_factor"] > 0.75 and stats["sk_deferred_keys"] > 0, stats
                 q = case.queries(4000, 4000, seed=1)
                 want = case.oracle.lookup_ids(q)
                 assert (d.lookup(q).kmer_id == want).all()
