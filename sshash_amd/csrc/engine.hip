@@ -788,19 +788,27 @@ static uint32_t resume_capacity_divisor() {
     return 2;
 }
 
-/* Tail passes on an auxiliary stream (launch()): OFF unless SSHASH_AMD_OVERLAP=1. Measured on the calibrated C3 stand-in,
-   same box, alternating runs (profiles/r03/overlap_ab_c3.txt, overlap_ab_c2.txt): 35.90 / 35.95 / 35.81 G lookups/s without,
-   35.67 / 35.65 / 35.61 with; on C2 (10^8 queries, four pieces) 33.5 / 34.6 / 33.5 without, 32.9 / 31.6 / 31.6 with. The tail
-   passes are not idle latency waiting to be hidden: they are more random line fetches (and partial-line id writes) for a
-   memory system the first pass already saturates, so running them beside it only takes lines away from it, and the
-   smaller pieces add launch tails. (Walking the rest of a probe inside the first pass itself, by the lane that needs it,
-   SSHASH_AMD_INLINE_RESUME in profiles/r03/inline_resume_ab.txt: no gain on C3, -4 % on C2; removed.) */
-static bool overlap_tail_passes() {
-    static const bool on = [] {
+/* Tail passes on an auxiliary stream (launch()). SSHASH_AMD_OVERLAP: unset = when the deferred pass is the only tail pass
+   (k <= 31 with the table: sk_finish_in_wave) and the batch is cut into several launch sequences anyway; 1 = always, and a
+   batch is cut into at least OVERLAP_PIECES pieces for it; 0 = never. Measured on the calibrated stand-ins, same box,
+   alternating runs:
+     with a resume pass (profiles/r03/overlap_ab_c3.txt, overlap_ab_c2.txt): C3 35.90 / 35.95 / 35.81 G lookups/s without,
+       35.67 / 35.65 / 35.61 with; C2 (10^8 queries, four pieces) 33.5 / 34.6 / 33.5 without, 32.9 / 31.6 / 31.6 with. That tail
+       is not idle latency waiting to be hidden: it is more random line fetches (and partial-line id writes) for a memory
+       system the first pass already saturates, and the smaller pieces add launch tails;
+     deferred pass only (profiles/r03/overlap_deferred_only_ab.txt): C3 40.51 / 40.38 / 40.47 without, 40.94 / 40.88 / 40.81
+       with (+1.0 %: 68 us of dependent reads by a few thousand lanes per 3.0 ms sequence, beside the next first pass instead of
+       after this one); C2 forced into four pieces 37.7 / 37.9 -> 36.9 / 36.8, hence no forcing.
+   (Walking the rest of a probe inside the first pass itself, by the lane that needs it, SSHASH_AMD_INLINE_RESUME in
+   profiles/r03/inline_resume_ab.txt: no gain on C3, -4 % on C2; removed.) */
+enum class overlap_mode { never, when_cheap, always };
+static overlap_mode overlap_tail_passes() {
+    static const overlap_mode mode = [] {
         const char* e = std::getenv("SSHASH_AMD_OVERLAP");
-        return e && e[0] == '1';
+        if (!e) return overlap_mode::when_cheap;
+        return e[0] == '1' ? overlap_mode::always : overlap_mode::never;
     }();
-    return on;
+    return mode;
 }
 constexpr uint64_t OVERLAP_PIECES = 4, OVERLAP_MIN_QUERIES = uint64_t(1) << 22;
 
@@ -835,10 +843,11 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                waits for the last tail before the call returns control of it. */
             const uint64_t piece_max = launch_piece_queries();
             uint64_t pieces = (n + piece_max - 1) / piece_max;
-            if (overlap_tail_passes() && n >= OVERLAP_MIN_QUERIES) pieces = std::max<uint64_t>(pieces, OVERLAP_PIECES);
+            const bool in_wave = W == 1 && d.sk.enabled && finish_in_wave();
+            if (overlap_tail_passes() == overlap_mode::always && n >= OVERLAP_MIN_QUERIES) pieces = std::max<uint64_t>(pieces, OVERLAP_PIECES);
             const uint64_t piece = ((n + pieces - 1) / pieces + block - 1) / block * block;  // equal pieces, whole workgroups
             pieces = (n + piece - 1) / piece;
-            const bool overlap = overlap_tail_passes() && pieces > 1;
+            const bool overlap = pieces > 1 && (overlap_tail_passes() == overlap_mode::always || (overlap_tail_passes() == overlap_mode::when_cheap && in_wave));
             const size_t qbytes = size_t(W) * 8, kbytes = d.k;
             const uint32_t nblocks_max = uint32_t((std::min(piece, n) + block - 1) / block);
             pass_queues shape{};
@@ -856,7 +865,7 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 const uint32_t set = overlap ? uint32_t(index & 1) : 0u;
                 pass_queues pq = shape;
                 pq.flag_misses = wants_flag ? 1u : 0u;
-                pq.finish_in_wave = (W == 1 && d.sk.enabled && finish_in_wave()) ? 1u : 0u;
+                pq.finish_in_wave = in_wave ? 1u : 0u;
                 char* scratch = static_cast<char*>(sc.block) + set * set_bytes;
                 if (overlap && index >= 2) HIP_CHECK(hipStreamWaitEvent(stream, sc.tail_done[set], 0));  // the set's queues are free again
                 HIP_CHECK(hipMemsetAsync(scratch, 0, 2 * DEFER_SHARDS * sizeof(uint32_t), stream));

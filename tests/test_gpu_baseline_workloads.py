@@ -237,7 +237,7 @@ def test_a_dictionary_with_more_than_2_32_kmer_starts_still_gets_its_table():
     import bench
     from sshash_amd.synthetic import revcomp_device
 
-    args = argparse.Namespace(bases=4_600_000_000, k=31, m=21, mean_len=274.0, canonical=False, seed=0x77AA,
+    args = argparse.Namespace(bases=4_600_000_000, k=31, m=21, canonical=False, seed=0x77AA, recipe="human_k31", repeat_scale=1.0,
                               cache_dir=os.environ.get("SSHASH_BENCH_CACHE", "/tmp"), verbose=False)
     d, _ = bench.get_index(args, 0, 1, lambda: None)
     d.to_device(0)
