@@ -281,33 +281,31 @@ def make_reads_device(d, device: int, n_reads: int, read_len: int = 150, positiv
     """-> uint8 torch tensor (n_reads, read_len) of ASCII bases on cuda:`device`. A positive read spells read_len - k + 1
     consecutive k-mers of the dictionary (ids id .. id + read_len - k: a read that runs past the end of its string continues in
     the next one, as a chimeric read would), every other one reverse-complemented, then gets substitutions at `substitution_rate`
-    per base; the other reads are uniformly random; 'N' replaces a base at `n_rate`. k <= 31."""
+    per base; the other reads are uniformly random; 'N' replaces a base at `n_rate`."""
     import torch
 
     dev = torch.device("cuda", device)
-    k, nk = d.k(), d.num_kmers()
-    if d.words_per_kmer() != 1:
-        raise ValueError("make_reads_device: k <= 31")
+    k, nk, W = d.k(), d.num_kmers(), d.words_per_kmer()
     g = torch.Generator(device=dev)
     g.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
     stream = torch.cuda.current_stream(dev).cuda_stream
     span = read_len - k + 1
     out = torch.empty((n_reads, read_len), dtype=torch.uint8, device=dev)
-    chunk = max(1, (1 << 26) // span)
+    chunk = max(1, (1 << 26) // (span * W))
     alphabet = torch.tensor(list(b"ACTG"), dtype=torch.uint8, device=dev)  # the reference's 2-bit codes (include/kmer.hpp:118)
     comp = torch.tensor([2, 3, 0, 1], dtype=torch.int64, device=dev)       # A<->T, C<->G as codes
     for at in range(0, n_reads, chunk):
         m = min(chunk, n_reads - at)
         first = torch.randint(0, max(1, nk - span), (m,), generator=g, device=dev, dtype=torch.int64)
         ids = (first[:, None] + torch.arange(span, device=dev, dtype=torch.int64)[None, :]).reshape(-1).contiguous()
-        km = torch.empty(m * span, dtype=torch.int64, device=dev)
+        km = torch.empty((m * span, W), dtype=torch.int64, device=dev)
         d.access_packed_device(device, ids.data_ptr(), m * span, km.data_ptr(), stream=stream)
-        km = km.reshape(m, span)
+        km = km.reshape(m, span, W)
         codes = torch.empty((m, read_len), dtype=torch.int64, device=dev)
-        codes[:, :span] = km & 3
-        last = km[:, span - 1]
+        codes[:, :span] = km[:, :, 0] & 3  # the first base of every k-mer of the run ...
+        last = km[:, span - 1, :]          # ... and the other k - 1 bases of the last one (base j: bits 2j, 2j+1 of its words)
         for j in range(1, k):
-            codes[:, span - 1 + j] = (last >> (2 * j)) & 3
+            codes[:, span - 1 + j] = (last[:, j // 32] >> (2 * (j % 32))) & 3
         flip = torch.rand(m, generator=g, device=dev) < 0.5
         codes = torch.where(flip[:, None], comp[codes.flip(1)], codes)
         sub = torch.rand((m, read_len), generator=g, device=dev) < substitution_rate

@@ -79,3 +79,23 @@ def test_two_ranks_route_one_batch_over_a_partitioned_dictionary(how, tmp_path):
     r = run_bench(["--gpus", "2", "--no-cpu-baseline", "--sharded", how], {"SSHASH_BENCH_TEST_ALL_RANKS_ON_DEVICE": "0"}, tmp_path)
     assert r["n_gpus"] == 2 and r["config"]["sharded"] == how and r["config"]["index_replicated_per_gpu"] is False
     assert sum(p["queries"] for p in r["per_rank"]) == 4000000 and abs(r["config"]["positive_fraction_found"] - 0.5) < 0.01
+
+
+def test_config_c4_line(tmp_path):
+    """`bench.py --workload c4` (human k = 63, m = 25 stand-in) at reduced size: the two-word path behind the same line -- statistics
+    against the published k = 63 build, the table-less paths, and the FASTQ query with its counters equal to the oracle's."""
+    env = dict(os.environ, SSHASH_BENCH_CACHE=str(tmp_path))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = ["--workload", "c4", "--bases", "30000000", "--queries", "2000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--file-reads", "100000"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert r["config"]["k"] == 63 and r["config"]["m"] == 25 and r["dtype"] == "u64" and r["config"]["recipe"] == "human_k63"
+    assert r["config"]["index_statistics"]["source"].startswith("benchmarks/results-10-11-25/k63/regular-build.log")
+    assert abs(r["config"]["positive_fraction_found"] - 0.5) < 0.01
+    assert all(v["ids_equal_table_path"] for v in r["other_paths"].values())
+    f = r["streaming_from_file"]
+    assert f["counters_equal_oracle_on_sample"] is True and f["kmers"] == 100000 * (150 - 63 + 1)
+    assert f["fastq"]["report"] == f["fastq.gz"]["report"] and f["fastq"]["report"]["num_positive_kmers"] > 0
+    assert f["published_reference"]["ns_per_kmer"] == 190.6

@@ -266,15 +266,19 @@ def test_batch_larger_than_one_launch_piece(case_se_regular):
 
 
 @pytest.mark.parametrize("settings", [{"SSHASH_AMD_DIRECTORY": "0", "SSHASH_AMD_SKTABLE": "0"}, {"SSHASH_AMD_SKTABLE": "0"}, {},
-                                      {"SSHASH_AMD_DIRECTORY": "1"}, {"SSHASH_AMD_SK_SLOTS_PER_KEY": "1.2", "SSHASH_AMD_SK_SLOTS_PER_KMER": "1.2"}],
-                         ids=["mphf_only", "directory_only", "sktable_lean", "sktable_over_directory", "sktable_packed_tight"])
+                                      {"SSHASH_AMD_DIRECTORY": "1"}, {"SSHASH_AMD_SK_SLOTS_PER_KEY": "1.2", "SSHASH_AMD_SK_SLOTS_PER_KMER": "1.2"}, {"SSHASH_AMD_PIECE": "4096"},
+                                      {"SSHASH_AMD_PIECE": "4096", "SSHASH_AMD_SKTABLE": "0"}],
+                         ids=["mphf_only", "directory_only", "sktable_lean", "sktable_over_directory", "sktable_packed_tight",
+                              "many_launch_pieces", "many_launch_pieces_no_table"])
 def test_accelerators_disabled(tmp_path, settings):
     """The lookup structures are layered (device_layout.hpp (3)-(5)): with the super-k-mer table and/or
     the minimizer directory switched off (also what an over-wide dictionary gets) the remaining path must
     give the same ids / membership / full results as the oracle. sktable_lean is the default replica: the table over
     bit-packed codewords, no directory; sktable_over_directory forces the round-2 layout; sktable_packed_tight fills both
     regions of the table (the keys', the heavy keys' k-mers') to a load factor of 0.83: long bucket sequences, and items
-    that find no slot and are left to the complete path."""
+    that find no slot and are left to the complete path; many_launch_pieces cuts every batch into sequences of 4096 queries:
+    the two sets of queues used in turn, the deferred pass of one sequence on the auxiliary stream beside the next one's
+    first pass (k <= 31 with the table), everything in order on the caller's stream otherwise."""
     import os
     import subprocess
     import sys
@@ -317,6 +321,7 @@ def test_accelerators_disabled(tmp_path, settings):
     env = dict(os.environ)
     env.pop("SSHASH_AMD_DIRECTORY", None)
     env.pop("SSHASH_AMD_SKTABLE", None)
+    env.pop("SSHASH_AMD_PIECE", None)
     env.update(settings)
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "LAYERS OK" in p.stdout, p.stdout + p.stderr
