@@ -92,7 +92,10 @@
 //               however many thousand occurrences the key has (what the reference's skew index does for its heavy
 //               buckets, include/sparse_and_skew_index.hpp:34-44, with the table's own machinery).
 //               The k-mers' copies live in a range of buckets of their own behind the keys' (sk_view::kmer_buckets), packed
-//               tighter: only the probes that met a marker pay for its second choices.
+//               tighter: only the probes that met a marker pay for its second choices. At k <= 63 an entry there is not a copy
+//               of the 64-byte slot but 32 bytes -- d0 valid + (entry 0) the bucket's flags and filter | d1 string id |
+//               d2,d3 position of the K-MER | fingerprint << 40 | d4-d7 the k-mer as the strings spell it -- two to a bucket,
+//               one 64-byte line: the region takes half the bytes and a probe never needs a second line.
 //        flags  go-on flag c of a bucket says "a key whose c-th choice is this bucket lives further along its
 //               sequence"; a probe that finds neither its k-mer nor that flag is a final miss -- negative
 //               queries end after ~1.1 line reads. The last choice's flag (a key or k-mer that found no slot at all)
@@ -195,7 +198,7 @@ constexpr uint32_t SK_ABSENT_DISABLED = 1, SK_ABSENT_MINIMIZER_SHARD = 2, SK_ABS
                    SK_ABSENT_NO_MEMORY = 5;
 
 struct sk_view {
-    void const* slots;    // (num_buckets + kmer_buckets) x 2 slots of 32 bytes (k <= 31) or of 64 bytes (k <= 63)
+    void const* slots;    // num_buckets x 2 slots of 32 bytes (k <= 31) or of 64 bytes (k <= 63), then kmer_buckets x 2 entries of 32 bytes
     uint32_t num_buckets; // the region the keys hash into: inline slots and markers
     uint32_t enabled;
     /* the heavy keys' k-mers (keyed by sk_kmer_key) have a region of their own behind the keys' -- buckets num_buckets ..

@@ -639,6 +639,47 @@ __device__ __forceinline__ void sk_examine_slot(dict_view const& d, sk_query_t<W
     r.outcome = hit ? int(FAST_HIT) : r.outcome;
 }
 
+/* k <= 63: one ENTRY of the k-mers' region (device_layout.hpp: 32 bytes -- meta, string id, position | fingerprint, the
+   k-mer as the strings spell it) against one query; two entries make a bucket, one 64-byte line. `piece(0)`, `piece(1)`: the
+   entry's two 16-byte pieces. FIRST: entry 0 carries the bucket's go-on flags and filter, like slot 0 of the keys' region. */
+template <bool FIRST, class Piece>
+__device__ __forceinline__ void sk_examine_kmer_entry(sk_query_t<2> const Q, uint32_t c, Piece piece, fast_t& r, sk_bucket_flags& flags) {
+    kmer_w<2> y, y_rc;
+    for (int t = 0; t < 2; ++t) {
+        y.w[t] = Q.y.w[t];
+        y_rc.w[t] = Q.y_rc.w[t];
+    }
+    const uint4 q0 = piece(0), q1 = piece(1);
+    const uint32_t meta = q0.x;
+    if constexpr (FIRST) {
+        uint32_t go_on = meta & (SK_GO_ON << c);
+        if (c == 0) go_on &= 0u - ((meta >> (SK_FILTER_SHIFT + sk_filter_index(Q.fingerprint))) & 1u);
+        asm volatile("" : "+v"(go_on));
+        flags.go_on = go_on;
+        flags.second_used = false;  // (both entries are in the line at hand)
+    }
+    kmer_w<2> body;
+    body.w[0] = uint64_t(q1.x) | (uint64_t(q1.y) << 32);
+    body.w[1] = uint64_t(q1.z) | (uint64_t(q1.w) << 32);
+    const bool valid = (meta & SK_VALID) != 0;
+    const bool as_y = valid && kmer_eq<2>(body, y), as_rc = valid && kmer_eq<2>(body, y_rc);
+    const bool hit = as_y || as_rc;
+    r.kmer_offset = hit ? (uint64_t(q0.z) | (uint64_t(q0.w & 0xFFu) << 32)) : r.kmer_offset;
+    r.string_id = hit ? q0.y : r.string_id;
+    r.orientation = hit ? ((as_rc != Q.s) ? int8_t(-1) : int8_t(1)) : r.orientation;
+    r.outcome = hit ? int(FAST_HIT) : r.outcome;
+}
+
+/* where the bucket with (global) index b starts, in bytes from d.sk.slots: the keys' region holds 64 W bytes per bucket; behind it,
+   at k <= 63, the k-mers' region holds 64 (two compact entries) */
+template <int W>
+__device__ __forceinline__ uint64_t sk_bucket_offset(dict_view const& d, uint32_t b, bool kmer_region) {
+    if constexpr (W == 2) {
+        if (kmer_region) return uint64_t(d.sk.num_buckets) * 128 + uint64_t(b - d.sk.num_buckets) * 64;
+    }
+    return uint64_t(b) * (64 * W);
+}
+
 /* Where a probe stands: the bucket sequence it follows (its key's, or -- once it has met its key's marker -- its
    k-mer's own), the next choice of it, and the choice of the key's sequence to come back to if the k-mer's sequence
    ends without the k-mer (the marker may have been another key's with an equal fingerprint). */
@@ -741,12 +782,24 @@ __device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& 
     }
 #pragma unroll 1
     while (more) {
-        const uint4* B = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(sk_choice(w.h, w.c));
+        /* k <= 63: the k-mers' region holds compact entries. (By the bucket's index, not by w.on_kmer_sequence: that stays set when a
+           probe comes back to the rest of its key's sequence.) */
+        const uint32_t bucket = sk_choice(w.h, w.c);
+        const bool compact = W == 2 && bucket >= d.sk.num_buckets;
+        const uint4* B = reinterpret_cast<const uint4*>(static_cast<char const*>(d.sk.slots) + sk_bucket_offset<W>(d, bucket, compact));
         sk_bucket_flags flags;
         bool marker = false, seen = false;
-        sk_examine_slot<W, true>(d, Q, w.c, [B](uint32_t i) { return B[i]; }, r, seen, marker, flags);
-        if (r.outcome == FAST_MISS && flags.second_used)
-            sk_examine_slot<W, false>(d, Q, w.c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags);
+        if constexpr (W == 2) {
+            if (compact) {
+                sk_examine_kmer_entry<true>(Q, w.c, [B](uint32_t i) { return B[i]; }, r, flags);
+                sk_examine_kmer_entry<false>(Q, w.c, [B](uint32_t i) { return B[2 + i]; }, r, flags);
+            }
+        }
+        if (!compact) {
+            sk_examine_slot<W, true>(d, Q, w.c, [B](uint32_t i) { return B[i]; }, r, seen, marker, flags);
+            if (r.outcome == FAST_MISS && flags.second_used)
+                sk_examine_slot<W, false>(d, Q, w.c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags);
+        }
         key_seen = key_seen || (seen && !w.on_kmer_sequence);
         const uint32_t go_on = flags.go_on;
         more = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
@@ -782,8 +835,8 @@ __device__ __forceinline__ uint4 sk_load_piece(char const* p) {
 
 /* LINE: which 64-byte line of the bucket (k <= 31: the bucket is one line holding both slots; k <= 63: line 0 = slot 0,
    line 1 = slot 1, fetched only by the lanes that still need it) */
-template <int W>
-__device__ __forceinline__ void sk_stage_lines(dict_view const& d, uint32_t bucket, uint32_t line, bool need, uint4* wave_stage) {
+template <int W, bool MIXED = false>
+__device__ __forceinline__ void sk_stage_lines(dict_view const& d, uint32_t bucket, uint32_t line, bool need, uint4* wave_stage, bool kmer_region = false) {
     char const* slots = static_cast<char const*>(d.sk.slots);
     const uint32_t sub = threadIdx.x & 3u;
     /* a 32-bit line number would overflow at k <= 63 (2 lines per bucket, up to 2^32 buckets): keep bucket and line apart */
@@ -796,8 +849,17 @@ __device__ __forceinline__ void sk_stage_lines(dict_view const& d, uint32_t buck
         l2 = quad_broadcast<2>(my_line);
         l3 = quad_broadcast<3>(my_line);
     }
-    const uint64_t a0 = uint64_t(b0) * (64 * W) + 64 * l0, a1 = uint64_t(b1) * (64 * W) + 64 * l1, a2 = uint64_t(b2) * (64 * W) + 64 * l2,
-                   a3 = uint64_t(b3) * (64 * W) + 64 * l3;
+    uint64_t a0 = uint64_t(b0) * (64 * W) + 64 * l0, a1 = uint64_t(b1) * (64 * W) + 64 * l1, a2 = uint64_t(b2) * (64 * W) + 64 * l2,
+             a3 = uint64_t(b3) * (64 * W) + 64 * l3;
+    if constexpr (W == 2 && MIXED) {
+        /* some owners are on their k-mer's sequence: those buckets are single lines of the k-mers' region (sk_bucket_offset) */
+        const uint32_t mine_region = need && kmer_region ? 1u : 0u;
+        const uint64_t base = uint64_t(d.sk.num_buckets) * 128, first = d.sk.num_buckets;
+        if (quad_broadcast<0>(mine_region)) a0 = base + uint64_t(b0 - first) * 64;
+        if (quad_broadcast<1>(mine_region)) a1 = base + uint64_t(b1 - first) * 64;
+        if (quad_broadcast<2>(mine_region)) a2 = base + uint64_t(b2 - first) * 64;
+        if (quad_broadcast<3>(mine_region)) a3 = base + uint64_t(b3 - first) * 64;
+    }
     const uint32_t lane = threadIdx.x & 63u;
     /* nontemporal: a bucket line is not read again before a few hundred million others have passed */
     const uint4 p0 = sk_load_piece(slots + a0 + 16 * sub), p1 = sk_load_piece(slots + a1 + 16 * sub),
@@ -816,18 +878,27 @@ __device__ __forceinline__ void sk_stage_lines(dict_view const& d, uint32_t buck
 /* One bucket for every lane with need = true: fetch (cooperatively) and examine. Called by all 64 lanes. k <= 31: one
    line, both slots compared. k <= 63: slot 0's line; the lanes that neither hit nor can rule slot 1 out (its "in use" bit
    sits in slot 0) fetch the second line in a second round -- 1.3 lines per probe instead of 2. */
-template <int W>
+template <int W, bool MIXED = false>
 __device__ __forceinline__ void sk_probe_bucket_wave(dict_view const& d, sk_query_t<W> const& Q, uint32_t bucket, uint32_t c, bool need,
-                                                     uint4* wave_stage, fast_t& r, bool& key_seen, bool& marker, uint32_t& go_on) {
+                                                     uint4* wave_stage, fast_t& r, bool& key_seen, bool& marker, uint32_t& go_on,
+                                                     bool kmer_region = false) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint4* mine = wave_stage + (lane & 3u) * 64 + (lane >> 2) * 4;  // region (lane & 3), line of quad (lane >> 2)
     sk_bucket_flags flags;
     flags.go_on = 0;
     flags.second_used = false;
-    sk_stage_lines<W>(d, bucket, 0u, need, wave_stage);
-    if (need) {
+    sk_stage_lines<W, MIXED>(d, bucket, 0u, need, wave_stage, kmer_region);
+    bool compact = false;
+    if constexpr (W == 2 && MIXED) compact = kmer_region;  // MIXED: lanes on their k-mer's sequence (k <= 63: compact entries) among the others
+    if (need && !compact) {
         sk_examine_slot<W, true>(d, Q, c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
         if constexpr (W == 1) sk_examine_slot<W, false>(d, Q, c, [mine](uint32_t i) { return mine[2 + i]; }, r, key_seen, marker, flags);
+    }
+    if constexpr (W == 2 && MIXED) {
+        if (need && compact) {
+            sk_examine_kmer_entry<true>(Q, c, [mine](uint32_t i) { return mine[i]; }, r, flags);
+            sk_examine_kmer_entry<false>(Q, c, [mine](uint32_t i) { return mine[2 + i]; }, r, flags);
+        }
     }
     if constexpr (W == 2) {
         __builtin_amdgcn_wave_barrier();
@@ -975,7 +1046,8 @@ __device__ __forceinline__ fast_t sk_second_pass_wave(dict_view const& d, kmer_w
     while (__ballot(need) != 0) {  // wave-uniform
         uint32_t go_on = 0;
         bool marker = false, key_seen = false;
-        sk_probe_bucket_wave<W>(d, Q, need ? sk_choice(w.h, w.c) : 0u, w.c, need, wave_stage, r, key_seen, marker, go_on);
+        const uint32_t bucket = need ? sk_choice(w.h, w.c) : 0u;
+        sk_probe_bucket_wave<W, true>(d, Q, bucket, w.c, need, wave_stage, r, key_seen, marker, go_on, bucket >= d.sk.num_buckets);
         if (need) need = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
     }
     if (r.outcome == FAST_MISS || (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc)) {

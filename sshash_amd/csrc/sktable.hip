@@ -200,7 +200,7 @@ sk_heavy_kmers_kernel(const dict_view d, const uint64_t first_tuple, const uint6
         if (mine) {
             const uint64_t at = base + uint64_t(__popcll(ballot & ((uint64_t(1) << lane) - 1)));
             item_keys[at] = key;
-            item_vals[at] = v;
+            item_vals[at] = v | (uint64_t(a) << SK_LEN_SHIFT);  // a: where the k-mer starts relative to the occurrence (p + a - km)
         }
     }
 }
@@ -208,7 +208,7 @@ sk_heavy_kmers_kernel(const dict_view d, const uint64_t first_tuple, const uint6
 /* One lane per item, one launch per bucket choice: claim the first free slot of the item's bucket of this choice and
    fill it; an item that finds the bucket full sets the bucket's go-on flag and waits for the next round (after the
    last one: it is left to the complete path). flags == nullptr: every item is an inline slot (the heavy keys' k-mers). */
-template <int W>
+template <int W, bool COMPACT = false>
 __global__ void __launch_bounds__(256)
 sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_items, const uint64_t* __restrict__ item_keys,
                 const uint64_t* __restrict__ item_vals, const uint8_t* __restrict__ flags, uint32_t* __restrict__ slots,
@@ -227,12 +227,15 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
             placed[t] = 1;
         } else {
             const sk_hash_t h = sk_hash(item_keys[t], num_buckets);
-            uint32_t* B = slots + (SK_BUCKET_SLOTS * 8 * W) * uint64_t(h.bucket[choice]);  // slot 0 of the bucket: carries the flags
+            /* COMPACT (k <= 63, the heavy keys' k-mers): 32-byte entries, two to a 64-byte bucket -- meta, string id, position of the
+               K-MER | fingerprint, the k-mer itself (lookup_device.hpp: sk_examine_kmer_entry) */
+            constexpr uint32_t SLOT_WORDS = COMPACT ? 8u : 8u * W;
+            uint32_t* B = slots + (SK_BUCKET_SLOTS * SLOT_WORDS) * uint64_t(h.bucket[choice]);  // slot 0 of the bucket: carries the flags
             /* claim the first free slot of the bucket: set its valid bit unless somebody holds it (other lanes may be
                OR-ing flags into slot 0's word) */
             uint32_t* S = nullptr;
             for (uint32_t slot = 0; slot < SK_BUCKET_SLOTS && !S; ++slot) {
-                uint32_t* T = B + slot * (8 * W);
+                uint32_t* T = B + slot * SLOT_WORDS;
                 uint32_t cur = __hip_atomic_load(T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 while (!(cur & SK_VALID)) {
                     const uint32_t seen = atomicCAS(T, cur, cur | SK_VALID);
@@ -254,7 +257,7 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
                     atomicOr(B, SK_SECOND_USED);
                     /* k <= 63: slot 1 lives in the bucket's second line; its fingerprint is kept in slot 0's spare bytes, so
                        that a probe fetches that line only when its own key is there */
-                    if constexpr (W == 2) B[SK_SECOND_FINGERPRINT_WORD] = h.fingerprint;
+                    if constexpr (W == 2 && !COMPACT) B[SK_SECOND_FINGERPRINT_WORD] = h.fingerprint;
                 }
                 uint32_t meta, d1;
                 uint64_t w1;
@@ -262,7 +265,14 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
                 for (int i = 0; i < 2 * W; ++i) body[i] = 0;
                 const uint64_t v = item_vals[t] & SK_VAL_MASK;
                 const uint64_t p = v >> 1;
-                if (kind == SK_ITEM_INLINE) {
+                if constexpr (COMPACT) {
+                    const uint64_t start = p + (item_vals[t] >> SK_LEN_SHIFT) - (d.k - d.m);
+                    const window_t<W> w = read_window<W>(d.granules, start, d.k);
+                    meta = 0;
+                    d1 = w.string_id;
+                    w1 = start | (uint64_t(h.fingerprint) << 40);
+                    for (int i = 0; i < W; ++i) body[i] = w.kmer.w[i];
+                } else if (kind == SK_ITEM_INLINE) {
                     const uint32_t km = d.k - d.m;
                     const uint32_t sid = read_window<W>(d.granules, p, 1).string_id;
                     const uint64_t s_begin = d.endpoints[sid], s_end = d.endpoints[sid + 1];
@@ -279,7 +289,7 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
                 }
                 S[1] = d1;
                 reinterpret_cast<uint64_t*>(S)[1] = w1;
-                for (int i = 0; i < 2 * W; ++i) reinterpret_cast<uint64_t*>(S)[2 + i] = body[i];
+                for (int i = 0; i < (COMPACT ? W : 2 * W); ++i) reinterpret_cast<uint64_t*>(S)[2 + i] = body[i];
                 if (meta) atomicOr(S, meta);
             }
         }
@@ -477,21 +487,25 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     const uint64_t key_buckets = uint64_t(double(wanted - heavy_kmers) * slots_per_key / SK_BUCKET_SLOTS) + 8;
     const uint64_t kmer_buckets = heavy_kmers ? uint64_t(double(heavy_kmers) * slots_per_kmer / SK_BUCKET_SLOTS) + 8 : 0;
     const uint64_t num_buckets = key_buckets + kmer_buckets;
-    const uint64_t num_slots = num_buckets * SK_BUCKET_SLOTS;
     const uint64_t slot_bytes = wide ? 64 : 32;
+    /* k <= 63: an entry of the k-mers' region is 32 bytes (the k-mer itself instead of its super-k-mer's 128 bases) */
+    const uint64_t table_bytes = key_buckets * SK_BUCKET_SLOTS * slot_bytes + kmer_buckets * SK_BUCKET_SLOTS * 32;
     if (num_buckets >= (uint64_t(1) << 32)) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);
     {
         size_t free_bytes = 0, total_bytes = 0;
         HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
-        if (num_slots * slot_bytes > free_bytes / 2) return absent(rep, SK_ABSENT_NO_MEMORY);  // leave HBM for the caller's batches
+        if (table_bytes > free_bytes / 2) return absent(rep, SK_ABSENT_NO_MEMORY);  // leave HBM for the caller's batches
         /* SSHASH_AMD_HBM_BUDGET (bytes): what ONE replica may hold -- how a deployment keeps room for several dictionaries,
            and how the tests make a dictionary "larger than the HBM" on a box whose HBM it would fit many times over */
         const uint64_t budget = hbm_budget();
-        if (budget && rep.bytes + num_slots * slot_bytes > budget) return absent(rep, SK_ABSENT_NO_MEMORY);
+        if (budget && rep.bytes + table_bytes > budget) return absent(rep, SK_ABSENT_NO_MEMORY);
     }
-    uint32_t* slots = tmp.alloc<uint32_t>(num_slots * slot_bytes / 4);
+    uint32_t* slots = tmp.alloc<uint32_t>(table_bytes / 4);
+    if (const char* e = std::getenv("SSHASH_AMD_VERBOSE"); e && e[0] == '1')
+        std::fprintf(stderr, "[sshash_amd] super-k-mer table: %.3f GB at %p (keys' region %llu buckets, k-mers' region %llu)\n", double(table_bytes) / 1e9,
+                     (void*)slots, (unsigned long long)key_buckets, (unsigned long long)kmer_buckets);
     uint8_t* placed = tmp.alloc<uint8_t>(T + heavy_kmers);
-    HIP_CHECK(hipMemset(slots, 0, num_slots * slot_bytes));
+    HIP_CHECK(hipMemset(slots, 0, table_bytes));
     HIP_CHECK(hipMemset(placed, 0, T + heavy_kmers));
     /* Rounds: one per bucket choice; the FIRST choice in three turns, long super-k-mers first. At load factor 0.4 with two
        slots per bucket 7.2 % of the items do not fit their first bucket whatever the order (Poisson), but WHICH items
@@ -506,7 +520,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
         if (wide) {
             hipLaunchKernelGGL(sk_place_kernel<2>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(key_buckets), placed, stats, lo, hi);
             if (heavy_kmers && with_heavy_kmers)
-                hipLaunchKernelGGL(sk_place_kernel<2>, g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, kmer_slots,
+                hipLaunchKernelGGL((sk_place_kernel<2, true>), g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, kmer_slots,
                                    uint32_t(kmer_buckets), placed + T, stats, 0u, 63u);
         } else {
             hipLaunchKernelGGL(sk_place_kernel<1>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(key_buckets), placed, stats, lo, hi);
@@ -524,7 +538,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
 
     tmp.keep(slots);
     rep.allocations.push_back(slots);
-    rep.bytes += num_slots * slot_bytes;
+    rep.bytes += table_bytes;
     {
         unsigned long long hist[2 * SK_HIST_BINS];
         HIP_CHECK(hipMemcpy(hist, stats + 8, sizeof(hist), hipMemcpyDeviceToHost));
@@ -537,7 +551,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     rep.sk_heavy_kmers = heavy_kmers;
     rep.sk_unplaced = h_stats[2];
     rep.sk_slots_used = h_stats[3];
-    rep.sk_bytes = num_slots * slot_bytes;
+    rep.sk_bytes = table_bytes;
     rep.sk_absent_reason = 0;
     v.sk.slots = slots;
     v.sk.num_buckets = uint32_t(key_buckets);
