@@ -210,11 +210,12 @@ def measure_streaming_from_file(d, index_path, reads_tensor, directory, tag, ora
     res = {"reads": int(n), "read_length": int(L), "kmers": int(n) * (L - k + 1)}
     exe = os.path.join(directory, "reader_rate")
     have_exe = subprocess.call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tools", "reader_rate.cpp"),
-                                os.path.join(ROOT, "sshash_amd", "csrc", "reads.cpp"), "-lz", "-o", exe]) == 0
-    for flavour, level in (("fastq", None), ("fastq.gz", gzip_level)):
+                                os.path.join(ROOT, "sshash_amd", "csrc", "reads.cpp"), "-lz", "-lpthread", "-o", exe]) == 0
+    # plain; gzip (one deflate stream after another: inflated on one thread, like the reference's input); BGZF (bgzip's members: on all cores)
+    for flavour, level in (("fastq", None), ("fastq.gz", gzip_level), ("bgzf.fastq.gz", gzip_level)):
         path = os.path.join(directory, f"sshash_amd_{tag}.{flavour}")
         t0 = time.perf_counter()
-        size = write_fastq(reads_tensor, path, gzip_level=level, workers=max(1, (os.cpu_count() or 8) // 2))
+        size = write_fastq(reads_tensor, path, gzip_level=level, workers=max(1, (os.cpu_count() or 8) // 2), bgzf=flavour.startswith("bgzf"))
         log(f"{path}: {size / 1e9:.2f} GB written in {time.perf_counter() - t0:.1f}s")
         d.streaming_query_from_file(path)  # (page cache warm, pools sized: the reference's numbers are warm-cache too)
         t0 = time.perf_counter()

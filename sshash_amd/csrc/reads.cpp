@@ -6,9 +6,14 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <stdexcept>
+#include <thread>
 
 namespace sshash_amd {
 
@@ -19,21 +24,154 @@ bool ends_with(std::string const& s, char const* suffix) {
     return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
 }
 
-/* Lines of a (possibly gzip-compressed) file: the file is inflated a block of megabytes at a time (gzread) and split with
-   memchr; a line is handed out as a view into the block -- no per-line gzgets, no per-line std::string. (Round 2 assembled
-   every line with gzgets into a std::string: 0.2 GB/s on uncompressed FASTQ, below zlib's own inflate rate; this reader
-   splits at several GB/s, so an uncompressed file is read at the page cache's pace and a .gz at zlib's.) */
+/* ---- BGZF (bgzip, htslib) -------------------------------------------------------------------------------------
+   A plain .gz is one deflate stream: it inflates on one thread, at zlib's 0.28 G bases/s, and that is what the file query
+   then runs at. A BGZF file -- what bgzip writes, a series of gzip members of at most 64 KiB each
+   whose header says how long the member is (extra subfield 'B','C': BSIZE) -- needs no decoding to find its members, so
+   they are inflated side by side: a group of members is read, their sizes are in their last four bytes (ISIZE), every
+   worker inflates a share of them into its place of the group's output, CRC-checked; the next group is decoded while the
+   lines of this one are being split. Recognised by its first header; anything else goes through gzread as before. */
+struct bgzf_source {
+    FILE* f = nullptr;
+    unsigned threads = 1;
+    struct group {
+        std::vector<unsigned char> packed;  // the members, back to back
+        std::unique_ptr<char[]> out;        // (not a vector: no zero-fill of what inflate is about to write)
+        size_t out_size = 0;
+        size_t taken = 0;
+        bool last = false;
+    };
+    std::future<std::unique_ptr<group>> ahead;
+    std::unique_ptr<group> cur;
+
+    static constexpr size_t GROUP_PACKED = size_t(8) << 20;  // compressed bytes per group (a few hundred members)
+
+    static bool is_bgzf_header(unsigned char const* h) {
+        return h[0] == 31 && h[1] == 139 && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+    }
+    /* does the file start with a BGZF member? */
+    static bool probe(std::string const& filename) {
+        FILE* g = fopen(filename.c_str(), "rb");
+        if (!g) return false;
+        unsigned char h[18];
+        const bool yes = fread(h, 1, 18, g) == 18 && is_bgzf_header(h);
+        fclose(g);
+        return yes;
+    }
+    explicit bgzf_source(std::string const& filename) {
+        f = fopen(filename.c_str(), "rb");
+        if (!f) throw error(error_kind::io, "error in opening the file '" + filename + "'");
+        threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        if (char const* e = std::getenv("SSHASH_AMD_READER_THREADS")) threads = unsigned(std::max(1l, std::min(64l, std::atol(e))));
+        ahead = std::async(std::launch::async, [this] { return decode_group(); });
+    }
+    ~bgzf_source() {
+        if (ahead.valid()) {
+            try { ahead.get(); } catch (...) {}
+        }
+        if (f) fclose(f);
+    }
+    bgzf_source(bgzf_source const&) = delete;
+    bgzf_source& operator=(bgzf_source const&) = delete;
+
+    std::unique_ptr<group> decode_group() {
+        auto g = std::make_unique<group>();
+        struct member { size_t at, size, out_at, out_size; };
+        std::vector<member> members;
+        size_t out_total = 0;
+        while (g->packed.size() < GROUP_PACKED) {
+            unsigned char h[18];
+            const size_t got = fread(h, 1, 18, f);
+            if (got == 0) { g->last = true; break; }
+            if (got != 18 || !is_bgzf_header(h)) throw error(error_kind::io, "error while reading the query file: not a BGZF member where one was expected");
+            const size_t size = size_t(h[16]) + (size_t(h[17]) << 8) + 1;  // whole member, header and trailer included
+            if (size < 18 + 8) throw error(error_kind::io, "error while reading the query file: BGZF member too short");
+            const size_t at = g->packed.size();
+            g->packed.resize(at + size);
+            memcpy(g->packed.data() + at, h, 18);
+            if (fread(g->packed.data() + at + 18, 1, size - 18, f) != size - 18) throw error(error_kind::io, "error while reading the query file: truncated BGZF member");
+            unsigned char const* t = g->packed.data() + at + size - 4;
+            const size_t isize = size_t(t[0]) | (size_t(t[1]) << 8) | (size_t(t[2]) << 16) | (size_t(t[3]) << 24);
+            members.push_back({at, size, out_total, isize});
+            out_total += isize;
+        }
+        g->out.reset(new char[std::max<size_t>(out_total, 1)]);
+        g->out_size = out_total;
+        std::atomic<size_t> next{0};
+        std::atomic<bool> bad{false};
+        auto work = [&] {
+            z_stream z;
+            memset(&z, 0, sizeof(z));
+            if (inflateInit2(&z, -15) != Z_OK) { bad = true; return; }  // raw deflate: the member's header and trailer are handled here
+            for (;;) {
+                const size_t first = next.fetch_add(16);
+                if (first >= members.size() || bad) break;
+                for (size_t i = first; i < std::min(first + 16, members.size()); ++i) {
+                    member const& m = members[i];
+                    unsigned char const* p = g->packed.data() + m.at;
+                    inflateReset(&z);
+                    z.next_in = const_cast<unsigned char*>(p + 18);
+                    z.avail_in = unsigned(m.size - 18 - 8);
+                    z.next_out = reinterpret_cast<unsigned char*>(g->out.get() + m.out_at);
+                    z.avail_out = unsigned(m.out_size);
+                    const int rc = inflate(&z, Z_FINISH);
+                    unsigned char const* t = p + m.size - 8;
+                    const uint32_t crc = uint32_t(t[0]) | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
+                    if (rc != Z_STREAM_END || z.avail_out != 0 ||
+                        uint32_t(crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<unsigned char const*>(g->out.get() + m.out_at), unsigned(m.out_size))) != crc)
+                        bad = true;
+                }
+            }
+            inflateEnd(&z);
+        };
+        const unsigned n = unsigned(std::min<size_t>(threads, (members.size() + 15) / 16));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n; ++t) pool.emplace_back(work);
+        if (!members.empty()) work();
+        for (auto& t : pool) t.join();
+        if (bad) throw error(error_kind::io, "error while reading the query file: corrupt BGZF member");
+        g->packed.clear();
+        g->packed.shrink_to_fit();
+        return g;
+    }
+    /* up to `room` inflated bytes; 0 = end of file */
+    size_t read(char* dst, size_t room) {
+        for (;;) {
+            if (cur && cur->taken < cur->out_size) {
+                const size_t n = std::min(room, cur->out_size - cur->taken);
+                memcpy(dst, cur->out.get() + cur->taken, n);
+                cur->taken += n;
+                return n;
+            }
+            if (cur && cur->last) return 0;
+            cur = ahead.get();  // rethrows a worker's error
+            if (!cur->last) ahead = std::async(std::launch::async, [this] { return decode_group(); });
+        }
+    }
+};
+
+/* Lines of a (possibly gzip-compressed) file: the file is inflated a block of megabytes at a time (gzread; BGZF: above) and
+   split with memchr; a line is handed out as a view into the block -- no per-line gzgets, no per-line std::string. (Round 2
+   assembled every line with gzgets into a std::string: 0.2 GB/s on uncompressed FASTQ, below zlib's own inflate rate; this
+   reader splits at several GB/s, so an uncompressed file is read at the page cache's pace and a .gz at zlib's.) */
 struct line_reader {
-    gzFile f;
+    gzFile f = nullptr;
+    std::unique_ptr<bgzf_source> bgzf;
     std::vector<char> buf;
     size_t begin = 0, end = 0;
     bool eof = false;
     explicit line_reader(std::string const& filename) : buf(size_t(8) << 20) {
+        if (bgzf_source::probe(filename)) {
+            bgzf = std::make_unique<bgzf_source>(filename);
+            return;
+        }
         f = gzopen(filename.c_str(), "rb");
         if (!f) throw error(error_kind::io, "error in opening the file '" + filename + "'");
         gzbuffer(f, 1 << 20);
     }
-    ~line_reader() { gzclose(f); }
+    ~line_reader() {
+        if (f) gzclose(f);
+    }
     line_reader(line_reader const&) = delete;
     line_reader& operator=(line_reader const&) = delete;
     /* std::getline semantics: false once nothing at all could be read; the view (without the '\n') is valid until the next call */
@@ -61,6 +199,12 @@ struct line_reader {
             }
             if (end == buf.size()) buf.resize(buf.size() * 2);  // a line longer than the block (a chromosome on one line)
             const size_t room = std::min<size_t>(buf.size() - end, size_t(1) << 30);
+            if (bgzf) {
+                const size_t got = bgzf->read(buf.data() + end, room);
+                if (got == 0) eof = true;
+                end += got;
+                continue;
+            }
             const int got = gzread(f, buf.data() + end, unsigned(room));
             if (got < 0) throw error(error_kind::io, "error while reading the query file");
             if (got == 0) eof = true;

@@ -6,7 +6,9 @@
 //   FASTA multiline every line (headers included -- the reference does not special-case '>',
 //                   such characters simply make k-mers invalid) is concatenated until an empty
 //                   line ends the segment                                      :9-47, include/util.hpp:287-340
-// Format is chosen by file extension (.fa/.fasta/.fq/.fastq, optionally .gz)  :131-171.
+// Format is chosen by file extension (.fa/.fasta/.fq/.fastq, optionally .gz)  :131-171. A .gz is read through zlib (one
+// thread: a deflate stream does not split); a BGZF file (bgzip: gzip members with their size in the header -- any gzip reader,
+// the reference's included, reads it as a .gz) is recognised by its first header and inflated member by member on all cores.
 // Reads shorter than k are dropped here (they contribute no k-mer: :63,:92).
 #pragma once
 

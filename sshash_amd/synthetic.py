@@ -319,10 +319,33 @@ def make_reads_device(d, device: int, n_reads: int, read_len: int = 150, positiv
     return out
 
 
-def write_fastq(reads, path: str, gzip_level: int | None = None, workers: int = 8) -> int:
+def bgzf_compress(raw: bytes, level: int = 6) -> bytes:
+    """raw -> BGZF members (what bgzip / htslib write: gzip members of at most 64 KiB of input each, the member's size in the
+    'BC' extra subfield of its header; SAM/BAM specification section 4.1), without the empty end-of-file member."""
+    import struct
+    import zlib
+
+    out = []
+    for at in range(0, len(raw), 65280):
+        piece = raw[at:at + 65280]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(piece) + c.flush()
+        size = 18 + len(body) + 8
+        if size > 65536:
+            raise ValueError("bgzf_compress: a block that does not compress")
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", size - 1) + body +
+                   struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece)))
+    return b"".join(out)
+
+
+BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def write_fastq(reads, path: str, gzip_level: int | None = None, workers: int = 8, bgzf: bool = False) -> int:
     """reads: uint8 array/tensor (n, L) of ASCII bases -> a FASTQ file (4 lines per read); gzip_level: also compress -- the
     file is written as independent gzip members by `workers` processes (a multi-member .gz is what `cat a.gz b.gz` makes;
-    zlib's gzread, the reference's zip_istream and gunzip all read it as one stream). Returns the bytes written."""
+    zlib's gzread, the reference's zip_istream and gunzip all read it as one stream); bgzf: as BGZF members (bgzip's format,
+    which the file reader inflates on all cores). Returns the bytes written."""
     import os
     import zlib
     from concurrent.futures import ThreadPoolExecutor
@@ -354,6 +377,8 @@ def write_fastq(reads, path: str, gzip_level: int | None = None, workers: int = 
         raw = records(*p)
         if gzip_level is None:
             return raw
+        if bgzf:
+            return bgzf_compress(raw, gzip_level)
         c = zlib.compressobj(gzip_level, zlib.DEFLATED, 31)  # 31: gzip container
         return c.compress(raw) + c.flush()
 
@@ -362,4 +387,7 @@ def write_fastq(reads, path: str, gzip_level: int | None = None, workers: int = 
         for blob in ex.map(make, pieces):
             f.write(blob)
             total += len(blob)
+        if bgzf and gzip_level is not None:
+            f.write(BGZF_EOF)
+            total += len(BGZF_EOF)
     return total

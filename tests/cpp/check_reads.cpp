@@ -1,7 +1,7 @@
 // check_reads.cpp -- host-side check of the query-file readers (csrc/reads.cpp): read_stream hands a file over in bounded
 // batches of whole reads; whatever the batch size, the reads that come out are those of load_reads (the whole file at
 // once), in order. Formats as src/query.cpp: FASTQ (.fq), one-line FASTA (.fa), multiline FASTA. Plain g++ + zlib, no GPU.
-// usage: check_reads <file> <multiline 0|1> <k>   -> prints "OK <reads> <bases>"
+// usage: check_reads <file> <multiline 0|1> <k>   -> prints "OK <reads> <bases> <checksum of the reads>"
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -41,6 +41,9 @@ int main(int argc, char** argv) {
         if (in.next(part, batch)) return printf("a batch after the end\n"), 1;
         (void)batches;
     }
-    printf("OK %llu %llu\n", (unsigned long long)whole.num_reads(), (unsigned long long)whole.bases.size());
+    uint64_t h = 1469598103934665603ull;  // FNV-1a over the bases and the read boundaries: equal files give equal lines
+    for (char c : whole.bases) h = (h ^ uint64_t(uint8_t(c))) * 1099511628211ull;
+    for (uint64_t o : whole.offsets) h = (h ^ o) * 1099511628211ull;
+    printf("OK %llu %llu %016llx\n", (unsigned long long)whole.num_reads(), (unsigned long long)whole.bases.size(), (unsigned long long)h);
     return 0;
 }

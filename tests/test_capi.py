@@ -158,7 +158,7 @@ def test_query_file_readers_hand_over_bounded_batches(tmp_path):
         pytest.skip("no g++")
     exe = str(tmp_path / "check_reads")
     subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "check_reads.cpp"),
-                           os.path.join(ROOT, "sshash_amd", "csrc", "reads.cpp"), "-lz", "-o", exe])
+                           os.path.join(ROOT, "sshash_amd", "csrc", "reads.cpp"), "-lz", "-lpthread", "-o", exe])
     golden = os.path.join(ROOT, "tests", "golden")
     multi = tmp_path / "multi.fa"
     with gzip.open(os.path.join(golden, "se.ust.k63.head.fa.gz"), "rt") as f:
@@ -173,6 +173,26 @@ def test_query_file_readers_hand_over_bounded_batches(tmp_path):
         assert p.returncode == 0 and p.stdout.startswith("OK "), (path, multiline, p.stdout + p.stderr)
         if reads is not None:
             assert int(p.stdout.split()[1]) == reads
+    # BGZF (bgzip's format: members inflated on several threads, csrc/reads.cpp bgzf_source): the same reads as the plain file,
+    # with one worker and with many, groups of members smaller than the file; a flipped byte is an error, not different reads
+    from sshash_amd.synthetic import BGZF_EOF, bgzf_compress
+
+    raw = gzip.open(os.path.join(golden, "SRR5833294.10K.fastq.gz"), "rb").read() * 12  # 120 000 reads, 30 MB: several groups
+    plain, packed, broken = tmp_path / "big.fastq", tmp_path / "big_bgzf.fastq.gz", tmp_path / "broken.fastq.gz"
+    plain.write_bytes(raw)
+    blob = bgzf_compress(raw, 1) + BGZF_EOF
+    packed.write_bytes(blob)
+    assert gzip.open(packed, "rb").read() == raw  # what any gzip reader makes of it
+    want = subprocess.run([exe, str(plain), "0", "31"], capture_output=True, text=True, timeout=300).stdout
+    assert want.startswith("OK 120000 ")
+    for threads in ("1", "7"):
+        got = subprocess.run([exe, str(packed), "0", "31"], capture_output=True, text=True, timeout=300, env=dict(os.environ, SSHASH_AMD_READER_THREADS=threads))
+        assert got.returncode == 0 and got.stdout == want, (threads, got.stdout, got.stderr)
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 0x55
+    broken.write_bytes(bytes(bad))
+    got = subprocess.run([exe, str(broken), "0", "31"], capture_output=True, text=True, timeout=300)
+    assert got.returncode != 0 and "BGZF" in got.stderr
     txt = tmp_path / "reads.txt"
     txt.write_text("ACGT\n")
     p = subprocess.run([exe, str(txt), "0", "31"], capture_output=True, text=True, timeout=60)

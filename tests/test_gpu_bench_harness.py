@@ -55,11 +55,11 @@ def test_one_gpu_line_carries_the_contract(tmp_path):
     assert set(r["other_paths"]) == {"directory", "mphf"} and all(v["ids_equal_table_path"] and v["lookups_per_s"] > 0 for v in r["other_paths"].values())
     f = r["streaming_from_file"]
     assert f["counters_equal_oracle_on_sample"] is True and f["kmers"] == 200000 * 120
-    for flavour in ("fastq", "fastq.gz"):
+    for flavour in ("fastq", "fastq.gz", "bgzf.fastq.gz"):
         rep = f[flavour]["report"]
         assert rep["num_kmers"] == f["kmers"] == rep["num_positive_kmers"] + rep["num_negative_kmers"] + rep["num_invalid_kmers"]
         assert f[flavour]["ns_per_kmer"] > 0 and f[flavour]["reader_alone"]["reads"] == 200000
-    assert f["fastq"]["report"] == f["fastq.gz"]["report"]
+    assert f["fastq"]["report"] == f["fastq.gz"]["report"] == f["bgzf.fastq.gz"]["report"]
 
 
 def test_two_ranks_split_one_batch(tmp_path):
