@@ -37,7 +37,7 @@ struct bgzf_source {
     struct group {
         std::vector<unsigned char> packed;  // the members, back to back
         std::unique_ptr<char[]> out;        // (not a vector: no zero-fill of what inflate is about to write)
-        size_t out_size = 0;
+        size_t out_size = 0, out_capacity = 0;
         size_t taken = 0;
         bool last = false;
     };
@@ -63,7 +63,7 @@ struct bgzf_source {
         if (!f) throw error(error_kind::io, "error in opening the file '" + filename + "'");
         threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         if (char const* e = std::getenv("SSHASH_AMD_READER_THREADS")) threads = unsigned(std::max(1l, std::min(64l, std::atol(e))));
-        ahead = std::async(std::launch::async, [this] { return decode_group(); });
+        ahead = std::async(std::launch::async, [this] { return decode_group(nullptr); });
     }
     ~bgzf_source() {
         if (ahead.valid()) {
@@ -74,8 +74,13 @@ struct bgzf_source {
     bgzf_source(bgzf_source const&) = delete;
     bgzf_source& operator=(bgzf_source const&) = delete;
 
-    std::unique_ptr<group> decode_group() {
-        auto g = std::make_unique<group>();
+    /* `g`: a group whose bytes have all been handed out, to be filled again (its buffers are kept: a fresh 40 MB block per group
+       is 10 000 page faults per group) */
+    std::unique_ptr<group> decode_group(std::unique_ptr<group> g) {
+        if (!g) g = std::make_unique<group>();
+        g->packed.clear();
+        g->taken = 0;
+        g->last = false;
         struct member { size_t at, size, out_at, out_size; };
         std::vector<member> members;
         size_t out_total = 0;
@@ -95,7 +100,10 @@ struct bgzf_source {
             members.push_back({at, size, out_total, isize});
             out_total += isize;
         }
-        g->out.reset(new char[std::max<size_t>(out_total, 1)]);
+        if (out_total > g->out_capacity) {
+            g->out_capacity = out_total + out_total / 4 + 1;
+            g->out.reset(new char[g->out_capacity]);
+        }
         g->out_size = out_total;
         std::atomic<size_t> next{0};
         std::atomic<bool> bad{false};
@@ -104,7 +112,7 @@ struct bgzf_source {
             memset(&z, 0, sizeof(z));
             if (inflateInit2(&z, -15) != Z_OK) { bad = true; return; }  // raw deflate: the member's header and trailer are handled here
             for (;;) {
-                const size_t first = next.fetch_add(16);
+                const size_t first = next.fetch_add(16);  // 16 members = 1 MB of output at a time
                 if (first >= members.size() || bad) break;
                 for (size_t i = first; i < std::min(first + 16, members.size()); ++i) {
                     member const& m = members[i];
@@ -130,8 +138,6 @@ struct bgzf_source {
         if (!members.empty()) work();
         for (auto& t : pool) t.join();
         if (bad) throw error(error_kind::io, "error while reading the query file: corrupt BGZF member");
-        g->packed.clear();
-        g->packed.shrink_to_fit();
         return g;
     }
     /* up to `room` inflated bytes; 0 = end of file */
@@ -144,8 +150,12 @@ struct bgzf_source {
                 return n;
             }
             if (cur && cur->last) return 0;
+            std::unique_ptr<group> done = std::move(cur);
             cur = ahead.get();  // rethrows a worker's error
-            if (!cur->last) ahead = std::async(std::launch::async, [this] { return decode_group(); });
+            if (!cur->last) {
+                group* recycled = done.release();
+                ahead = std::async(std::launch::async, [this, recycled] { return decode_group(std::unique_ptr<group>(recycled)); });
+            }
         }
     }
 };
