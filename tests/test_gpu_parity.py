@@ -321,7 +321,8 @@ def test_accelerators_disabled(tmp_path, settings):
     env = dict(os.environ)
     env.pop("SSHASH_AMD_DIRECTORY", None)
     env.pop("SSHASH_AMD_SKTABLE", None)
-    env.pop("SSHASH_AMD_PIECE", None)
+    for name in ("SSHASH_AMD_PIECE", "SSHASH_AMD_SK_SLOTS_PER_KEY", "SSHASH_AMD_SK_SLOTS_PER_KMER"):  # (a caller's measurement switches)
+        env.pop(name, None)
     env.update(settings)
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "LAYERS OK" in p.stdout, p.stdout + p.stderr
