@@ -138,6 +138,31 @@ def test_query_file_goes_through_in_batches(case_se_regular, case_skew_regular, 
         d.streaming_query_from_file(str(tmp_path / "missing.fq"))
 
 
+def test_query_file_in_bgzf_members(case_se_regular, tmp_path):
+    """A BGZF file (bgzip: gzip members with their size in the header, inflated on several threads by csrc/reads.cpp) gives the
+    report of the plain gzip file it was made from -- also when the file spans several groups of members and batches --; a
+    corrupt member is an error through the C ABI, not a different report."""
+    import sshash_amd
+    from sshash_amd.synthetic import BGZF_EOF, bgzf_compress
+
+    d = case_se_regular.dict.to_device(0)
+    raw = gzip.open(FASTQ, "rb").read()
+    want = _as_dict(d.streaming_query_from_file(FASTQ))
+    one = tmp_path / "one.fastq.gz"
+    one.write_bytes(bgzf_compress(raw) + BGZF_EOF)
+    assert _as_dict(d.streaming_query_from_file(str(one))) == want
+    many = tmp_path / "many.fastq.gz"
+    many.write_bytes(bgzf_compress(raw * 40, 1) + BGZF_EOF)  # 100 MB of FASTQ: several groups of members
+    got = _as_dict(d.streaming_query_from_file(str(many)))
+    assert got == {f: 40 * v for f, v in want.items()}
+    bad = bytearray(many.read_bytes())
+    bad[len(bad) // 3] ^= 0x10
+    broken = tmp_path / "broken.fastq.gz"
+    broken.write_bytes(bytes(bad))
+    with pytest.raises(sshash_amd.SSHashError):
+        d.streaming_query_from_file(str(broken))
+
+
 # ---- per-k-mer results: streaming_query::lookup for every k-mer (include/streaming_query.hpp:56-109) ----------------
 
 FIELDS = ("kmer_id", "kmer_id_in_string", "string_id", "string_begin", "string_end", "kmer_orientation")  # what
