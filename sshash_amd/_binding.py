@@ -16,7 +16,8 @@ _LIB_NAME = "libsshash_amd.so"
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, _LIB_NAME)
+    # SSHASH_AMD_LIBRARY: another build of the same HIP library (tools/debug builds variants of it side by side)
+    return os.environ.get("SSHASH_AMD_LIBRARY") or os.path.join(_HERE, _LIB_NAME)
 
 
 class SSHashError(RuntimeError):

@@ -540,7 +540,13 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
             asm volatile("" : : "v"(lo), "v"(hi), "v"(sid));
 #endif
         }
+#if defined(SSHASH_DEBUG_MEMBER_SKIP_DEFER)   // (tools/debug: no placeholder for the lanes the deferred pass rewrites)
+        if (r.outcome != FAST_DEFER) __builtin_nontemporal_store(uint8_t(r.outcome == FAST_HIT ? 1 : 0), member + i);
+#elif defined(SSHASH_DEBUG_MEMBER_CODES_FIRST)  // (tools/debug: what the first pass thought)
+        __builtin_nontemporal_store(uint8_t(r.outcome == FAST_HIT ? 1 : (r.outcome == FAST_DEFER ? 0x80 : 0)), member + i);
+#else
         __builtin_nontemporal_store(uint8_t(r.outcome == FAST_HIT ? 1 : 0), member + i);
+#endif
     } else {
         hit_t h;
         h.kmer_offset = r.kmer_offset;
@@ -746,7 +752,11 @@ deferred_lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew
         }
         const hit_t h = lookup_one<W, CANON, true>(d, skew, x, check_rc);
         if constexpr (MODE == int(out_mode::member)) {
+#ifdef SSHASH_DEBUG_MEMBER_CODES_DEFERRED  // (tools/debug: tell the deferred pass's answers from the first pass's)
+            member[i] = h.found ? 0x41 : 0x40;
+#else
             member[i] = h.found ? 1 : 0;
+#endif
         } else {
             store_result<MODE == int(out_mode::full)>(d, out, i, h);
         }

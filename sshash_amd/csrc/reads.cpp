@@ -47,7 +47,8 @@ struct bgzf_source {
     static constexpr size_t GROUP_PACKED = size_t(8) << 20;  // compressed bytes per group (a few hundred members)
 
     static bool is_bgzf_header(unsigned char const* h) {
-        return h[0] == 31 && h[1] == 139 && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+        /* FLG = FEXTRA alone, XLEN = 6: what bgzip writes (a name or comment field would move the deflate data; not BGZF as specified) */
+        return h[0] == 31 && h[1] == 139 && h[2] == 8 && h[3] == 4 && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
     }
     /* does the file start with a BGZF member? */
     static bool probe(std::string const& filename) {
@@ -97,10 +98,15 @@ struct bgzf_source {
             if (fread(g->packed.data() + at + 18, 1, size - 18, f) != size - 18) throw error(error_kind::io, "error while reading the query file: truncated BGZF member");
             unsigned char const* t = g->packed.data() + at + size - 4;
             const size_t isize = size_t(t[0]) | (size_t(t[1]) << 8) | (size_t(t[2]) << 16) | (size_t(t[3]) << 24);
+            /* a BGZF member holds at most 64 KiB of input (SAM specification 4.1); the trailer is untrusted: a larger claim is a
+               corrupt file, not a reason to allocate gigabytes */
+            if (isize > (size_t(1) << 16)) throw error(error_kind::io, "error while reading the query file: corrupt BGZF member");
             members.push_back({at, size, out_total, isize});
             out_total += isize;
         }
-        if (out_total > g->out_capacity) {
+        /* (also when nothing is to be written: a group of empty members only -- the 28-byte end-of-file marker alone in a fresh
+           group -- must hand inflate a valid pointer) */
+        if (!g->out || out_total > g->out_capacity) {
             g->out_capacity = out_total + out_total / 4 + 1;
             g->out.reset(new char[g->out_capacity]);
         }

@@ -193,6 +193,33 @@ def test_query_file_readers_hand_over_bounded_batches(tmp_path):
     broken.write_bytes(bytes(bad))
     got = subprocess.run([exe, str(broken), "0", "31"], capture_output=True, text=True, timeout=300)
     assert got.returncode != 0 and "BGZF" in got.stderr
+    # a group holding empty members only. (a) the end-of-file marker alone in a FRESH group: 129 stored members take
+    # the first group just past its 8 MiB, the marker opens the second; (b) an empty bgzip file: the marker and nothing else;
+    # (c) a trailer that claims more than a BGZF member can hold is a corrupt file, not an allocation of gigabytes
+    import struct
+
+    record = gzip.open(os.path.join(golden, "SRR5833294.10K.fastq.gz"), "rb").read()
+    records = record.split(b"\n")
+    one = b"\n".join(records[:4]) + b"\n"
+    raw = (one * (129 * 65280 // len(one) + 1))[:129 * 65280]
+    raw = raw[:raw.rfind(b"\n@") + 1]  # whole records
+    raw += b"\n" * (129 * 65280 - len(raw))  # (blank lines behind the last record: up to exactly 129 members)
+    stored = bgzf_compress(raw, 0)
+    assert 128 * (len(stored) // 129) < (8 << 20) < len(stored)
+    edge, edge_plain, empty, liar = tmp_path / "edge.fastq.gz", tmp_path / "edge.fastq", tmp_path / "empty.fastq.gz", tmp_path / "liar.fastq.gz"
+    edge.write_bytes(stored + BGZF_EOF)
+    edge_plain.write_bytes(raw)
+    want = subprocess.run([exe, str(edge_plain), "0", "31"], capture_output=True, text=True, timeout=300)
+    got = subprocess.run([exe, str(edge), "0", "31"], capture_output=True, text=True, timeout=300)
+    assert want.returncode == 0 and got.returncode == 0 and got.stdout == want.stdout and want.stdout.startswith("OK "), (got.stdout, got.stderr)
+    empty.write_bytes(BGZF_EOF)
+    got = subprocess.run([exe, str(empty), "0", "31"], capture_output=True, text=True, timeout=60)
+    assert got.returncode == 0 and got.stdout.startswith("OK 0 0 "), (got.stdout, got.stderr)
+    lie = bytearray(bgzf_compress(one * 10, 1))
+    lie[-4:] = struct.pack("<I", 0xF0000000)
+    liar.write_bytes(bytes(lie) + BGZF_EOF)
+    got = subprocess.run([exe, str(liar), "0", "31"], capture_output=True, text=True, timeout=60)
+    assert got.returncode != 0 and "BGZF" in got.stderr, (got.stdout, got.stderr)
     txt = tmp_path / "reads.txt"
     txt.write_text("ACGT\n")
     p = subprocess.run([exe, str(txt), "0", "31"], capture_output=True, text=True, timeout=60)
