@@ -342,6 +342,20 @@ sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char*
             fprintf(stderr, "unsupported query file format\n");
             return;
         }
+        /* an uncompressed FASTQ is read and parsed by all the lanes at once (reads.hpp: fastq_pieces); a file that is not four
+           lines per record comes back here and takes the sequential reader */
+        if (!multiline && fastq_pieces::applicable(filename) && !std::getenv("SSHASH_AMD_SEQUENTIAL_READER")) {
+            streaming_report r;
+            if (d->eng->streaming_query_fastq_pieces(filename, r)) {
+                report->num_kmers = r.num_kmers;
+                report->num_positive_kmers = r.num_positive_kmers;
+                report->num_negative_kmers = r.num_negative_kmers;
+                report->num_invalid_kmers = r.num_invalid_kmers;
+                report->num_searches = r.num_searches;
+                report->num_extensions = r.num_extensions;
+                return;
+            }
+        }
         /* The file goes through in batches of ~256 MiB of bases (a FASTQ of hundreds of gigabytes must not be
            materialised): a reader thread decompresses batch i+1 while the devices work on batch i. */
         uint64_t batch_bases = uint64_t(256) << 20;

@@ -100,6 +100,11 @@ public:
     /* Batched streaming query over `n_reads` reads stored back to back in `bases`
        (read r = bases[read_offsets[r] .. read_offsets[r+1])). Host buffers. */
     streaming_report streaming_query_host(char const* bases, uint64_t const* read_offsets, uint64_t n_reads) const;
+    /* An uncompressed FASTQ file, read and parsed by the lanes themselves (reads.hpp: fastq_pieces): every lane takes pieces of
+       the file from a shared counter, parses a piece straight into its pinned block, uploads it and runs the streaming
+       kernels -- no single reader thread, no intermediate batch. Returns false when the file turned out not to be four lines
+       per record (or holds reads longer than a piece): the caller then takes the sequential reader, `total` is untouched. */
+    bool streaming_query_fastq_pieces(std::string const& filename, streaming_report& total) const;
     /* Device buffers, asynchronous; `d_report` receives 6 u64 counters (accumulated). */
     void streaming_query_device(int device, char const* d_bases, uint64_t const* d_read_offsets, uint64_t n_reads,
                                 uint64_t total_bases, uint64_t* d_report, void* stream) const;

@@ -3,6 +3,10 @@
 
 #include "errors.hpp"
 
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -62,7 +66,7 @@ struct bgzf_source {
     explicit bgzf_source(std::string const& filename) {
         f = fopen(filename.c_str(), "rb");
         if (!f) throw error(error_kind::io, "error in opening the file '" + filename + "'");
-        threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        threads = std::max(1u, std::min(16u, usable_cpus()));
         if (char const* e = std::getenv("SSHASH_AMD_READER_THREADS")) threads = unsigned(std::max(1l, std::min(64l, std::atol(e))));
         ahead = std::async(std::launch::async, [this] { return decode_group(nullptr); });
     }
@@ -299,6 +303,128 @@ bool read_stream::next(read_batch& out, uint64_t max_bases) {
         }
     }
     return out.num_reads() != 0 || !r.done;
+}
+
+unsigned usable_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::max(1, CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        unsigned long long period = 0;
+        if (fscanf(f, "%31s %llu", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const unsigned long long q = strtoull(quota, nullptr, 10);
+            n = unsigned(std::max<unsigned long long>(1, std::min<unsigned long long>(n, q / period)));
+        }
+        fclose(f);
+    }
+    return n;
+}
+
+/* ---- plain FASTQ in pieces (reads.hpp) ------------------------------------------------------------------------ */
+
+bool fastq_pieces::applicable(std::string const& filename) {
+    if (!(ends_with(filename, ".fq") || ends_with(filename, ".fastq"))) return false;
+    FILE* f = fopen(filename.c_str(), "rb");
+    if (!f) return false;
+    unsigned char h[2] = {0, 0};
+    const size_t got = fread(h, 1, 2, f);
+    fclose(f);
+    return !(got == 2 && h[0] == 31 && h[1] == 139);
+}
+
+fastq_pieces::fastq_pieces(std::string const& filename, uint64_t piece_bytes) : piece_(std::max<uint64_t>(piece_bytes, 4096)) {
+    fd_ = ::open(filename.c_str(), O_RDONLY);
+    if (fd_ < 0) throw error(error_kind::io, "error in opening the file '" + filename + "'");
+    struct stat st;
+    if (fstat(fd_, &st) != 0) {
+        ::close(fd_);
+        throw error(error_kind::io, "error in opening the file '" + filename + "'");
+    }
+    size_ = uint64_t(st.st_size);
+    pieces_ = (size_ + piece_ - 1) / piece_;
+}
+
+fastq_pieces::~fastq_pieces() {
+    if (fd_ >= 0) ::close(fd_);
+}
+
+fastq_pieces::parsed fastq_pieces::parse(uint64_t i, uint32_t k, char* bases, uint64_t bases_capacity, uint64_t* offsets,
+                                         uint64_t offsets_capacity, std::vector<char>& raw) const {
+    const uint64_t cut = i * piece_, next_cut = std::min(size_, cut + piece_);
+    parsed out;
+    offsets[0] = 0;
+    for (uint64_t slack = slack_;; slack *= 4) {
+        if (slack > slack_ && next_cut - cut + slack > bases_capacity) {  // a record longer than the output: not for this reader
+            out.overflow = true;
+            return out;
+        }
+        /* file bytes [from, to): from one byte before the cut (does the cut start a line?) to the next cut plus slack */
+        const uint64_t from = cut ? cut - 1 : 0, to = std::min(size_, next_cut + slack);
+        raw.resize(size_t(to - from));
+        for (uint64_t done = 0; done < to - from;) {
+            const ssize_t got = ::pread(fd_, raw.data() + done, size_t(to - from - done), off_t(from + done));
+            if (got < 0) throw error(error_kind::io, "error while reading the query file");
+            if (got == 0) throw error(error_kind::io, "error while reading the query file: it shrank while being read");
+            done += uint64_t(got);
+        }
+        char const* const B = raw.data();
+        const uint64_t n = to - from;
+        const bool whole = to == size_;  // the rest of the file is in hand: a line without '\n' is the last line, not a lack of slack
+        bool starved = false;
+        /* index of the '\n' ending the line that starts at p; n when the file ends first (or the buffer: then `starved`) */
+        auto line_end = [&](uint64_t p) -> uint64_t {
+            void const* nl = p < n ? memchr(B + p, '\n', size_t(n - p)) : nullptr;
+            if (nl) return uint64_t(static_cast<char const*>(nl) - B);
+            if (!whole) starved = true;
+            return n;
+        };
+        /* does a record start at line start p? '@', and the line after next begins with '+' */
+        auto record_starts = [&](uint64_t p) -> bool {
+            if (B[p] != '@') return false;
+            const uint64_t l1 = line_end(p) + 1;
+            const uint64_t l2 = l1 < n ? line_end(l1) + 1 : n;
+            return l2 < n && B[l2] == '+';
+        };
+        /* synchronise: the first record start at or behind the cut (size_: none) */
+        uint64_t p = cut ? std::min(n, line_end(0) + 1) : 0;  // B[0] is the byte before the cut: its line ends, the next begins
+        if (cut)
+            while (p < n && !starved && !record_starts(p)) p = std::min(n, line_end(p) + 1);
+        if (starved) continue;
+        out.first_record = from + p;
+        /* four lines per record from there: header, bases, '+', qualities, nothing validated (src/query.cpp:78-108) */
+        uint64_t reads = 0, nb = 0;
+        while (p < n && from + p < next_cut) {
+            const uint64_t b0 = line_end(p) + 1;   // behind the header
+            if (starved) break;
+            if (b0 >= n) {                         // a header and nothing behind it: the sequential reader ends here as well
+                p = n;
+                break;
+            }
+            const uint64_t e1 = line_end(b0);      // the bases: [b0, e1)
+            if (starved) break;
+            const uint64_t len = e1 - b0;
+            if (len >= k) {
+                if (nb + len > bases_capacity || reads + 1 >= offsets_capacity) {
+                    out.overflow = true;
+                    return out;
+                }
+                memcpy(bases + nb, B + b0, size_t(len));
+                nb += len;
+                offsets[++reads] = nb;
+            }
+            uint64_t q = std::min(n, e1 + 1);
+            for (int skipped = 0; skipped < 2 && q < n && !starved; ++skipped) q = std::min(n, line_end(q) + 1);  // '+', qualities
+            if (starved) break;
+            p = q;
+        }
+        if (starved) continue;
+        out.next_record = from + p;
+        out.num_reads = reads;
+        out.num_bases = nb;
+        return out;
+    }
 }
 
 bool load_reads(std::string const& filename, bool multiline, uint32_t k, read_batch& out) {

@@ -17,6 +17,7 @@
 //     either way, so the counters are unchanged; queries the table defers take the path above.
 // Output: the six counters of streaming_query_report (include/util.hpp:21-36).
 #include <hip/hip_runtime.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <atomic>
@@ -26,6 +27,7 @@
 #include <thread>
 
 #include "engine.hpp"
+#include "reads.hpp"
 #include "replica.hpp"
 
 namespace sshash_amd {
@@ -731,6 +733,123 @@ streaming_report engine::streaming_query_host(char const* bases, uint64_t const*
         total.num_extensions += p.num_extensions;
     }
     return total;
+}
+
+/* The file query of an uncompressed FASTQ (engine.hpp). One reader thread feeding batches through streaming_query_host splits
+   9 GB/s of file and the devices wait for it nine tenths of the time; here parsing is the lanes' own
+   work: lane = host thread + stream + pinned block + device block, as many lanes as usable CPUs, dealt round-robin to the
+   resident replicas. */
+bool engine::streaming_query_fastq_pieces(std::string const& filename, streaming_report& total) const {
+    const std::vector<int> devs = devices();
+    if (devs.empty()) throw error(error_kind::no_device, "dictionary is not resident on any device (call sshash_to_device first)");
+    const uint64_t G = devs.size();
+    uint64_t want_lanes = std::max<uint64_t>(G, std::min<uint64_t>(32, usable_cpus()));
+    if (char const* e = std::getenv("SSHASH_AMD_READER_THREADS")) want_lanes = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+    /* pieces of 32 MiB of file; a smaller file is cut finer, so that every lane still gets several (4 MiB at least) */
+    uint64_t piece_bytes = uint64_t(32) << 20;
+    {
+        struct stat st;
+        if (stat(filename.c_str(), &st) == 0)
+            piece_bytes = std::min<uint64_t>(piece_bytes, std::max<uint64_t>(uint64_t(4) << 20, uint64_t(st.st_size) / (want_lanes * 8)));
+    }
+    if (char const* e = std::getenv("SSHASH_AMD_FASTQ_PIECE_BYTES")) piece_bytes = std::max<uint64_t>(4096, std::strtoull(e, nullptr, 10));  // tests
+    const fastq_pieces file(filename, piece_bytes);
+    const uint64_t num_pieces = file.num_pieces();
+    if (num_pieces == 0) return true;  // an empty file: an empty report
+    const uint32_t k = m_idx->k;
+    const uint64_t off_capacity = file.offsets_capacity(k), bases_capacity = file.bases_capacity();
+    const uint64_t bases_at = (off_capacity * sizeof(uint64_t) + 255) & ~uint64_t(255);
+    const uint64_t report_at = (bases_at + bases_capacity + 255) & ~uint64_t(255);
+    const uint64_t lane_bytes = report_at + 6 * sizeof(uint64_t);
+    const uint64_t num_lanes = std::min(num_pieces, want_lanes);
+
+    std::atomic<uint64_t> next{0};
+    std::atomic<bool> give_up{false};
+    std::vector<fastq_pieces::parsed> seen(num_pieces);
+    std::vector<std::exception_ptr> errors(num_lanes);
+    std::vector<streaming_report> partial(num_lanes);
+
+    auto run_lane = [&](uint64_t li) {
+        try {
+            const int device = devs[li % G];
+            device_replica const* rep = replica(device);
+            HIP_CHECK(hipSetDevice(device));
+            host_lane* lane = rep->acquire_lane(lane_bytes);
+            struct give_back {
+                device_replica const* rep;
+                host_lane* lane;
+                ~give_back() { rep->release_lane(lane); }
+            } guard{rep, lane};
+            hipStream_t s = lane->stream;
+            char* hp = static_cast<char*>(lane->pinned);
+            char* dp = static_cast<char*>(lane->device);
+            uint64_t* d_report = reinterpret_cast<uint64_t*>(dp + report_at);
+            HIP_CHECK(hipMemsetAsync(d_report, 0, 6 * sizeof(uint64_t), s));
+            std::vector<char> raw;
+            for (;;) {
+                const uint64_t piece = next.fetch_add(1);
+                if (piece >= num_pieces || give_up) break;
+                uint64_t* offsets = reinterpret_cast<uint64_t*>(hp);
+                const fastq_pieces::parsed got = file.parse(piece, k, hp + bases_at, bases_capacity, offsets, off_capacity, raw);
+                seen[piece] = got;
+                if (got.overflow) {
+                    give_up = true;
+                    break;
+                }
+                if (got.num_reads == 0) continue;
+                HIP_CHECK(hipMemcpyAsync(dp, hp, (got.num_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipMemcpyAsync(dp + bases_at, hp + bases_at, got.num_bases, hipMemcpyHostToDevice, s));
+                bool long_read = false;  // (as streaming_query_host: a read of megabases must not sit on one lane of a wave)
+                for (uint64_t i = 0; i < got.num_reads && !long_read; ++i) long_read = offsets[i + 1] - offsets[i] > LONG_READ_BASES;
+                if (long_read) streaming_lookup_device(device, dp + bases_at, reinterpret_cast<uint64_t const*>(dp), got.num_reads, got.num_bases, result_view{}, d_report, s);
+                else streaming_query_device(device, dp + bases_at, reinterpret_cast<uint64_t const*>(dp), got.num_reads, got.num_bases, d_report, s);
+                HIP_CHECK(hipStreamSynchronize(s));  // the pinned block is parsed into again
+            }
+            uint64_t h[6];
+            HIP_CHECK(hipMemcpyAsync(h, d_report, sizeof(h), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            partial[li].num_kmers = h[0];
+            partial[li].num_positive_kmers = h[1];
+            partial[li].num_negative_kmers = h[2];
+            partial[li].num_invalid_kmers = h[3];
+            partial[li].num_searches = h[4];
+            partial[li].num_extensions = h[5];
+        } catch (...) {
+            errors[li] = std::current_exception();
+            give_up = true;
+        }
+    };
+
+    int prev = 0;
+    HIP_CHECK(hipGetDevice(&prev));
+    if (num_lanes == 1) {
+        run_lane(0);
+    } else {
+        std::vector<std::thread> workers;
+        for (uint64_t li = 0; li < num_lanes; ++li) workers.emplace_back(run_lane, li);
+        for (auto& w : workers) w.join();
+    }
+    (void)hipSetDevice(prev);
+    for (auto const& e : errors)
+        if (e) std::rethrow_exception(e);
+    if (give_up) return false;
+    /* every piece began where its predecessor stopped, the first at 0, the last stopped at the end of the file: the pieces
+       together are the sequential reader's records (reads.hpp) */
+    uint64_t expect = 0;
+    for (uint64_t i = 0; i < num_pieces; ++i) {
+        if (seen[i].first_record != expect) return false;
+        expect = seen[i].next_record;
+    }
+    if (expect != file.file_bytes()) return false;
+    for (auto const& p : partial) {
+        total.num_kmers += p.num_kmers;
+        total.num_positive_kmers += p.num_positive_kmers;
+        total.num_negative_kmers += p.num_negative_kmers;
+        total.num_invalid_kmers += p.num_invalid_kmers;
+        total.num_searches += p.num_searches;
+        total.num_extensions += p.num_extensions;
+    }
+    return true;
 }
 
 }  // namespace sshash_amd

@@ -138,6 +138,43 @@ def test_query_file_goes_through_in_batches(case_se_regular, case_skew_regular, 
         d.streaming_query_from_file(str(tmp_path / "missing.fq"))
 
 
+def test_plain_fastq_is_read_in_pieces_by_all_lanes(case_se_regular, tmp_path, monkeypatch):
+    """An uncompressed FASTQ is cut at fixed byte positions and parsed by the lanes themselves (csrc/reads.cpp: fastq_pieces,
+    streaming_query_fastq_pieces): the report is the sequential reader's whatever the piece size and the number of lanes -- also
+    with quality lines that begin with '@', CR LF line ends and a last record cut short --, and a file that is not four lines
+    per record falls back to the sequential reader instead of giving another answer."""
+    d = case_se_regular.dict.to_device(0)
+    raw = gzip.open(FASTQ, "rb").read()
+    want = _as_dict(d.streaming_query_from_file(FASTQ))  # (gzip: the sequential reader)
+    lines = raw.split(b"\n")
+    assert lines[-1] == b"" and (len(lines) - 1) % 4 == 0
+    records = [lines[i:i + 4] for i in range(0, len(lines) - 1, 4)]
+    at_quals = b"".join(b"\n".join([h, b, p, b"@" + q[1:]]) + b"\n" for h, b, p, q in records)
+    crlf = b"".join(b"\r\n".join([h, b, p, q]) + b"\r\n" for h, b, p, q in records[:2000])
+    cut_short = raw[:raw.rfind(b"\n+")]  # the last record: header and bases, no newline behind them
+    five_lines = b"".join(b"\n".join([h, b[:40], b[40:], p, q]) + b"\n" for h, b, p, q in records[:3000])
+    files = {"plain": raw * 6, "at_quals": at_quals, "crlf": crlf, "cut_short": cut_short, "five_lines": five_lines}
+    for name, blob in files.items():
+        path = tmp_path / f"{name}.fastq"
+        path.write_bytes(blob)
+        monkeypatch.setenv("SSHASH_AMD_SEQUENTIAL_READER", "1")
+        sequential = _as_dict(d.streaming_query_from_file(str(path)))
+        monkeypatch.delenv("SSHASH_AMD_SEQUENTIAL_READER")
+        if name == "plain":
+            assert sequential == {f: 6 * v for f, v in want.items()}
+        if name in ("at_quals", "cut_short"):
+            assert sequential == want
+        for piece, lanes in ((None, None), ("4096", "3"), ("100003", "1"), ("1000000", "16")):
+            for var, value in (("SSHASH_AMD_FASTQ_PIECE_BYTES", piece), ("SSHASH_AMD_READER_THREADS", lanes)):
+                if value is None:
+                    monkeypatch.delenv(var, raising=False)
+                else:
+                    monkeypatch.setenv(var, value)
+            assert _as_dict(d.streaming_query_from_file(str(path))) == sequential, (name, piece, lanes)
+        monkeypatch.delenv("SSHASH_AMD_FASTQ_PIECE_BYTES", raising=False)
+        monkeypatch.delenv("SSHASH_AMD_READER_THREADS", raising=False)
+
+
 def test_query_file_in_bgzf_members(case_se_regular, tmp_path):
     """A BGZF file (bgzip: gzip members with their size in the header, inflated on several threads by csrc/reads.cpp) gives the
     report of the plain gzip file it was made from -- also when the file spans several groups of members and batches --; a
