@@ -10,7 +10,11 @@ replicated in every GPU's HBM, and one batch of 10^9 random queries -- 50 % posi
 reverse-complemented), 50 % uniform random (tools/perf.hpp:38-74), seeded, drawn on the device -- sharded over
 the ranks ("scaling": "strong"). `--workload c2` selects configs[1] (S. enterica pangenome scale, 10^8 queries).
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2] [--bases B --queries Q] [--canonical]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2|c4] [--bases B --queries Q] [--canonical]
+    python bench.py --workload c4 --streaming [--gpus N --reads R]      the streaming query of configs[3], read-sharded
+
+The default run (C3, one GPU) appends `other_workloads`: the C2 line, the C4 (k = 63) line and the C4 streaming line, each a
+child run of this script with its own oracle check, roofline and cpu_baseline.
 
 `--gpus N` with N > 1 starts the N ranks itself (python -m torch.distributed.run, rendezvous on 127.0.0.1);
 launched under torch.distributed.run it uses the ranks it is given. One process per GPU; no collective on the
@@ -258,20 +262,166 @@ def measure_streaming_from_file(d, index_path, reads_tensor, directory, tag, ora
 
 
 def traffic_record(d, n_local: int, args):
-    """HBM bytes per step from the PMC passes of THIS workload (profiles/traffic.json, written by
-    tools/jobs/*traffic*.sh from rocprofv3 --pmc runs of this very command); None when the tracked record is of
-    another workload. The provenance (file, commit, counters) is printed with the number."""
+    """HBM bytes per step from the PMC passes of THIS workload (profiles/traffic.json: one record per workload name, written by
+    tools/make_traffic_json.py from rocprofv3 --pmc runs of this very command); None when no record fits this run's shape. The
+    provenance (file, commit, counters) is printed with the number."""
     prof = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        rec = json.load(open(prof))
+        recs = json.load(open(prof))
     except Exception:
+        return None, None
+    rec = recs.get(args.workload) if "queries" not in recs else (recs if args.workload == "c3" else None)  # (round-3 file: one record, C3's)
+    if not rec:
         return None, None
     same = (rec.get("queries") == n_local and rec.get("bases") == args.bases and rec.get("canonical") == args.canonical
             and rec.get("k", 31) == args.k)
     if not same:
         return None, None
-    return rec.get("hbm_bytes_per_launch"), {"file": "profiles/traffic.json", "commit": rec.get("commit"),
-                                            "counters": rec.get("counters"), "note": rec.get("note")}
+    return rec.get("hbm_bytes_per_launch"), {"file": "profiles/traffic.json", "workload": args.workload, "commit": rec.get("commit"),
+                                            "counters": rec.get("counters"), "note": rec.get("note"), "source": rec.get("source")}
+
+
+def run_other_workload(args, extra):
+    """`python bench.py --workload ...` as a child process (its own index, replica and batch; this process has released its GPU
+    memory): the child's JSON line, or the reason there is none."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cache-dir", args.cache_dir,
+           "--seed", str(args.seed), "--no-extra-mixes", "--no-other-paths", "--no-file-query", "--no-other-workloads"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr[-1500:]}
+    line = json.loads(lines[-1])
+    line["wall_s_of_the_child"] = round(time.time() - t0, 1)
+    return line
+
+
+def streaming_mode(args, d, index_path, rank, world, local_rank, dev, use_dist, dist, coll_dev, barrier, stats):
+    """`--streaming`: BASELINE.json configs[3] -- streaming_query over synthetic reads, read-sharded: ONE set of --reads reads of
+    --read-len bases (half -- `--positive` -- spell consecutive k-mers of the dictionary, with 1 % substitutions; the rest random;
+    'N' at 1e-3), rank r draws and keeps its share on its device; a step is one sshash_streaming_query_device call over the share
+    (the reference's state machine per read, include/streaming_query.hpp:56-197; six counters out). No collective on the data path:
+    the counters are summed with one all_reduce after the timed region. Returns the JSON line (rank 0) or None."""
+    import torch
+
+    from sshash_amd.synthetic import make_reads_device
+
+    lo, hi = split_batch(args.reads, world, rank)
+    n = hi - lo
+    L, k = args.read_len, d.k()
+    t0 = time.time()
+    reads = make_reads_device(d, local_rank, n, L, positive_fraction=args.positive, seed=args.seed + 7919 * rank)
+    offsets = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    report = torch.zeros(6, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f"{n} reads of {L} bases drawn on the device in {time.time() - t0:.1f}s")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        report.zero_()
+        d.streaming_query_device(local_rank, reads.data_ptr(), offsets.data_ptr(), n, report.data_ptr(), stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t_begin = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record(stream)
+        step()
+        stops[i].record(stream)
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t_begin
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_begin
+    kernel_ms = [starts[i].elapsed_time(stops[i]) for i in range(args.steps)]
+    avg_kernel_ms = float(np.mean(kernel_ms))
+    counters = report.clone()
+    per_rank = [{"rank": 0, "reads": n, "ms_per_step": round(own_elapsed / args.steps * 1e3, 3), "kernel_ms_per_step": round(avg_kernel_ms, 3),
+                 "report": [int(v) for v in counters.cpu().tolist()]}]
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        mine = torch.tensor([float(n), own_elapsed / args.steps * 1e3, avg_kernel_ms] + [float(v) for v in counters.cpu().tolist()], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r, "reads": int(v[0].item()), "ms_per_step": round(float(v[1].item()), 3), "kernel_ms_per_step": round(float(v[2].item()), 3),
+                     "report": [int(x.item()) for x in v[3:]]} for r, v in enumerate(every)]
+        total = counters.to(coll_dev)
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)  # the one reduction of the read-sharded query: six counters
+        counters = total
+    if rank != 0:
+        return None
+    names = ("num_kmers", "num_positive_kmers", "num_negative_kmers", "num_invalid_kmers", "num_searches", "num_extensions")
+    rep = dict(zip(names, (int(v) for v in counters.cpu().tolist())))
+    # the reference's own consistency rules (src/query.cpp:44-45, include/streaming_query.hpp:113) and the known k-mer count
+    assert rep["num_kmers"] == args.reads * (L - k + 1), rep
+    assert rep["num_kmers"] == rep["num_positive_kmers"] + rep["num_negative_kmers"] + rep["num_invalid_kmers"], rep
+    assert rep["num_positive_kmers"] == rep["num_searches"] + rep["num_extensions"], rep
+    assert sum(r["report"][0] for r in per_rank) == rep["num_kmers"]
+    # parity: the first reads of rank 0's share through the CPU oracle's restated state machine (oracle = checker only)
+    from oracle import oracle as O
+
+    ora = O.OracleIndex(index_path)
+    m = min(n, args.stream_oracle_reads)
+    sample = [bytes(r) for r in reads[:m].cpu().numpy()]
+    t0 = time.perf_counter()
+    want = ora.streaming_query(sample)
+    t_oracle = time.perf_counter() - t0
+    part = torch.zeros(6, dtype=torch.int64, device=dev)
+    d.streaming_query_device(local_rank, reads.data_ptr(), offsets.data_ptr(), m, part.data_ptr(), stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    got = dict(zip(names, (int(v) for v in part.cpu().tolist())))
+    if got != {f: int(v) for f, v in want.items()}:
+        raise SystemExit(f"PARITY FAILURE: streaming counters of the first {m} reads: GPU {got} vs oracle {want}")
+    # algorithmic bytes (SURVEY 8(d) rule, extended to the streaming query): every base is read once (1 B); a k-mer that does not
+    # extend the previous one costs the reference a full lookup (seed(): searches + negatives, at the bytes per lookup the
+    # instrumented oracle counts on this dictionary's 50/50 mix); an extension reads the next k-mer of the string (8 W B)
+    W = d.words_per_kmer()
+    from sshash_amd.synthetic import draw_queries_device
+
+    mix = draw_queries_device(d, local_rank, 100_000, 0.5, seed=args.seed + 3).cpu().numpy().view(np.uint64)
+    bytes_per_lookup = ora.count_bytes(mix) / 100_000
+    lookups = rep["num_searches"] + rep["num_negative_kmers"]
+    algorithmic = args.reads * L + lookups * bytes_per_lookup + rep["num_extensions"] * 8 * W
+    n_local_kmers = per_rank[0]["report"][0]
+    achieved = algorithmic * (n_local_kmers / rep["num_kmers"]) / (avg_kernel_ms * 1e-3) / 1e9
+    total_kmers = rep["num_kmers"] * args.steps
+    return {
+        "metric": "streaming_query k-mers/sec (synthetic reads resident in HBM, six counters; BASELINE.json configs[3])",
+        "value": round(total_kmers / elapsed, 1), "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"{WORKLOADS[args.workload][3]}, k={k} m={d.m()} {'canonical' if d.canonical() else 'regular'}, {d.num_kmers()} k-mers; "
+                               f"streaming_query over ONE set of {args.reads} reads x {L} bases ({args.positive:.0%} spell k-mers of the dictionary with 1 % "
+                               f"substitutions, the rest random; N at 1e-3), read-sharded over {world} GPU(s), index replicated",
+                   "reads": args.reads, "read_length": L, "reads_per_gpu": n, "k": k, "m": d.m(), "canonical": d.canonical(), "num_kmers": d.num_kmers(),
+                   "device_index_bytes": d.device_bytes(local_rank), "report": rep,
+                   "positive_fraction_of_kmers": round(rep["num_positive_kmers"] / rep["num_kmers"], 4),
+                   "extensions_per_search": round(rep["num_extensions"] / max(1, rep["num_searches"]), 2),
+                   "counters_equal_oracle_on_reads": m, "device_stats": stats},
+        "per_rank": per_rank,
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": None, "kernel": "streaming_kernel<W=%d> (one read per lane; avg_kernel_ms = HIP-event time around one step, on the launch stream)" % W,
+                     "avg_kernel_ms": round(avg_kernel_ms, 3), "kernel_ms_steps": [round(float(t), 3) for t in kernel_ms],
+                     "algorithmic_bytes_per_kmer": round(algorithmic / rep["num_kmers"], 3),
+                     "algorithmic_bytes_rule": "1 B per base + (searches + negatives) x the oracle-counted bytes of a lookup (%.1f B: the reference's seed() is a "
+                                               "full lookup) + extensions x 8 W B (the string's next k-mer)" % bytes_per_lookup,
+                     "bound_note": "a lane walks its read's dependent chain (extend or seed): latency of the chain per lane, not bytes, bounds this kernel "
+                                   "(DESIGN.md section 6)"},
+        "cpu_baseline": {"value": round(want["num_kmers"] / t_oracle, 1), "unit": "k-mers/s", "cores": 1, "kind": "port",
+                         "sample": f"the first {m} reads of the same set through the oracle's streaming state machine on one thread (the reference's query "
+                                   f"tool is single-threaded): {t_oracle / max(1, want['num_kmers']) * 1e9:.1f} ns per k-mer",
+                         "published_reference_ns_per_kmer": "89.5 (k=31) / 190.6 (k=63): human, high-hit, gzipped FASTQ, one 5.4 GHz core; "
+                                                            "benchmarks/results-21-01-26/k{31,63}/regular-streaming-queries-high-hit.json:3"},
+    }
 
 
 def main():
@@ -302,6 +452,14 @@ def main():
                     help="NOT the headline mode: partition the dictionary over the GPUs instead of replicating it (BASELINE.json "
                          "configs[4]) -- 'table': the super-k-mer table by key, 'minimizer': the minimizer-side structures -- and "
                          "route every query to its owner with an all-to-all over RCCL (sshash_sharded_lookup_device)")
+    ap.add_argument("--streaming", action="store_true",
+                    help="measure the streaming query (BASELINE.json configs[3]) instead of the point lookup: --reads reads of --read-len bases, read-sharded")
+    ap.add_argument("--reads", type=int, default=100_000_000, help="--streaming: reads in the set, ALL GPUs together")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--stream-oracle-reads", type=int, default=50_000, help="--streaming: reads checked against (and timed on) the CPU oracle")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default run (C3, one GPU): do not append the C2 and C4 lines (`other_workloads`: child runs of this script)")
+    ap.add_argument("--other-streaming-reads", type=int, default=20_000_000, help="reads of the C4 streaming line inside `other_workloads`")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
     bases, recipe, queries, what = WORKLOADS[args.workload]
@@ -392,6 +550,14 @@ def main():
     stats = d.device_stats(local_rank)
     if rank == 0:
         log(f"replica in HBM: {d.device_bytes(local_rank) / 1e6:.0f} MB (upload {time.time() - t0:.1f}s); {stats}")
+
+    if args.streaming:
+        result = streaming_mode(args, d, index_path, rank, world, local_rank, dev, use_dist, dist, coll_dev, barrier, stats)
+        barrier()
+        if use_dist:
+            dist.destroy_process_group()
+        emit(json_fd, rank, result)
+        return
 
     # this rank's share of the batch
     lo, hi = split_batch(args.queries, world, rank)
@@ -551,6 +717,24 @@ def main():
             table_histogram["super_kmers_under_heavy_keys_fraction"] = round(heavy / max(1, table_histogram["super_kmers"]), 5)
             table_histogram["kmers_under_heavy_keys"] = stats["sk_heavy_kmers"]
             table_histogram["kmers_under_heavy_keys_fraction"] = round(stats["sk_heavy_kmers"] / d.num_kmers(), 5)
+        other_workloads = None
+        # test scaffolding (tests/test_gpu_bench_harness.py): "bases,queries,reads" shrinks the children and lets a reduced parent have them
+        reduced = os.environ.get("SSHASH_BENCH_TEST_OTHER_WORKLOADS")
+        if world == 1 and sharded is None and args.workload == "c3" and not args.no_other_workloads and (args.bases == WORKLOADS["c3"][0] or reduced):
+            # BASELINE.json's other single-GPU configurations, each a run of this script of its own (index, replica, batch, oracle check,
+            # roofline, cpu_baseline): C2 (configs[1]) and C4 (configs[3]: the k = 63 dictionary -- point lookups and its streaming query)
+            del dq, out
+            d.close()
+            torch.cuda.empty_cache()
+            other_workloads = {}
+            for name, extra in (("c2", ["--workload", "c2"]), ("c4", ["--workload", "c4"]),
+                                ("c4_streaming", ["--workload", "c4", "--streaming", "--reads", str(args.other_streaming_reads)])):
+                if reduced:
+                    b_, q_, r_ = reduced.split(",")
+                    extra = extra + ["--bases", b_, "--cpu-sample", "100000"] + (["--reads", r_, "--stream-oracle-reads", "5000"] if "--streaming" in extra else ["--queries", q_])
+                log(f"other workload {name} ...")
+                other_workloads[name] = run_other_workload(args, extra)
+                log(f"other workload {name}: {other_workloads[name].get('value')} {other_workloads[name].get('unit')}")
         total = args.queries * args.steps
         result = {
             "metric": "k-mer Lookups/sec (batched random queries, bit-exact ids)",
@@ -582,10 +766,16 @@ def main():
             "other_mixes": extra,
             "other_paths": other_paths,
             "streaming_from_file": from_file,
+            "other_workloads": other_workloads,
         }
     barrier()
     if use_dist:
         dist.destroy_process_group()
+    emit(json_fd, rank, result)
+
+
+def emit(json_fd, rank, result):
+    """stdout back in place; rank 0 prints the ONE JSON line"""
     sys.stdout.flush()
     try:
         import ctypes

@@ -527,19 +527,10 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
     /* every remaining lane stores first (a deferred or resumed lane's value is a placeholder that a later pass
        overwrites), the deferred-queue push comes last */
     if constexpr (MODE == int(out_mode::member)) {
-        {
-            /* The position fields are dead here, and hipcc 7.2 builds a wrong kernel once it may drop them: with the probes
-               finished inside the first pass (sk_finish_in_wave) this instance reported 0.15 % of the indexed k-mers absent,
-               differently from launch to launch, while the id-returning instance of the very same code never did
-               (tools/debug/member_mismatch.py; explicit s_waitcnt at every LDS hand-over changed nothing; round 2 met the same
-               ghost in its is_member instances and blamed the LDS-DMA path it was trying). Keeping the fields alive up to
-               here costs three registers and cures it; the parity tests run every k-mer of every fixture and of both bench
-               stand-ins through this instance. */
-#ifndef SSHASH_DEBUG_NO_KEEPALIVE  // (tools/debug: build the failing variant)
-            uint32_t lo = uint32_t(r.kmer_offset), hi = uint32_t(r.kmer_offset >> 32), sid = r.string_id;
-            asm volatile("" : : "v"(lo), "v"(hi), "v"(sid));
-#endif
-        }
+        /* (This instance allocates exactly 64 VGPRs and hipcc keeps a 64-bit shift's amount in v63, the last of them: on this chip
+           such a shift is wrong in 6-7 % of its executions -- the "0.15 % of the indexed k-mers absent, differently from launch to
+           launch" of rounds 2 and 3, which an asm keep-alive of three dead registers used to hide by moving the allocation to 72.
+           tools/isa_guard.py now pads such kernels when the library is built; DESIGN.md section 6, tools/debug/vgpr64_check.hip.) */
 #if defined(SSHASH_DEBUG_MEMBER_SKIP_DEFER)   // (tools/debug: no placeholder for the lanes the deferred pass rewrites)
         if (r.outcome != FAST_DEFER) __builtin_nontemporal_store(uint8_t(r.outcome == FAST_HIT ? 1 : 0), member + i);
 #elif defined(SSHASH_DEBUG_MEMBER_CODES_FIRST)  // (tools/debug: what the first pass thought)

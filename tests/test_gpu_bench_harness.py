@@ -99,3 +99,53 @@ def test_config_c4_line(tmp_path):
     assert f["counters_equal_oracle_on_sample"] is True and f["kmers"] == 100000 * (150 - 63 + 1)
     assert f["fastq"]["report"] == f["fastq.gz"]["report"] and f["fastq"]["report"]["num_positive_kmers"] > 0
     assert f["published_reference"]["ns_per_kmer"] == 190.6
+
+
+def test_streaming_mode_one_rank_and_two(tmp_path):
+    """`bench.py --workload c4 --streaming [--gpus 2]` (BASELINE.json configs[3]) at reduced size: reads drawn on every rank's device,
+    read-sharded, the six counters summed with one all_reduce; the line carries the contract, per-rank reports and the oracle check."""
+    env = dict(os.environ, SSHASH_BENCH_CACHE=str(tmp_path))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    base = ["--workload", "c4", "--bases", "30000000", "--streaming", "--reads", "400001", "--steps", "2", "--warmup", "1", "--stream-oracle-reads", "5000"]
+    lines = {}
+    for n, extra, env_extra in ((1, [], {}), (2, ["--gpus", "2"], {"SSHASH_BENCH_TEST_ALL_RANKS_ON_DEVICE": "0"})):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + base + extra, env=dict(env, **env_extra), capture_output=True, text=True, timeout=1200)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out = [l for l in p.stdout.splitlines() if l.strip()]
+        assert len(out) == 1
+        lines[n] = r = json.loads(out[0])
+        for key in CONTRACT:
+            assert key in r, key
+        assert r["unit"] == "k-mers/s" and r["n_gpus"] == n and r["scaling"] == "strong" and r["config"]["k"] == 63
+        rep = r["config"]["report"]
+        assert rep["num_kmers"] == 400001 * (150 - 63 + 1) == sum(p_["report"][0] for p_ in r["per_rank"])
+        assert [sum(p_["report"][i] for p_ in r["per_rank"]) for i in range(6)] == list(rep.values())
+        assert sum(p_["reads"] for p_ in r["per_rank"]) == 400001 and len(r["per_rank"]) == n
+        assert r["config"]["counters_equal_oracle_on_reads"] == 5000 and r["cpu_baseline"]["cores"] == 1
+        assert 0.15 < r["config"]["positive_fraction_of_kmers"] < 0.5  # half of the reads spell k-mers of the dictionary, 1 % substitutions
+        assert abs(r["value"] - rep["num_kmers"] / r["ms_per_step"] * 1e3) / r["value"] < 0.02
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".sshash")]) == 1
+
+
+def test_default_run_appends_the_other_baseline_configurations(tmp_path):
+    """The driver's command measures C3 and, behind it, BASELINE.json's other single-GPU configurations as child runs of the same script
+    (`other_workloads`: C2, C4, C4's streaming query), each with its own oracle check, roofline and cpu_baseline -- here at reduced size."""
+    env = dict(os.environ, SSHASH_BENCH_CACHE=str(tmp_path), SSHASH_BENCH_TEST_OTHER_WORKLOADS="24000000,2000000,200000")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = ["--bases", "24000000", "--queries", "2000000", "--steps", "2", "--warmup", "1", "--cpu-sample", "100000", "--no-extra-mixes", "--no-other-paths", "--no-file-query"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=2400)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(out) == 1
+    r = json.loads(out[0])
+    others = r["other_workloads"]
+    assert set(others) == {"c2", "c4", "c4_streaming"}
+    for name, line in others.items():
+        assert "error" not in line, line
+        for key in CONTRACT:
+            assert key in line, (name, key)
+        assert line["value"] > 0 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0 and line["n_gpus"] == 1
+    assert others["c2"]["config"]["k"] == 31 and others["c4"]["config"]["k"] == 63 and others["c4_streaming"]["unit"] == "k-mers/s"
+    assert others["c2"]["config"]["recipe"] == "se_k31" and others["c4"]["config"]["recipe"] == "human_k63"

@@ -1,0 +1,54 @@
+"""GPU: the environment switches that select kernels at run time (engine.hip, sktable.hip), each in a process of its own
+(tests/gpu_switch_worker.py): every k-mer of a C2-like stand-in through the id-returning and the is_member instances, launch after
+launch -- 20 launches where the round-3 hazard lived (probes finished in the wave / in the resume pass) --, ASCII input, the bench's
+mixes against the oracle. (Round 3 ran these settings once, from a job script.)"""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+SETTINGS = [
+    ("default", {}, 20),
+    ("resume_pass", {"SSHASH_AMD_INWAVE": "0"}, 20),
+    ("no_overlap", {"SSHASH_AMD_OVERLAP": "0"}, 3),
+    ("overlap_always", {"SSHASH_AMD_OVERLAP": "1"}, 3),
+    ("overlap_always_resume_pass", {"SSHASH_AMD_OVERLAP": "1", "SSHASH_AMD_INWAVE": "0"}, 3),
+    ("packed_table", {"SSHASH_AMD_SK_SLOTS_PER_KEY": "1.4", "SSHASH_AMD_SK_SLOTS_PER_KMER": "1.3"}, 3),
+    ("small_pieces", {"SSHASH_AMD_PIECE": "1000000"}, 3),
+    ("directory", {"SSHASH_AMD_SKTABLE": "0", "SSHASH_AMD_DIRECTORY": "1"}, 3),
+    ("mphf", {"SSHASH_AMD_SKTABLE": "0", "SSHASH_AMD_DIRECTORY": "0"}, 3),
+]
+WORKLOADS = {"c2_like_regular": ("se_k31", 20_000_000, 31, 21, 0), "c3_like_canonical": ("human_k31", 12_000_000, 31, 21, 1),
+             "c4_like_k63": ("human_k63", 12_000_000, 63, 25, 0)}
+
+
+def run(workload, env, launches):
+    recipe, bases, k, m, canonical = WORKLOADS[workload]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_switch_worker.py"), recipe, str(bases), str(k), str(m), str(canonical), str(launches)],
+                       capture_output=True, text=True, timeout=1500, env=dict(os.environ, **env))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name,env,launches", SETTINGS, ids=[s[0] for s in SETTINGS])
+def test_every_kmer_launch_after_launch(name, env, launches):
+    got = run("c2_like_regular", env, launches)
+    assert got["ok"] and got["launches"] == launches
+    if name in ("directory", "mphf"):
+        assert got["sk_slots"] == 0 and (name == "directory") == bool(got["directory_sectors"])
+    else:
+        assert got["sk_slots"] > 0
+
+
+@pytest.mark.parametrize("workload", ["c3_like_canonical", "c4_like_k63"])
+@pytest.mark.parametrize("name,env", [("default", {}), ("resume_pass", {"SSHASH_AMD_INWAVE": "0"})])
+def test_other_flavours_launch_after_launch(workload, name, env):
+    assert run(workload, env, 20)["ok"]

@@ -120,3 +120,57 @@ def test_strong_scaling_shares_cover_the_batch():
         assert shares[0][0] == 0 and shares[-1][1] == total
         assert all(shares[r][1] == shares[r + 1][0] for r in range(world - 1))
         assert max(hi - lo for lo, hi in shares) - min(hi - lo for lo, hi in shares) <= 1
+
+
+STREAMING_WORKER = textwrap.dedent(
+    """
+    import gzip, os, sys
+    import numpy as np
+    sys.path.insert(0, sys.argv[1])
+    import torch, torch.distributed as dist
+    import bench, sshash_amd
+    from oracle import oracle as O
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo")
+    fasta = os.path.join(sys.argv[1], "tests", "golden", "salmonella_enterica_k31_ust.fa.gz")
+    path = os.path.join(sys.argv[2], "se.sshash")
+    if rank == 0:
+        sshash_amd.Dictionary.build(fasta, k=31, m=13, num_threads=2).save(path)
+    dist.barrier()
+    ora = O.OracleIndex(path)
+    lines = gzip.open(os.path.join(sys.argv[1], "tests", "golden", "SRR5833294.10K.fastq.gz"), "rb").read().split(b"\\n")
+    reads = lines[1::4][:3001]                                  # ONE set of reads ...
+    lo, hi = bench.split_batch(len(reads), world, rank)        # ... read-sharded: contiguous shares, as bench.py --streaming
+    names = ("num_kmers", "num_positive_kmers", "num_negative_kmers", "num_invalid_kmers", "num_searches", "num_extensions")
+    mine = ora.streaming_query(reads[lo:hi])
+    total = torch.tensor([int(mine[f]) for f in names], dtype=torch.int64)
+    dist.all_reduce(total, op=dist.ReduceOp.SUM)               # the one reduction: six counters
+    if rank == 0:
+        whole = ora.streaming_query(reads)
+        assert [int(whole[f]) for f in names] == total.tolist(), (whole, total.tolist())
+        assert int(total[0]) == sum(max(0, len(r) - 30) for r in reads)
+        assert int(total[0]) == int(total[1] + total[2] + total[3]) and int(total[1]) == int(total[4] + total[5])
+        print("OK", total.tolist(), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    """
+)
+
+
+def test_read_sharded_streaming_counters_sum_over_two_ranks(tmp_path):
+    """bench.py --streaming at N > 1 (BASELINE.json configs[3]: reads sharded, index replicated): every rank queries its contiguous share
+    of ONE read set and the six counters are summed with one all_reduce -- with the CPU oracle standing in for the device, the sum over
+    two ranks is the report of the whole set (a read is a unit: the streaming state is reset between reads,
+    include/streaming_query.hpp:48)."""
+    script = tmp_path / "worker.py"
+    script.write_text(STREAMING_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert "OK [" in outs[0]

@@ -40,7 +40,7 @@ struct probe_mode {
     int allocation;
     const char* what;
 };
-constexpr int MODES = 11;
+constexpr int MODES = 19;
 static const probe_mode modes[MODES] = {
     {64, "data v[58:61], 2a in v62, 63-2a in v63 (the kernel's own allocation): v_lshlrev_b64 shifts by v63"},
     {64, "data v[58:61], 2a in v63, 63-2a in v62: v_lshrrev_b64 shifts by v63"},
@@ -53,6 +53,14 @@ static const probe_mode modes[MODES] = {
     {56, "data v[50:53], shift amounts in v54 / v55: the last register of a 56-register allocation"},
     {64, "as mode 0 with s_nop 4 in front of each 64-bit shift"},
     {64, "as mode 0, the shift amount copied out of v63 (v_mov_b32) into the output register first, then shifted by that"},
+    {64, "v_mad_u64_u32 with src0 = v63 (32-bit factor in the last register)"},
+    {64, "v_mad_u64_u32 with src1 = v63"},
+    {64, "v_ashrrev_i64 by v63"},
+    {64, "v_lshl_add_u64 with the shift amount (src1) in v63"},
+    {64, "v_cvt_f64_u32 of v63"},
+    {64, "v_mul_hi_u32 with src0 = v63 (32-bit control)"},
+    {64, "ds_read_b32 with the LDS address in v63"},
+    {64, "v_mad_u64_u32 with the 64-bit addend (src2) in v[62:63]"},
 };
 
 template <int MODE>
@@ -127,6 +135,55 @@ __global__ void __launch_bounds__(256) probe(const uint4* __restrict__ table, ui
                     "v_or_b32_e32 %[hi], v61, v59\n\t"
                     "v_or_b32_e32 %[lo], v60, v58\n\t",
                     "v58", "v59", "v60", "v61", "v62", "v63");
+            /* other instructions with a 32-bit operand in the last register: f = low word of w0, g = low word of w1 */
+            const uint32_t f = uint32_t(w0), g = uint32_t(w1);
+            if constexpr (MODE == 11 || MODE == 12) {
+                if constexpr (MODE == 11)
+                    RUN("ds_read_b128 v[58:61], %[addr] offset:48\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v63, v58\n\tv_mov_b32_e32 v62, v60\n\t"
+                        "v_mad_u64_u32 v[58:59], vcc, v63, v62, 0\n\tv_mov_b32_e32 %[lo], v58\n\tv_mov_b32_e32 %[hi], v59\n\t",
+                        "v58", "v59", "v60", "v61", "v62", "v63", "vcc");
+                else
+                    RUN("ds_read_b128 v[58:61], %[addr] offset:48\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v63, v58\n\tv_mov_b32_e32 v62, v60\n\t"
+                        "v_mad_u64_u32 v[58:59], vcc, v62, v63, 0\n\tv_mov_b32_e32 %[lo], v58\n\tv_mov_b32_e32 %[hi], v59\n\t",
+                        "v58", "v59", "v60", "v61", "v62", "v63", "vcc");
+                want = uint64_t(f) * uint64_t(g);
+            }
+            if constexpr (MODE == 13) {
+                RUN("ds_read_b128 v[58:61], %[addr] offset:48\n\tv_lshlrev_b32_e32 v63, 1, %[a]\n\ts_waitcnt lgkmcnt(0)\n\t"
+                    "v_ashrrev_i64 v[58:59], v63, v[58:59]\n\tv_mov_b32_e32 %[lo], v58\n\tv_mov_b32_e32 %[hi], v59\n\t",
+                    "v58", "v59", "v60", "v61", "v62", "v63");
+                want = uint64_t(int64_t(w0) >> (2 * a));
+            }
+            if constexpr (MODE == 14) {
+                RUN("ds_read_b128 v[58:61], %[addr] offset:48\n\tv_and_b32_e32 v63, 3, %[a]\n\ts_waitcnt lgkmcnt(0)\n\t"
+                    "v_lshl_add_u64 v[58:59], v[58:59], v63, v[60:61]\n\tv_mov_b32_e32 %[lo], v58\n\tv_mov_b32_e32 %[hi], v59\n\t",
+                    "v58", "v59", "v60", "v61", "v62", "v63");
+                want = (w0 << (a & 3u)) + w1;
+            }
+            if constexpr (MODE == 15) {
+                RUN("ds_read_b128 v[58:61], %[addr] offset:48\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v63, v58\n\t"
+                    "v_cvt_f64_u32_e32 v[60:61], v63\n\tv_mov_b32_e32 %[lo], v60\n\tv_mov_b32_e32 %[hi], v61\n\t",
+                    "v58", "v59", "v60", "v61", "v62", "v63");
+                const double dv = double(f);
+                want = __double_as_longlong(dv);
+            }
+            if constexpr (MODE == 16) {
+                RUN("ds_read_b128 v[58:61], %[addr] offset:48\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v63, v58\n\t"
+                    "v_mul_hi_u32 %[hi], v63, v60\n\tv_mul_lo_u32 %[lo], v63, v60\n\t",
+                    "v58", "v59", "v60", "v61", "v62", "v63");
+                want = uint64_t(f) * uint64_t(g);
+            }
+            if constexpr (MODE == 17) {
+                RUN("v_add_u32_e32 v63, 48, %[addr]\n\tds_read_b32 %[lo], v63\n\tds_read_b32 %[hi], v63 offset:4\n\ts_waitcnt lgkmcnt(0)\n\t",
+                    "v58", "v59", "v60", "v61", "v62", "v63");
+                want = w0;
+            }
+            if constexpr (MODE == 18) {
+                RUN("ds_read_b128 v[58:61], %[addr] offset:48\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v62, v60\n\tv_mov_b32_e32 v63, v61\n\t"
+                    "v_mad_u64_u32 v[60:61], vcc, v58, v59, v[62:63]\n\tv_mov_b32_e32 %[lo], v60\n\tv_mov_b32_e32 %[hi], v61\n\t",
+                    "v58", "v59", "v60", "v61", "v62", "v63", "vcc");
+                want = uint64_t(f) * uint64_t(uint32_t(w0 >> 32)) + w1;
+            }
             const uint64_t got = uint64_t(lo) | (uint64_t(hi) << 32);
             wrong += got != want;
             ++did;
@@ -165,10 +222,21 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&counters, 16));
     fill<<<4096, 256>>>(table, n_lines);
     CHECK(hipDeviceSynchronize());
+    const bool only_new = argc > 3;  // (the shift modes 0-10 are in profiles/r04/vgpr64_check_shift_modes.jsonl)
+    if (only_new) {
+        if (run_mode<11>(table, n_lines, rounds, counters) || run_mode<12>(table, n_lines, rounds, counters) || run_mode<13>(table, n_lines, rounds, counters) ||
+            run_mode<14>(table, n_lines, rounds, counters) || run_mode<15>(table, n_lines, rounds, counters) || run_mode<16>(table, n_lines, rounds, counters) ||
+            run_mode<17>(table, n_lines, rounds, counters) || run_mode<18>(table, n_lines, rounds, counters))
+            return 1;
+        return 0;
+    }
     if (run_mode<0>(table, n_lines, rounds, counters) || run_mode<1>(table, n_lines, rounds, counters) || run_mode<2>(table, n_lines, rounds, counters) ||
         run_mode<3>(table, n_lines, rounds, counters) || run_mode<4>(table, n_lines, rounds, counters) || run_mode<5>(table, n_lines, rounds, counters) ||
         run_mode<6>(table, n_lines, rounds, counters) || run_mode<7>(table, n_lines, rounds, counters) || run_mode<8>(table, n_lines, rounds, counters) ||
-        run_mode<9>(table, n_lines, rounds, counters) || run_mode<10>(table, n_lines, rounds, counters))
+        run_mode<9>(table, n_lines, rounds, counters) || run_mode<10>(table, n_lines, rounds, counters) || run_mode<11>(table, n_lines, rounds, counters) ||
+        run_mode<12>(table, n_lines, rounds, counters) || run_mode<13>(table, n_lines, rounds, counters) || run_mode<14>(table, n_lines, rounds, counters) ||
+        run_mode<15>(table, n_lines, rounds, counters) || run_mode<16>(table, n_lines, rounds, counters) || run_mode<17>(table, n_lines, rounds, counters) ||
+        run_mode<18>(table, n_lines, rounds, counters))
         return 1;
     return 0;
 }

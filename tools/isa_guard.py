@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""isa_guard.py -- keep a gfx950 hardware hazard out of the shipped kernels (tools/debug/vgpr64_check.hip).
+
+The hazard, as measured on MI355X (profiles/r04/vgpr64_check_*.jsonl): a VALU instruction of a 64-bit data type whose 32-BIT source
+operand is the LAST VGPR of the wave's allocation -- v63 of 64, v55 of 56, v71 of 72 (allocations are granules of 8) -- returns a
+wrong result in 6-7 % of its executions, differently from launch to launch: v_lshlrev_b64 / v_lshrrev_b64 / v_ashrrev_i64 with the
+shift amount there, for one. The same instruction is right with the operand in any other register, with the 64-bit VALUE in the
+last pair, with the wave given eight more registers, and after a v_mov of the operand into another register. hipcc 7.2 knows no such
+constraint (the operand is 32 bits wide: any VGPR will do), so whether a kernel is hit is an accident of register allocation: the
+is_member instance of fast_lookup_kernel allocates exactly 64 registers and keeps a shift amount in v63.
+
+Which instructions: of those tried (tools/debug/vgpr64_check.hip modes 0-18, profiles/r04/vgpr64_check_*.jsonl) the three 64-bit
+shifts fail -- v_lshlrev_b64, v_lshrrev_b64, v_ashrrev_i64 --; v_mad_u64_u32 (either factor, or the addend pair), v_lshl_add_u64,
+v_cvt_f64_u32, 32-bit shifts and multiplies by that register and LDS addresses in it are right. The guard stays on the safe side of
+what was tried: ANY 64-bit-typed VALU instruction with a 32-bit source in the last register.
+
+What this does: reads the device assembly of one translation unit (hipcc --cuda-device-only -S), finds every kernel that (1) uses
+the last register of its allocation and (2) names it as a 32-bit operand of an instruction whose mnemonic carries a 64-bit type, and
+gives such a kernel eight more registers (.amdhsa_next_free_vgpr, .amdhsa_accum_offset, .vgpr_count): the code is untouched, the
+register it names is no longer the last one. Writes the assembly back out and a JSON report; csrc/Makefile assembles what comes out.
+
+    python3 tools/isa_guard.py in.s out.s [--report report.json] [--check]     (--check: exit 1 if anything had to be changed)
+"""
+import json
+import re
+import sys
+
+GRANULE = 8
+# 64-bit typed VALU mnemonics: ..._b64, _u64, _i64, _f64 anywhere in the name (v_lshlrev_b64, v_mad_u64_u32, v_lshl_add_u64, v_cvt_f64_u32 ...)
+WIDE = re.compile(r"^v_\w*(b64|u64|i64|f64)")
+
+
+def kernels_of(lines):
+    """-> [{name, body: (first, last) line indices, vgpr_line, accum_line, next_free_vgpr}]"""
+    labels = {}
+    for i, l in enumerate(lines):
+        if l and not l[0].isspace() and l.rstrip().split(";")[0].rstrip().endswith(":"):
+            labels.setdefault(l.split(":")[0].strip(), i)
+    out = []
+    i = 0
+    while i < len(lines):
+        m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", lines[i])
+        if m:
+            k = {"name": m.group(1), "desc": i}
+            j = i
+            while ".end_amdhsa_kernel" not in lines[j]:
+                mm = re.match(r"\s*\.amdhsa_next_free_vgpr\s+(\d+)", lines[j])
+                if mm:
+                    k["vgpr_line"], k["next_free_vgpr"] = j, int(mm.group(1))
+                mm = re.match(r"\s*\.amdhsa_accum_offset\s+(\d+)", lines[j])
+                if mm:
+                    k["accum_line"], k["accum_offset"] = j, int(mm.group(1))
+                j += 1
+            k["body"] = (labels[k["name"]], i)
+            out.append(k)
+            i = j
+        i += 1
+    return out
+
+
+def hazards(lines, k):
+    n = k["next_free_vgpr"]
+    alloc = (max(n, 1) + GRANULE - 1) // GRANULE * GRANULE
+    last = alloc - 1
+    if n - 1 < last:
+        return alloc, []  # the last register of the allocation is not used at all
+    single = re.compile(r"(?<![\w\[:])v%d\b(?!\s*:)" % last)  # v63 as an operand of its own, not inside v[62:63]
+    found = []
+    for i in range(k["body"][0], k["body"][1]):
+        code = lines[i].split(";")[0].strip()
+        if not code or code.startswith(".") or code.endswith(":"):
+            continue
+        parts = code.split(None, 1)
+        if len(parts) < 2 or not WIDE.match(parts[0]):
+            continue
+        operands = parts[1].split(",")
+        # sources only: the first operand is the destination (a 32-bit destination in the last register is fine, and rare)
+        if any(single.search(o) for o in operands[1:]):
+            found.append({"line": i + 1, "instruction": code})
+    return alloc, found
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    src, dst = args[0], args[1]
+    report_path = sys.argv[sys.argv.index("--report") + 1] if "--report" in sys.argv else None
+    if report_path in args:
+        args.remove(report_path)
+    lines = open(src).read().split("\n")
+    report = {"source": src, "kernels": 0, "use_their_last_register": 0, "padded": []}
+    bumped = {}
+    for k in kernels_of(lines):
+        report["kernels"] += 1
+        if "next_free_vgpr" not in k:
+            continue
+        alloc, found = hazards(lines, k)
+        if k["next_free_vgpr"] == alloc:
+            report["use_their_last_register"] += 1
+        if not found:
+            continue
+        new = alloc + GRANULE
+        lines[k["vgpr_line"]] = re.sub(r"\d+\s*$", str(new), lines[k["vgpr_line"]])
+        if "accum_line" in k:
+            lines[k["accum_line"]] = re.sub(r"\d+\s*$", str(new), lines[k["accum_line"]])
+        bumped[k["name"]] = new
+        report["padded"].append({"kernel": k["name"], "allocation": alloc, "now": new, "instructions": found[:8], "count": len(found)})
+    # the metadata copy of the register count (what hipFuncGetAttributes reports)
+    name = None
+    for i, l in enumerate(lines):
+        m = re.match(r"\s*(?:- )?\.name:\s+(\S+)", l)
+        if m:
+            name = m.group(1)
+        m = re.match(r"(\s*\.vgpr_count:\s+)(\d+)", l)
+        if m and name in bumped:
+            lines[i] = m.group(1) + str(bumped[name])
+    open(dst, "w").write("\n".join(lines))
+    if report_path:
+        json.dump(report, open(report_path, "w"), indent=1)
+    print("[isa_guard] %s: %d kernels, %d use the last register of their allocation, %d padded%s" % (
+        src, report["kernels"], report["use_their_last_register"], len(report["padded"]),
+        "".join("\n  " + p["kernel"][:100] + " %d -> %d: %s" % (p["allocation"], p["now"], p["instructions"][0]["instruction"]) for p in report["padded"])), file=sys.stderr)
+    if "--check" in sys.argv and report["padded"]:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
