@@ -265,11 +265,11 @@ SSH_HD uint64_t sk_kmer_key(kmer_w<W> const& x, kmer_w<W> const& x_rc) {
 
 /* Key of a k-mer for the super-k-mer table: an m-mer occurrence chosen so that a k-mer and its reverse complement
    choose the same one. The table is free to use any such function (it is built and probed with the same one), so
-   this is NOT the reference's minimizer. The election looks at the first min(m, 16) bases of every m-mer occurrence
-   only -- ONE 32-bit word per candidate, one funnel shift to extract it, one 32-bit multiply to hash it -- and carries
-   the candidate's position in the low 6 bits of the hash, so that a running minimum replaces compare-and-select: four
-   VALU instructions per candidate (the first version hashed the whole m-mer: eleven; at k = 63, m = 25 the 78
-   candidates made the first pass VALU-bound). Per strand the leftmost occurrence with the smallest
+   this is NOT the reference's minimizer. The election looks at the first min(m, 12) bases of every m-mer occurrence
+   only -- 24 bits per candidate, one funnel shift to extract them, one 24-bit multiply-add to hash them -- and carries
+   the candidate's position in the low 6 bits of the hash, so that a running minimum replaces compare-and-select: two and a
+   half VALU instructions per candidate (the first version hashed the whole m-mer: eleven; round 2: four; at k = 63, m = 25
+   the 78 candidates made the first pass VALU-bound). Per strand the leftmost occurrence with the smallest
    26-bit hash wins; the strand with the smaller winning hash supplies the key -- the whole m-mer at the elected
    position --; equal hashes on the two strands = tie (no key: the caller takes the complete path). */
 struct sk_key_t {
@@ -280,8 +280,8 @@ struct sk_key_t {
 };
 
 constexpr uint32_t SK_POS_BITS = 6;  // positions 0 .. k - m <= 62
-/* 26-bit election hash (in the top bits) of the first bases of an m-mer occurrence: (bases ^ salt) * constant. The salt keeps
-   poly-A (all zero) from winning every election it takes part in. Two salts:
+/* 26-bit election hash (in the top bits) of the first 12 bases of an m-mer occurrence, the candidate's position below it:
+   (bases ^ salt) * constant + position. The salt keeps poly-A (all zero) from winning every election it takes part in. Two salts:
      k <= 31  SK_SELECT_SALT, irregular, applied to every candidate: consecutive candidates are shifts of one another and
               a multiplicative hash alone orders them in a correlated way -- 2 % more super-k-mers (table slots) measured
               with a salt that commutes with the shift; the lookup is bound by memory there, not by instructions;
@@ -291,10 +291,30 @@ constexpr uint32_t SK_POS_BITS = 6;  // positions 0 .. k - m <= 62
 constexpr uint32_t SK_SELECT_SALT = 0x6A09E667u, SK_SELECT_FLIP = 0xAAAAAAAAu;
 template <int W>
 SSH_HD uint32_t sk_select_salt() { return W == 1 ? SK_SELECT_SALT : SK_SELECT_FLIP; }
-/* the multiplier carries the shift that makes room for the position: (salted * odd) << 6 -- a bijection on the first 13
-   bases, the best-mixed bits of the product on top; one multiply, no masking (and + or would be two more instructions:
-   gfx950's v_and_or_b32 takes no 32-bit literal) */
-SSH_HD uint32_t sk_select_hash(uint32_t salted) { return salted * (0x9E3779B1u << SK_POS_BITS); }
+/* ONE instruction for hash and position (round 4; rounds 2-3: a 32-bit multiply and an or): v_mad_u32_u24 multiplies the low
+   24 bits of its operands -- it cuts the 12-base window out of the funnel-shifted word by itself -- and adds the position,
+   an inline constant. The multiplier carries the shift that makes room for the position: (window * odd 18-bit) << 6 -- the
+   low 32 bits of that are a 26-bit multiplicative hash (a bijection on the window's low 26 bits, its best-mixed bits on
+   top) above six zero bits. */
+constexpr uint32_t SK_SELECT_MUL = 0x278DDu << SK_POS_BITS;  // 0x9E3740: 24 bits
+static_assert(SK_SELECT_MUL < (1u << 24) && ((SK_SELECT_MUL >> SK_POS_BITS) & 1u), "an odd multiplier times 2^6, within 24 bits");
+SSH_HD uint32_t sk_select_hash(uint32_t salted, uint32_t position, uint32_t mul) {  // mul: sk_select_mul()
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(salted, mul) + position;
+#else
+    return (salted & 0xFFFFFFu) * mul + position;
+#endif
+}
+/* the multiplier in a scalar register, its value hidden from the compiler: knowing that its low six bits are zero hipcc turns
+   the addition of the position into an OR, and for multiply-then-OR it has no single instruction (v_mul_u32_u24 + v_or_b32:
+   the three instructions per candidate this was meant to leave behind) */
+SSH_HD uint32_t sk_select_mul() {
+    uint32_t mul = SK_SELECT_MUL;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(mul));
+#endif
+    return mul;
+}
 
 /* low 32 bits of (hi:lo) >> s, s in 0..31: one v_alignbit_b32 on the device (a 64-bit shift costs five times as much) */
 SSH_HD uint32_t funnel32(uint32_t lo, uint32_t hi, uint32_t s) {
@@ -306,22 +326,25 @@ SSH_HD uint32_t funnel32(uint32_t lo, uint32_t hi, uint32_t s) {
 }
 
 /* the election over one strand: f = the strand's words (SALT_EACH false: already salted), one more word behind them.
-   MASKED: m < 16 (the hashed word is cut to 2m bits). Four instructions per candidate at best: funnel shift, multiply,
-   or, minimum */
+   MASKED: m < 12: the hashed window is cut to 2m bits -- shifted left by `mask` = 24 - 2m bits, out of the multiply's reach.
+   Two and a half instructions per candidate at best: funnel shift, multiply-add, and a minimum shared between two (v_min3) */
 template <int D, bool MASKED, bool SALT_EACH>
 SSH_HD uint32_t sk_elect(uint32_t const (&f)[D + 1], uint32_t n, uint32_t mask) {
     uint32_t best = 0xFFFFFFFFu;
+    const uint32_t mul = sk_select_mul();
     auto candidate = [&](uint32_t lo, uint32_t hi, uint32_t t, uint32_t i) {
         uint32_t word = funnel32(lo, hi, 2 * t);
         if constexpr (SALT_EACH) word ^= SK_SELECT_SALT;
-        if constexpr (MASKED) word &= mask;
-        const uint32_t h = sk_select_hash(word) | i;
+        if constexpr (MASKED) word <<= mask;  // (what lies beyond the m-mer leaves the 24 bits the multiply looks at)
+        const uint32_t h = sk_select_hash(word, i, mul);
         best = h < best ? h : best;
     };
     /* n is the same for all lanes. A word whose 16 candidates all exist is unrolled: shifts and positions are constants,
-       nothing for the scalar unit to do; the last, partial word is a counted loop. (One loop over all candidates with a
-       bound test per candidate costs a select per candidate on the vector side, or -- the bound folded into a scalar tag --
-       four scalar instructions per candidate: at k = 63 the CU's single scalar unit was then 72 % busy.) */
+       nothing for the scalar unit to do. The last, partial word is entered at the right candidate through a switch (one
+       computed jump; its candidates are constants as well, taken from the last down to the first) -- as a counted loop
+       (rounds 2-3) it cost ten scalar instructions per candidate, 140 of the 304 of a k = 63 first-pass wave. (One loop over
+       all candidates with a bound test per candidate costs a select per candidate on the vector side, or -- the bound folded
+       into a scalar tag -- four scalar instructions per candidate: at k = 63 the CU's single scalar unit was then 72 % busy.) */
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -333,10 +356,25 @@ SSH_HD uint32_t sk_elect(uint32_t const (&f)[D + 1], uint32_t n, uint32_t mask) 
             for (uint32_t t = 0; t < 16; ++t) candidate(f[j], f[j + 1], t, 16 * uint32_t(j) + t);
         } else {
             const uint32_t rest = n > 16 * uint32_t(j) ? n - 16 * uint32_t(j) : 0u;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-            for (uint32_t t = 0; t < rest; ++t) candidate(f[j], f[j + 1], t, 16 * uint32_t(j) + t);
+            const uint32_t lo = f[j], hi = f[j + 1], at = 16 * uint32_t(j);
+            switch (rest) {  // (rest < 16: a full word was taken by the branch above)
+                case 15: candidate(lo, hi, 14, at + 14); [[fallthrough]];
+                case 14: candidate(lo, hi, 13, at + 13); [[fallthrough]];
+                case 13: candidate(lo, hi, 12, at + 12); [[fallthrough]];
+                case 12: candidate(lo, hi, 11, at + 11); [[fallthrough]];
+                case 11: candidate(lo, hi, 10, at + 10); [[fallthrough]];
+                case 10: candidate(lo, hi, 9, at + 9); [[fallthrough]];
+                case 9: candidate(lo, hi, 8, at + 8); [[fallthrough]];
+                case 8: candidate(lo, hi, 7, at + 7); [[fallthrough]];
+                case 7: candidate(lo, hi, 6, at + 6); [[fallthrough]];
+                case 6: candidate(lo, hi, 5, at + 5); [[fallthrough]];
+                case 5: candidate(lo, hi, 4, at + 4); [[fallthrough]];
+                case 4: candidate(lo, hi, 3, at + 3); [[fallthrough]];
+                case 3: candidate(lo, hi, 2, at + 2); [[fallthrough]];
+                case 2: candidate(lo, hi, 1, at + 1); [[fallthrough]];
+                case 1: candidate(lo, hi, 0, at + 0); [[fallthrough]];
+                default: break;
+            }
             break;
         }
     }
@@ -360,11 +398,11 @@ SSH_HD sk_key_t sk_key(kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, ui
     f[D] = r[D] = once;
     const uint32_t n = k - m + 1;
     uint32_t best_f, best_r;
-    if (m >= 16) {  // uniform
+    if (m >= 12) {  // uniform: the 12-base window lies inside every m-mer
         best_f = sk_elect<D, false, EACH>(f, n, 0u);
         best_r = sk_elect<D, false, EACH>(r, n, 0u);
     } else {
-        const uint32_t mask = (1u << (2 * m)) - 1;
+        const uint32_t mask = 24 - 2 * m;  // (a shift count: see sk_elect)
         best_f = sk_elect<D, true, EACH>(f, n, mask);
         best_r = sk_elect<D, true, EACH>(r, n, mask);
     }

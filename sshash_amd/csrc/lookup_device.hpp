@@ -833,6 +833,17 @@ __device__ __forceinline__ uint4 sk_load_piece(char const* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+/* Between two phases of a wave that talk through LDS: everything this lane has issued has completed, and the compiler moves
+   no memory operation across. (The "wavefront" fences used elsewhere in this file order the accesses for the compiler and rely on
+   the hardware executing a wave's DS instructions in order; here an LDS word written by one lane steers a GLOBAL load of another
+   and the loaded line goes back through LDS -- the explicit wait keeps the hand-over independent of what the compiler infers about it,
+   tools/debug/member_mismatch.py.) */
+__device__ __forceinline__ void sk_wave_sync() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 /* LINE: which 64-byte line of the bucket (k <= 31: the bucket is one line holding both slots; k <= 63: line 0 = slot 0,
    line 1 = slot 1, fetched only by the lanes that still need it) */
 template <int W, bool MIXED = false>
@@ -901,11 +912,34 @@ __device__ __forceinline__ void sk_probe_bucket_wave(dict_view const& d, sk_quer
         }
     }
     if constexpr (W == 2) {
-        __builtin_amdgcn_wave_barrier();
-        const bool second = need && r.outcome == FAST_MISS && flags.second_used;
-        if (__ballot(second) != 0) {  // wave-uniform
-            sk_stage_lines<W>(d, bucket, 1u, second, wave_stage);
-            if (second) sk_examine_slot<W, false>(d, Q, c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
+        /* Slot 1's line, for the fifth of the lanes whose key's fingerprint is there. Not another four rounds of the whole wave
+           (rounds 2-3: 4 loads a lane, 8 broadcasts, 4 LDS writes, for 13 lines of 64 on average): the wave's 16 quads become
+           fetch units, as in sk_finish_in_wave -- the lanes that want a line are ranked with a ballot, lane number q of them
+           posts its bucket for quad q, ONE load instruction of all 64 lanes fetches those lines, the owners examine them out
+           of LDS; a second turn when more than 16 lanes want one (one wave in eight). The first pass at k <= 63 is bound by
+           its instructions: this takes some thirty of them off every wave. */
+        bool second = need && r.outcome == FAST_MISS && flags.second_used;
+        uint32_t* posted = reinterpret_cast<uint32_t*>(wave_stage + 64);  // (behind the 64 pieces of the lines fetched below; slot 0's lines are spent)
+        char const* slots = static_cast<char const*>(d.sk.slots);
+#pragma unroll 1
+        for (;;) {
+            sk_wave_sync();  // every lane is done with what the staging area held
+            const uint64_t mask = __ballot(second);
+            if (mask == 0) break;  // wave-uniform
+            const uint32_t rank = uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
+            const bool served = second && rank < 16;
+            if (lane < 16) posted[lane] = 0u;
+            sk_wave_sync();
+            if (served) posted[rank] = bucket;
+            sk_wave_sync();
+            const uint32_t b = posted[lane >> 2];
+            wave_stage[lane] = sk_load_piece(slots + uint64_t(b) * 128 + 64 + 16 * (lane & 3u));  // quad q's line at wave_stage[4q .. 4q+3]
+            sk_wave_sync();
+            if (served) {
+                const uint4* line = wave_stage + 4 * rank;
+                sk_examine_slot<W, false>(d, Q, c, [line](uint32_t i) { return line[i]; }, r, key_seen, marker, flags);
+                second = false;
+            }
         }
     }
     go_on = flags.go_on;
@@ -961,17 +995,6 @@ __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<
    queue entry written and read back, no second kernel, and above all no placeholder id that a later pass rewrites: an 8-byte
    store into a line that has left the caches costs the DRAM a masked write -- a random access of its own, one of the 2.5 a
    resumed query cost in the resume pass. */
-/* Between two phases of a wave that talk through LDS: everything this lane has issued has completed, and the compiler moves
-   no memory operation across. (The "wavefront" fences used elsewhere in this file order the accesses for the compiler and rely on
-   the hardware executing a wave's DS instructions in order; here an LDS word written by one lane steers a GLOBAL load of another
-   and the loaded line goes back through LDS -- the explicit wait keeps the hand-over independent of what the compiler infers about it,
-   tools/debug/member_mismatch.py.) */
-__device__ __forceinline__ void sk_wave_sync() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-}
-
 /* k <= 31 only: at k <= 63 the first pass is bound by its instructions, not by memory, and carrying this loop cost it 6 %
    (28.3 -> 26.7 G lookups/s, profiles/r03/inwave_ab_k63.txt): there the stragglers keep their own pass. */
 __device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<1> const& x, kmer_w<1> const& x_rc, sk_key_t const& kk, sk_walk_t& w,

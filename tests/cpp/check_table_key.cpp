@@ -31,17 +31,22 @@ static int check(uint32_t k, uint32_t m, uint64_t trials, std::mt19937_64& rng, 
         if (a.pos > k - m) return printf("position outside the k-mer (k=%u m=%u)\n", k, m), 1;
         const kmer_w<W>& winner = a.rc ? y : x;
         if ((kmer_shr_chars<W>(winner, a.pos).w[0] & mask) != a.key) return printf("key is not the m-mer at its position\n"), 1;
-        /* leftmost among equal hashes on the winning strand */
-        const uint32_t prefix_mask = m >= 16 ? 0xFFFFFFFFu : uint32_t(mask);
-        const uint32_t won = sk_select_hash((uint32_t(a.key) ^ sk_select_salt<W>()) & prefix_mask);
+        /* leftmost among equal hashes on the winning strand: the election hashes the first min(m, 12) bases of an occurrence
+           (device_layout.hpp: sk_select_hash; m < 12: the window shifted left by 24 - 2m bits) and compares the 26-bit hashes */
+        auto hash_at = [&](kmer_w<W> const& strand, uint32_t i) {
+            uint32_t word = uint32_t(kmer_shr_chars<W>(strand, i).w[0]) ^ sk_select_salt<W>();
+            if (m < 12) word <<= 24 - 2 * m;
+            return sk_select_hash(word, 0u, sk_select_mul()) >> SK_POS_BITS;
+        };
+        const uint32_t won = hash_at(winner, a.pos);
         for (uint32_t i = 0; i + m <= k; ++i) {
-            const uint32_t h = sk_select_hash((uint32_t(kmer_shr_chars<W>(winner, i).w[0]) ^ sk_select_salt<W>()) & prefix_mask);
+            const uint32_t h = hash_at(winner, i);
             if (i < a.pos ? h <= won : h < won)
                 return printf("another m-mer of the winning strand should have been elected (k=%u m=%u)\n", k, m), 1;
         }
         const kmer_w<W>& loser = a.rc ? x : y;
         for (uint32_t i = 0; i + m <= k; ++i)
-            if (sk_select_hash((uint32_t(kmer_shr_chars<W>(loser, i).w[0]) ^ sk_select_salt<W>()) & prefix_mask) <= won)
+            if (hash_at(loser, i) <= won)
                 return printf("an m-mer of the other strand should have been elected (k=%u m=%u)\n", k, m), 1;
     }
     return 0;
