@@ -288,10 +288,10 @@ def run_other_workload(args, extra):
            "--seed", str(args.seed), "--no-extra-mixes", "--no-other-paths", "--no-file-query", "--no-other-workloads"] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     t0 = time.time()
-    p = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)  # (its log goes where this process's log goes)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     if p.returncode != 0 or not lines:
-        return {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr[-1500:]}
+        return {"error": f"exit code {p.returncode}", "command": " ".join(cmd[1:])}
     line = json.loads(lines[-1])
     line["wall_s_of_the_child"] = round(time.time() - t0, 1)
     return line
@@ -717,24 +717,6 @@ def main():
             table_histogram["super_kmers_under_heavy_keys_fraction"] = round(heavy / max(1, table_histogram["super_kmers"]), 5)
             table_histogram["kmers_under_heavy_keys"] = stats["sk_heavy_kmers"]
             table_histogram["kmers_under_heavy_keys_fraction"] = round(stats["sk_heavy_kmers"] / d.num_kmers(), 5)
-        other_workloads = None
-        # test scaffolding (tests/test_gpu_bench_harness.py): "bases,queries,reads" shrinks the children and lets a reduced parent have them
-        reduced = os.environ.get("SSHASH_BENCH_TEST_OTHER_WORKLOADS")
-        if world == 1 and sharded is None and args.workload == "c3" and not args.no_other_workloads and (args.bases == WORKLOADS["c3"][0] or reduced):
-            # BASELINE.json's other single-GPU configurations, each a run of this script of its own (index, replica, batch, oracle check,
-            # roofline, cpu_baseline): C2 (configs[1]) and C4 (configs[3]: the k = 63 dictionary -- point lookups and its streaming query)
-            del dq, out
-            d.close()
-            torch.cuda.empty_cache()
-            other_workloads = {}
-            for name, extra in (("c2", ["--workload", "c2"]), ("c4", ["--workload", "c4"]),
-                                ("c4_streaming", ["--workload", "c4", "--streaming", "--reads", str(args.other_streaming_reads)])):
-                if reduced:
-                    b_, q_, r_ = reduced.split(",")
-                    extra = extra + ["--bases", b_, "--cpu-sample", "100000"] + (["--reads", r_, "--stream-oracle-reads", "5000"] if "--streaming" in extra else ["--queries", q_])
-                log(f"other workload {name} ...")
-                other_workloads[name] = run_other_workload(args, extra)
-                log(f"other workload {name}: {other_workloads[name].get('value')} {other_workloads[name].get('unit')}")
         total = args.queries * args.steps
         result = {
             "metric": "k-mer Lookups/sec (batched random queries, bit-exact ids)",
@@ -766,8 +748,26 @@ def main():
             "other_mixes": extra,
             "other_paths": other_paths,
             "streaming_from_file": from_file,
-            "other_workloads": other_workloads,
+            "other_workloads": None,
         }
+        other_workloads = None  # (last: this process gives its GPU memory back first)
+        # test scaffolding (tests/test_gpu_bench_harness.py): "bases,queries,reads" shrinks the children and lets a reduced parent have them
+        reduced = os.environ.get("SSHASH_BENCH_TEST_OTHER_WORKLOADS")
+        if world == 1 and sharded is None and args.workload == "c3" and not args.no_other_workloads and (args.bases == WORKLOADS["c3"][0] or reduced):
+            # BASELINE.json's other single-GPU configurations, each a run of this script of its own (index, replica, batch, oracle check,
+            # roofline, cpu_baseline): C2 (configs[1]) and C4 (configs[3]: the k = 63 dictionary -- point lookups and its streaming query)
+            d.close()
+            torch.cuda.empty_cache()
+            other_workloads = {}
+            for name, extra in (("c2", ["--workload", "c2"]), ("c4", ["--workload", "c4"]),
+                                ("c4_streaming", ["--workload", "c4", "--streaming", "--reads", str(args.other_streaming_reads)])):
+                if reduced:
+                    b_, q_, r_ = reduced.split(",")
+                    extra = extra + ["--bases", b_, "--cpu-sample", "100000"] + (["--reads", r_, "--stream-oracle-reads", "5000"] if "--streaming" in extra else ["--queries", q_])
+                log(f"other workload {name} ...")
+                other_workloads[name] = run_other_workload(args, extra)
+                log(f"other workload {name}: {other_workloads[name].get('value')} {other_workloads[name].get('unit')}")
+        result["other_workloads"] = other_workloads
     barrier()
     if use_dist:
         dist.destroy_process_group()

@@ -193,6 +193,12 @@ constexpr double SK_SLOTS_PER_KEY = 2.5;  // slots per item: load factor 0.4 (DE
    37.8 -> 37.6 -> 37.25 -> 36.6 G lookups/s; C4 (k = 63, 64-byte slots, 9.9 % of the k-mers under heavy keys) 66.7 -> 58.0 -> 53.6 ->
    49.3 GB with every rate inside the box's +-3 % run-to-run spread (the first pass is bound by instructions there, not by lines). */
 constexpr double SK_SLOTS_PER_KMER_NARROW = 2.0, SK_SLOTS_PER_KMER_WIDE = 1.75;  // k <= 31, k <= 63
+/* k <= 31 (round 4): a bucket of the k-mers' region is one 64-byte line of THREE entries instead of two copies of 32-byte slots --
+   a k-mer entered under its own key needs the k-mer, where it lies and in which string, not its super-k-mer's 64 bases:
+     dword 0          bits 0-2 entry e in use | bits 3-7 the bucket's go-on flags | bits 21-31 the first-choice filter (as slot 0)
+     dwords 1+5e ..   k-mer (as the strings spell it) lo, hi | position lo | string id | position bits 32-39
+   134.9 M k-mers of C3's heavy keys: 8.6 GB at one slot each, 5.8 GB so. */
+constexpr uint32_t SK_KMER_ENTRIES_NARROW = 3, SK_KMER_ENTRY_WORDS = 5;
 /* why a replica was given no table (sshash_device_stats) */
 constexpr uint32_t SK_ABSENT_DISABLED = 1, SK_ABSENT_MINIMIZER_SHARD = 2, SK_ABSENT_TOO_MANY_BASES = 3, SK_ABSENT_TOO_MANY_ITEMS = 4,
                    SK_ABSENT_NO_MEMORY = 5;

@@ -180,7 +180,10 @@ void engine::device_stats(int device, uint64_t out[16]) const {
     out[1] = r->view.directory.enabled ? r->view.directory.num_buckets : 0;
     out[2] = r->directory_overflowed;
     out[3] = r->directory_entries;
-    out[4] = r->view.sk.enabled ? (uint64_t(r->view.sk.num_buckets) + r->view.sk.kmer_buckets) * SK_BUCKET_SLOTS : 0;
+    /* places an item can take: two slots per bucket of the keys' region; per bucket of the k-mers' region two entries (k <= 63) or three (k <= 31) */
+    out[4] = r->view.sk.enabled ? uint64_t(r->view.sk.num_buckets) * SK_BUCKET_SLOTS +
+                                      uint64_t(r->view.sk.kmer_buckets) * (r->view.k > 31 ? SK_BUCKET_SLOTS : SK_KMER_ENTRIES_NARROW)
+                                : 0;
     out[5] = r->sk_keys;
     out[6] = r->sk_keys - r->sk_heavy_keys;
     out[7] = r->sk_unplaced;
@@ -260,6 +263,19 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
     v.directory.buckets = nullptr;
     v.directory.num_buckets = 0;
     v.directory.enabled = 0;
+    /* what is uploaded BEHIND the table (skew index, weights): the table's budget test must leave room for it, or a table that
+       just fits would take the finished replica past SSHASH_AMD_HBM_BUDGET and the upload would fail where a table-less replica
+       was possible */
+    rep->bytes_still_to_come = 8 * sizeof(skew_part_dev);
+    for (uint32_t p = 0; p < 8; ++p) {
+        if (p < idx.skew_num_partitions && idx.skew_mphfs[p].num_keys) {
+            mphf_host const& f = idx.skew_mphfs[p];
+            rep->bytes_still_to_come += f.parts.size() * sizeof(f.parts[0]) + (f.pilots.size() + f.free_slots.size() + idx.skew_positions[p].words.size()) * 8;
+        } else {
+            rep->bytes_still_to_come += 64;
+        }
+    }
+    if (idx.weighted()) rep->bytes_still_to_come += (idx.weight_starts.size() + idx.weight_values.size()) * 8;
     build_sk_table(*rep, idx, table_shards, table_shard_id);
     /* With the table resident only the deferred queries (ties, items that found no slot: ~0.05 %) and the
        `minimizer_found` byte of a miss come through the minimizer structures: they keep the host index's form -- bit-packed
@@ -409,7 +425,7 @@ struct pass_queues {
        reference's flag depends on which arbitrary bucket the MPHF lands on): misses are queued with DEFER_FLAG_ONLY set
        and the last pass stores that one byte for them */
     uint32_t flag_misses;
-    /* k <= 31: the first pass finishes every probe itself (sk_lookup_in_wave); the resume queue stays empty */
+    /* the first pass finishes every probe itself (sk_lookup_in_wave); the resume queue stays empty */
     uint32_t finish_in_wave;
 };
 constexpr uint32_t DEFER_FLAG_ONLY = 1u << 31;  // in a deferred-queue entry (query indices stay below 2^27)
@@ -484,10 +500,18 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
     const uint32_t shard = blockIdx.x & (DEFER_SHARDS - 1);  // the queues are sharded by workgroup: one hot counter would
                                                              // serialise at ~90 atomics/us
     if constexpr (SK) {
+        /* k <= 31 (SSHASH_INWAVE_WIDE: k <= 63 as well -- measured in round 4, profiles/r04/inwave_k63_ab.txt: 27.1 -> 25.6 G lookups/s;
+           the loop's state takes the kernel from 60 to 86 registers, 8 to 5 waves per SIMD, and a pass that runs at the random-line rate
+           wants the waves) */
+#ifdef SSHASH_INWAVE_WIDE
+        constexpr bool IN_WAVE = true;
+#else
+        constexpr bool IN_WAVE = W == 1;
+#endif
         bool whole = false;
-        if constexpr (W == 1) {
+        if constexpr (IN_WAVE) {
             whole = q.finish_in_wave != 0;  // uniform
-            if (whole) r = sk_lookup_in_wave(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1), lds + (threadIdx.x >> 6) * (64 * 4));
+            if (whole) r = sk_lookup_in_wave<W>(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1), lds + (threadIdx.x >> 6) * (64 * 4));
         }
         if (!whole)
             r = sk_first_pass_wave<W>(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1),
@@ -507,7 +531,8 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
         }
         if (!active) return;
     } else {
-        r = active ? fast_lookup_one<W, CANON>(d, x, check_rc) : fast_unsettled(false);
+        if constexpr (W == 1 && !CANON) r = fast_lookup_pairs(d, x, active, check_rc);  // (32-byte units fetched by pairs of lanes)
+        else r = active ? fast_lookup_one<W, CANON>(d, x, check_rc) : fast_unsettled(false);
         /* a MIDLOAD bucket whose first position did not settle the query: the rest of it is scanned by whole waves
            (scan_lookup_kernel), not by this lane while its 63 neighbours wait */
         const bool scan = active && r.outcome == FAST_SCAN;
@@ -813,8 +838,8 @@ static overlap_mode overlap_tail_passes() {
 }
 constexpr uint64_t OVERLAP_PIECES = 4, OVERLAP_MIN_QUERIES = uint64_t(1) << 22;
 
-/* k <= 31: probes that need more than their first bucket are finished inside the first pass (lookup_device.hpp:
-   sk_finish_in_wave); SSHASH_AMD_INWAVE=0 sends them to the resume pass instead (the round-2 form; k <= 63 always does) */
+/* k <= 31: probes that need more than their first bucket are finished inside the first pass (lookup_device.hpp: sk_finish_in_wave);
+   SSHASH_AMD_INWAVE=0 sends them to the resume pass instead (the round-2 form; k <= 63 always does: measured again in round 4) */
 static bool finish_in_wave() {
     static const bool on = [] {
         const char* e = std::getenv("SSHASH_AMD_INWAVE");
@@ -844,7 +869,11 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                waits for the last tail before the call returns control of it. */
             const uint64_t piece_max = launch_piece_queries();
             uint64_t pieces = (n + piece_max - 1) / piece_max;
+#ifdef SSHASH_INWAVE_WIDE
+            const bool in_wave = d.sk.enabled && finish_in_wave();
+#else
             const bool in_wave = W == 1 && d.sk.enabled && finish_in_wave();
+#endif
             if (overlap_tail_passes() == overlap_mode::always && n >= OVERLAP_MIN_QUERIES) pieces = std::max<uint64_t>(pieces, OVERLAP_PIECES);
             const uint64_t piece = ((n + pieces - 1) / pieces + block - 1) / block * block;  // equal pieces, whole workgroups
             pieces = (n + piece - 1) / piece;

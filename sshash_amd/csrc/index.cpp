@@ -406,6 +406,8 @@ void build_from_packed(host_index& idx, std::vector<uint64_t>&& packed_bases, st
     uint64_t max_code = (uint64_t(1) << bits_per_offset);  // width >= bits_per_offset + 1 (:58-61)
     for (uint64_t c : code) max_code = std::max(max_code, c);
     idx.control_codewords.resize(num_minimizers, bits_for(max_code));
+    /* (the device's bucket-scan pass carries a bucket's place in this array in 32 bits: lookup_device.hpp scan_meta) */
+    if (num_mid_positions >= (uint64_t(1) << 32)) throw error(error_kind::build, "mid_load_buckets exceeds 2^32 entries");
     idx.mid_load_buckets.resize(num_mid_positions, bits_per_offset);
     idx.heavy_load_buckets.resize(num_heavy_positions, bits_per_offset);
     {
@@ -785,6 +787,7 @@ static void validate_index(host_index const& idx) {
     validate_mphf(idx.minimizers_mphf, "minimizers");
     validate_packed(idx.control_codewords, "control codewords");
     validate_packed(idx.mid_load_buckets, "mid-load buckets");
+    if (idx.mid_load_buckets.size >= (uint64_t(1) << 32)) bad("mid-load buckets (2^32 entries or more)");
     validate_packed(idx.heavy_load_buckets, "heavy-load buckets");
     if (idx.control_codewords.size != idx.minimizers_mphf.num_keys) bad("one control codeword per minimizer");
     if (idx.heavy_load_buckets.size && idx.mid_load_buckets.size && idx.mid_load_buckets.width != idx.heavy_load_buckets.width)

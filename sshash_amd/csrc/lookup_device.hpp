@@ -36,6 +36,13 @@ struct window_t {
     bool crosses;        // a string boundary lies in (off, off + k - 1]
 };
 
+/* 16 bytes that will not be read again soon (a bucket line, an atom, a tile of queries): nontemporal */
+typedef uint32_t sk_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 sk_load_piece(char const* p) {
+    const sk_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const sk_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ uint64_t funnel_shr(uint64_t lo, uint64_t hi, uint32_t s /* 0..63 */) {
     return (lo >> s) | ((hi << 1) << (63 - s));
 }
@@ -499,6 +506,112 @@ __device__ __forceinline__ fast_t fast_probe_canonical(dict_view const& d, kmer_
     return r;
 }
 
+/* ---- the same first pass with PAIR-COOPERATIVE 32-byte fetches (round 4; regular dictionaries, k <= 31) ---------------------
+   A lane that reads a 32-byte unit -- a directory bucket, an atom of the strings -- with two 16-byte loads makes every load
+   instruction of the wave touch 64 different pages: two translation requests per unit, and the chip serves 75 G of those a second
+   (DESIGN.md section 6): the table-less first pass ran at 39 G units/s, that bound, not the memory's. Here the two lanes of a pair
+   read each other's units together: one load instruction fetches the even lane's unit (16 bytes a lane), the next the odd lane's,
+   the halves change hands through DPP -- the same two load instructions per lane, but each touches 32 units instead of 64: one
+   translation per unit. Called by all lanes of the wave (need = false: no unit wanted; the pair's load goes to unit 0). */
+template <int SEL>  // 0: the pair's even lane's value; 1: the odd lane's; 2: the other lane's
+__device__ __forceinline__ uint32_t pair_perm(uint32_t v) {
+    constexpr int CTRL = SEL == 0 ? 0xA0 : SEL == 1 ? 0xF5 : 0xB1;  // quad_perm [0,0,2,2], [1,1,3,3], [1,0,3,2]
+    return uint32_t(__builtin_amdgcn_mov_dpp(int(v), CTRL, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ void pair_load32(void const* __restrict__ base, uint32_t unit, bool need, uint4& lo, uint4& hi) {
+    const uint32_t idx = need ? unit : 0u;
+    const uint32_t ie = pair_perm<0>(idx), io = pair_perm<1>(idx);
+    const uint32_t sub = threadIdx.x & 1u;
+    char const* b = static_cast<char const*>(base) + 16 * sub;
+    const uint4 pa = sk_load_piece(b + uint64_t(ie) * 32), pb = sk_load_piece(b + uint64_t(io) * 32);  // nontemporal: read once
+    /* the even lane holds the first half of both units, the odd lane the second half of both: each gives the other what it lacks */
+    const uint4 give = sub ? pa : pb;
+    const uint4 got = make_uint4(pair_perm<2>(give.x), pair_perm<2>(give.y), pair_perm<2>(give.z), pair_perm<2>(give.w));
+    lo = sub ? got : pa;
+    hi = sub ? pb : got;
+}
+
+__device__ __forceinline__ resolve_t fast_resolve_pairs(dict_view const& d, uint64_t minimizer, bool need) {
+    resolve_t r;
+    r.code = 0;
+    r.present = false;
+    r.settled = true;
+    if (d.directory.enabled) {  // uniform
+        const uint64_t h = directory_hash(minimizer);
+        uint4 q0, q1;
+        pair_load32(d.directory.buckets, directory_bucket(h, d.directory.num_buckets), need, q0, q1);
+        const uint32_t want = (directory_fingerprint(h) << 8) | (1u << 24);  // (as directory_probe)
+        const uint32_t mask = 0x01FFFF00u;
+        const bool m0 = (q0.y & mask) == want, m1 = (q0.w & mask) == want, m2 = (q1.y & mask) == want, m3 = (q1.w & mask) == want;
+        uint32_t lo = 0, hi = 0;
+        lo = m0 ? q0.x : lo;  hi = m0 ? q0.y : hi;
+        lo = m1 ? q0.z : lo;  hi = m1 ? q0.w : hi;
+        lo = m2 ? q1.x : lo;  hi = m2 ? q1.y : hi;
+        lo = m3 ? q1.z : lo;  hi = m3 ? q1.w : hi;
+        r.present = need && (m0 || m1 || m2 || m3);
+        r.code = uint64_t(lo) | (uint64_t(hi & 0xFFu) << 32);
+        r.settled = (q0.y >> 31) == 0;
+    } else if (need) {  // pilot and codeword are 8-byte reads: one translation each as they are
+        r = fast_resolve(d, minimizer);
+    }
+    return r;
+}
+
+__device__ __forceinline__ fast_t fast_probe_regular_pairs(dict_view const& d, kmer_w<1> const& x, minimizer_t mini, bool rc_strand,
+                                                           resolve_t const& a, bool need) {
+    fast_t r = fast_unsettled(need && !a.present && !a.settled);
+    bucket_t b;
+    b.first_offset = 0;
+    b.size = 1;
+    bool probe = need && a.present;
+    if (probe && !fast_bucket(d, a.code, b)) {  // HEAVYLOAD: the complete path
+        r = fast_unsettled(true);
+        probe = false;
+    }
+    const uint64_t p = b.first_offset;
+    const bool aligned = p >= mini.pos;
+    const uint64_t off = aligned ? p - mini.pos : p;
+    uint4 q0, q1;
+    pair_load32(d.granules, uint32_t(off >> 5), probe, q0, q1);
+    if (probe) {
+        const uint32_t rr = uint32_t(off) & 31u;  // (read_window<1>)
+        const uint64_t b0 = uint64_t(q0.x) | (uint64_t(q0.y) << 32), b1 = uint64_t(q0.z) | (uint64_t(q0.w) << 32);
+        const uint64_t kmer = funnel_shr(b0, b1, 2 * rr) & low_mask(2 * d.k);
+        const uint64_t marks = uint64_t(q1.x) | (uint64_t(q1.y) << 32);
+        const bool crosses = ((marks >> (rr + 1)) & low_mask(d.k - 1)) != 0;
+        const uint64_t mm = aligned ? ((kmer >> (2 * mini.pos)) & low_mask(2 * d.m)) : (kmer & low_mask(2 * d.m));
+        if (mm != mini.value) {
+            r = fast_unsettled(!a.settled);  // a fingerprint's false positive: final only if the directory bucket never overflowed
+        } else if (aligned && kmer == x.w[0] && !crosses) {
+            r.outcome = FAST_HIT;
+            r.kmer_offset = p - mini.pos;
+            r.string_id = q1.z + __popc(q1.x & uint32_t((uint64_t(2) << rr) - 1)) - 1;
+        } else if (b.size > 1) {
+            r.outcome = FAST_SCAN;
+            r.kmer_offset = scan_meta(b, mini.pos, rc_strand);
+        }
+    }
+    return r;
+}
+
+/* all lanes of the wave; active = false: no query */
+__device__ __forceinline__ fast_t fast_lookup_pairs(dict_view const& d, kmer_w<1> const& x, bool active, bool check_rc) {
+    const minimizer_t mf = compute_minimizer<1>(x, d.k, d.m, d.hash_magic);
+    fast_t r = fast_probe_regular_pairs(d, x, mf, false, fast_resolve_pairs(d, mf.value, active), active);
+    const bool second = active && r.outcome == FAST_MISS && check_rc;
+    if (__ballot(second) != 0) {  // wave-uniform
+        const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
+        const minimizer_t mr = compute_minimizer<1>(x_rc, d.k, d.m, d.hash_magic);
+        const fast_t r2 = fast_probe_regular_pairs(d, x_rc, mr, true, fast_resolve_pairs(d, mr.value, second), second);
+        if (second) {
+            r = r2;
+            r.orientation = -1;
+        }
+    }
+    return r;
+}
+
 template <int W, bool CANON>
 __device__ __forceinline__ fast_t fast_lookup_one(dict_view const& d, kmer_w<W> const& x, bool check_rc) {
     if constexpr (CANON) {
@@ -670,6 +783,30 @@ __device__ __forceinline__ void sk_examine_kmer_entry(sk_query_t<2> const Q, uin
     r.outcome = hit ? int(FAST_HIT) : r.outcome;
 }
 
+/* k <= 31: one LINE of the k-mers' region (device_layout.hpp: a flags word and three 20-byte entries) against one query.
+   `word(i)`: the line's i-th dword, out of LDS or out of registers. */
+template <class Word>
+__device__ __forceinline__ void sk_examine_kmer_line(sk_query_t<1> const Q, uint32_t c, Word word, fast_t& r, sk_bucket_flags& flags) {
+    const uint64_t y = Q.y.w[0], y_rc = Q.y_rc.w[0];
+    const uint32_t meta = word(0);
+    uint32_t go_on = meta & (SK_GO_ON << c);
+    if (c == 0) go_on &= 0u - ((meta >> (SK_FILTER_SHIFT + sk_filter_index(Q.fingerprint))) & 1u);
+    flags.go_on = go_on;
+    flags.second_used = false;
+#pragma unroll
+    for (uint32_t e = 0; e < SK_KMER_ENTRIES_NARROW; ++e) {
+        const uint32_t at = 1 + SK_KMER_ENTRY_WORDS * e;
+        const uint64_t kmer = uint64_t(word(at)) | (uint64_t(word(at + 1)) << 32);
+        const bool valid = ((meta >> e) & 1u) != 0;
+        const bool as_y = valid && kmer == y, as_rc = valid && kmer == y_rc;
+        const bool hit = as_y || as_rc;
+        r.kmer_offset = hit ? (uint64_t(word(at + 2)) | (uint64_t(word(at + 4) & 0xFFu) << 32)) : r.kmer_offset;
+        r.string_id = hit ? word(at + 3) : r.string_id;
+        r.orientation = hit ? ((as_rc != Q.s) ? int8_t(-1) : int8_t(1)) : r.orientation;
+        r.outcome = hit ? int(FAST_HIT) : r.outcome;
+    }
+}
+
 /* where the bucket with (global) index b starts, in bytes from d.sk.slots: the keys' region holds 64 W bytes per bucket; behind it,
    at k <= 63, the k-mers' region holds 64 (two compact entries) */
 template <int W>
@@ -785,7 +922,7 @@ __device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& 
         /* k <= 63: the k-mers' region holds compact entries. (By the bucket's index, not by w.on_kmer_sequence: that stays set when a
            probe comes back to the rest of its key's sequence.) */
         const uint32_t bucket = sk_choice(w.h, w.c);
-        const bool compact = W == 2 && bucket >= d.sk.num_buckets;
+        const bool compact = bucket >= d.sk.num_buckets;
         const uint4* B = reinterpret_cast<const uint4*>(static_cast<char const*>(d.sk.slots) + sk_bucket_offset<W>(d, bucket, compact));
         sk_bucket_flags flags;
         bool marker = false, seen = false;
@@ -793,6 +930,12 @@ __device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& 
             if (compact) {
                 sk_examine_kmer_entry<true>(Q, w.c, [B](uint32_t i) { return B[i]; }, r, flags);
                 sk_examine_kmer_entry<false>(Q, w.c, [B](uint32_t i) { return B[2 + i]; }, r, flags);
+            }
+        } else {
+            if (compact) {
+                const uint4 l0 = B[0], l1 = B[1], l2 = B[2], l3 = B[3];
+                const uint32_t words[16] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
+                sk_examine_kmer_line(Q, w.c, [&words](uint32_t i) { return words[i]; }, r, flags);
             }
         }
         if (!compact) {
@@ -827,11 +970,6 @@ __device__ __forceinline__ uint32_t quad_broadcast(uint32_t v) {
    The pieces move through registers (global_load_dwordx4 + ds_write_b128). Moving them straight into LDS
    (global_load_lds_dwordx4) measured the same speed and miscompiled under hipcc 7.2 -- the repro and the micro-benchmarks
    are kept in tools/debug/ (glds_check, m0_check, vcc_check), the code path is gone. */
-typedef uint32_t sk_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 sk_load_piece(char const* p) {
-    const sk_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const sk_u32x4*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
 
 /* Between two phases of a wave that talk through LDS: everything this lane has issued has completed, and the compiler moves
    no memory operation across. (The "wavefront" fences used elsewhere in this file order the accesses for the compiler and rely on
@@ -900,7 +1038,7 @@ __device__ __forceinline__ void sk_probe_bucket_wave(dict_view const& d, sk_quer
     flags.second_used = false;
     sk_stage_lines<W, MIXED>(d, bucket, 0u, need, wave_stage, kmer_region);
     bool compact = false;
-    if constexpr (W == 2 && MIXED) compact = kmer_region;  // MIXED: lanes on their k-mer's sequence (k <= 63: compact entries) among the others
+    if constexpr (MIXED) compact = kmer_region;  // MIXED: lanes on their k-mer's sequence (compact entries) among the others
     if (need && !compact) {
         sk_examine_slot<W, true>(d, Q, c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
         if constexpr (W == 1) sk_examine_slot<W, false>(d, Q, c, [mine](uint32_t i) { return mine[2 + i]; }, r, key_seen, marker, flags);
@@ -909,6 +1047,12 @@ __device__ __forceinline__ void sk_probe_bucket_wave(dict_view const& d, sk_quer
         if (need && compact) {
             sk_examine_kmer_entry<true>(Q, c, [mine](uint32_t i) { return mine[i]; }, r, flags);
             sk_examine_kmer_entry<false>(Q, c, [mine](uint32_t i) { return mine[2 + i]; }, r, flags);
+        }
+    }
+    if constexpr (W == 1 && MIXED) {
+        if (need && compact) {
+            const uint32_t* words = reinterpret_cast<const uint32_t*>(mine);
+            sk_examine_kmer_line(Q, c, [words](uint32_t i) { return words[i]; }, r, flags);
         }
     }
     if constexpr (W == 2) {
@@ -995,8 +1139,11 @@ __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<
    queue entry written and read back, no second kernel, and above all no placeholder id that a later pass rewrites: an 8-byte
    store into a line that has left the caches costs the DRAM a masked write -- a random access of its own, one of the 2.5 a
    resumed query cost in the resume pass. */
-/* k <= 31 only: at k <= 63 the first pass is bound by its instructions, not by memory, and carrying this loop cost it 6 %
-   (28.3 -> 26.7 G lookups/s, profiles/r03/inwave_ab_k63.txt): there the stragglers keep their own pass. */
+/* (k <= 63: the form further down, behind SSHASH_INWAVE_WIDE. Round 3 measured finishing in the wave there as a loss of 6 % and round
+   4, with ranked fetches everywhere, as a loss of 5.5 % -- profiles/r04/inwave_k63_ab.txt: 27.1 -> 25.6 G lookups/s. The k <= 63 first
+   pass runs at the chip's random-line rate (150.7 M line requests per 1.25 x 10^8 lookups in 3.38 ms = 44.6 G/s, vector ALUs 64 %
+   busy, profiles/r04/bench_c4_pmc_summary.json), and what it needs for that is waves in flight: the loop's state takes the kernel
+   from 60 to 86 registers, eight waves per SIMD to five. There the stragglers keep their own, compacted pass.) */
 __device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<1> const& x, kmer_w<1> const& x_rc, sk_key_t const& kk, sk_walk_t& w,
                                                   sk_query_t<1>& Q, fast_t& r, bool need, uint4* wave_stage) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1021,8 +1168,13 @@ __device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<1> 
             flags.go_on = 0;
             flags.second_used = false;
             bool marker = false, key_seen = false;
-            sk_examine_slot<1, true>(d, Q, w.c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
-            sk_examine_slot<1, false>(d, Q, w.c, [mine](uint32_t i) { return mine[2 + i]; }, r, key_seen, marker, flags);
+            if (sk_choice(w.h, w.c) >= d.sk.num_buckets) {  // a bucket of the k-mers' region: three compact entries
+                const uint32_t* words = reinterpret_cast<const uint32_t*>(mine);
+                sk_examine_kmer_line(Q, w.c, [words](uint32_t i) { return words[i]; }, r, flags);
+            } else {
+                sk_examine_slot<1, true>(d, Q, w.c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
+                sk_examine_slot<1, false>(d, Q, w.c, [mine](uint32_t i) { return mine[2 + i]; }, r, key_seen, marker, flags);
+            }
             const uint32_t go_on = flags.go_on;
             need = sk_walk_step<1>(d, x, x_rc, kk, w, Q, r, go_on, marker);
         }
@@ -1030,22 +1182,83 @@ __device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<1> 
     }
 }
 
+/* The same at k <= 63, where a bucket of the keys' region is two lines (slot 0, slot 1) and a bucket of the k-mers' region one line of
+   two compact entries: a turn fetches ONE line per served lane -- a 64-byte line NUMBER is what it posts (the table stays below
+   2^32 lines = 256 GB) --: slot 0's line of a keys' bucket (and slot 1's line in a turn of its own, if slot 0 says the key's
+   fingerprint is there), or the line of a k-mers' bucket. */
+__device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<2> const& x, kmer_w<2> const& x_rc, sk_key_t const& kk, sk_walk_t& w,
+                                                  sk_query_t<2>& Q, fast_t& r, bool need, uint4* wave_stage) {
+    const uint32_t lane = threadIdx.x & 63u;
+    char const* slots = static_cast<char const*>(d.sk.slots);
+    uint32_t* posted = reinterpret_cast<uint32_t*>(wave_stage + 64);
+    bool second = false;           // this lane's next line is slot 1's of the bucket it is at
+    uint32_t held_go_on = 0;       // what slot 0 of that bucket said, until slot 1 has been examined
+    bool held_marker = false;
+#pragma unroll 1
+    for (;;) {
+        const uint64_t mask = __ballot(need);
+        if (mask == 0) break;  // wave-uniform
+        const uint32_t rank = uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
+        const bool served = need && rank < 16;
+        const uint32_t bucket = sk_choice(w.h, w.c);
+        const bool compact = bucket >= d.sk.num_buckets;
+        if (lane < 16) posted[lane] = 0u;
+        sk_wave_sync();
+        if (served) posted[rank] = compact ? 2 * d.sk.num_buckets + (bucket - d.sk.num_buckets) : 2 * bucket + (second ? 1u : 0u);
+        sk_wave_sync();
+        const uint32_t line = posted[lane >> 2];
+        wave_stage[lane] = sk_load_piece(slots + uint64_t(line) * 64 + 16 * (lane & 3u));
+        sk_wave_sync();
+        if (served) {
+            const uint4* mine = wave_stage + 4 * rank;
+            sk_bucket_flags flags;
+            flags.go_on = held_go_on;
+            flags.second_used = false;
+            bool marker = held_marker, key_seen = false;
+            bool step = true;
+            if (compact) {
+                sk_examine_kmer_entry<true>(Q, w.c, [mine](uint32_t i) { return mine[i]; }, r, flags);
+                sk_examine_kmer_entry<false>(Q, w.c, [mine](uint32_t i) { return mine[2 + i]; }, r, flags);
+            } else if (!second) {
+                sk_examine_slot<2, true>(d, Q, w.c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
+                if (r.outcome == FAST_MISS && flags.second_used) {  // slot 1 holds a key with this fingerprint: its line next
+                    second = true;
+                    held_go_on = flags.go_on;
+                    held_marker = marker;
+                    step = false;
+                }
+            } else {
+                sk_examine_slot<2, false>(d, Q, w.c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
+                second = false;
+            }
+            if (step) {
+                const uint32_t go_on = flags.go_on;
+                need = sk_walk_step<2>(d, x, x_rc, kk, w, Q, r, go_on, marker);
+                held_go_on = 0;
+                held_marker = false;
+            }
+        }
+        sk_wave_sync();  // the staging area is rewritten by the next turn
+    }
+}
+
 /* The whole table lookup of a wave in one call: the first bucket by all lanes (sk_probe_bucket_wave), whatever is left by
    sk_finish_in_wave. Returns FAST_HIT / FAST_MISS (final) / FAST_DEFER; same arguments as sk_first_pass_wave. */
-__device__ __forceinline__ fast_t sk_lookup_in_wave(dict_view const& d, kmer_w<1> const& x, bool active, bool allow_rc, int8_t miss_orientation,
+template <int W>
+__device__ __forceinline__ fast_t sk_lookup_in_wave(dict_view const& d, kmer_w<W> const& x, bool active, bool allow_rc, int8_t miss_orientation,
                                                     uint4* wave_stage) {
-    const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
-    const sk_key_t kk = sk_key<1>(x, x_rc, d.k, d.m);
+    const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
+    const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
     const bool usable = active && sk_usable(d, kk);
     sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), 0);
-    sk_query_t<1> Q = sk_make_query<1>(x, x_rc, kk, w.h.fingerprint);
+    sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, w.h.fingerprint);
     fast_t r = fast_unsettled(active && !usable);
     uint32_t go_on = 0;
     bool marker = false, key_seen = false;
-    sk_probe_bucket_wave<1>(d, Q, usable ? w.h.bucket[0] : 0u, 0u, usable, wave_stage, r, key_seen, marker, go_on);
+    sk_probe_bucket_wave<W>(d, Q, usable ? w.h.bucket[0] : 0u, 0u, usable, wave_stage, r, key_seen, marker, go_on);
     sk_wave_sync();
     bool need = false;
-    if (usable) need = sk_walk_step<1>(d, x, x_rc, kk, w, Q, r, go_on, marker);
+    if (usable) need = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
     sk_finish_in_wave(d, x, x_rc, kk, w, Q, r, need, wave_stage);
     if (usable && (r.outcome == FAST_MISS || (r.outcome == FAST_HIT && r.orientation < 0 && !allow_rc))) {
         r = fast_unsettled(false);

@@ -375,8 +375,10 @@ fastq_pieces::parsed fastq_pieces::parse(uint64_t i, uint32_t k, char* bases, ui
         bool starved = false;
         /* index of the '\n' ending the line that starts at p; n when the file ends first (or the buffer: then `starved`) */
         auto line_end = [&](uint64_t p) -> uint64_t {
-            void const* nl = p < n ? memchr(B + p, '\n', size_t(n - p)) : nullptr;
-            if (nl) return uint64_t(static_cast<char const*>(nl) - B);
+            if (p < n) {
+                const size_t room = size_t(n - p) & (~size_t(0) >> 1);  // (n - p > 0; the mask only tells gcc that it is no huge number)
+                if (void const* nl = memchr(B + p, '\n', room)) return uint64_t(static_cast<char const*>(nl) - B);
+            }
             if (!whole) starved = true;
             return n;
         };

@@ -1,6 +1,9 @@
 // replica.hpp -- one dictionary replica resident in the HBM of one device (internal header).
 #pragma once
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <hip/hip_runtime.h>
 
 #include <mutex>
@@ -42,6 +45,7 @@ struct host_lane {
 struct device_replica {
     int device = -1;
     uint64_t bytes = 0;
+    uint64_t bytes_still_to_come = 0;  // during the upload: what follows the super-k-mer table (its budget test counts it in)
     dict_view view{};
     skew_part_dev* d_skew = nullptr;
     uint64_t directory_overflowed = 0;  // sectors carrying the overflow flag
@@ -67,6 +71,10 @@ struct device_replica {
         if (hipMemPoolCreate(&scratch_pool, &props) != hipSuccess) {
             scratch_pool = nullptr;  // (fall back to the default pool with its default behaviour)
             (void)hipGetLastError();
+            /* not silently: the default pool hands its memory back at every synchronisation -- 190-260 ms instead of 13 per batched
+               streaming call */
+            if (std::getenv("SSHASH_AMD_VERBOSE"))
+                fprintf(stderr, "[sshash_amd] device %d: no private memory pool (hipMemPoolCreate failed): stream-ordered scratch comes out of the default pool\n", device);
             return;
         }
         uint64_t keep = ~uint64_t(0);

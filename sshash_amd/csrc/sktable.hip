@@ -227,6 +227,39 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
             placed[t] = 1;
         } else {
             const sk_hash_t h = sk_hash(item_keys[t], num_buckets);
+            if constexpr (COMPACT && W == 1) {
+                /* k <= 31, the heavy keys' k-mers: a bucket is one line of three 20-byte entries behind a flags word
+                   (device_layout.hpp: SK_KMER_ENTRIES_NARROW; lookup_device.hpp: sk_examine_kmer_line) */
+                uint32_t* B = slots + 16 * uint64_t(h.bucket[choice]);
+                uint32_t mine = SK_KMER_ENTRIES_NARROW;
+                uint32_t cur = __hip_atomic_load(B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (;;) {
+                    const uint32_t in_use = cur & ((1u << SK_KMER_ENTRIES_NARROW) - 1u);
+                    if (in_use == (1u << SK_KMER_ENTRIES_NARROW) - 1u) break;  // full
+                    const uint32_t e = uint32_t(__ffs(int(~in_use))) - 1u;
+                    const uint32_t seen = atomicCAS(B, cur, cur | (1u << e));
+                    if (seen == cur) {
+                        mine = e;
+                        break;
+                    }
+                    cur = seen;
+                }
+                if (mine == SK_KMER_ENTRIES_NARROW) {
+                    atomicOr(B, (SK_GO_ON << choice) | (choice == 0 ? 1u << (SK_FILTER_SHIFT + sk_filter_index(h.fingerprint)) : 0u));
+                    unplaced = choice + 1 == SK_CHOICES;
+                } else {
+                    placed[t] = 1;
+                    used = true;
+                    const uint64_t start = ((item_vals[t] & SK_VAL_MASK) >> 1) + (item_vals[t] >> SK_LEN_SHIFT) - (d.k - d.m);
+                    const window_t<1> w = read_window<1>(d.granules, start, d.k);
+                    uint32_t* E = B + 1 + SK_KMER_ENTRY_WORDS * mine;
+                    E[0] = uint32_t(w.kmer.w[0]);
+                    E[1] = uint32_t(w.kmer.w[0] >> 32);
+                    E[2] = uint32_t(start);
+                    E[3] = w.string_id;
+                    E[4] = uint32_t(start >> 32) & 0xFFu;
+                }
+            } else {
             /* COMPACT (k <= 63, the heavy keys' k-mers): 32-byte entries, two to a 64-byte bucket -- meta, string id, position of the
                K-MER | fingerprint, the k-mer itself (lookup_device.hpp: sk_examine_kmer_entry) */
             constexpr uint32_t SLOT_WORDS = COMPACT ? 8u : 8u * W;
@@ -291,6 +324,7 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
                 reinterpret_cast<uint64_t*>(S)[1] = w1;
                 for (int i = 0; i < (COMPACT ? W : 2 * W); ++i) reinterpret_cast<uint64_t*>(S)[2 + i] = body[i];
                 if (meta) atomicOr(S, meta);
+            }
             }
         }
     }
@@ -485,11 +519,13 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     }
     const uint64_t wanted = (T - heavy_occurrences) + heavy_keys + heavy_kmers;
     const uint64_t key_buckets = uint64_t(double(wanted - heavy_kmers) * slots_per_key / SK_BUCKET_SLOTS) + 8;
-    const uint64_t kmer_buckets = heavy_kmers ? uint64_t(double(heavy_kmers) * slots_per_kmer / SK_BUCKET_SLOTS) + 8 : 0;
+    /* a bucket of the k-mers' region is one 64-byte line: two 32-byte entries at k <= 63, three 20-byte ones at k <= 31 (the k-mer
+       itself instead of its super-k-mer's bases) */
+    const uint64_t kmer_entries = wide ? SK_BUCKET_SLOTS : SK_KMER_ENTRIES_NARROW;
+    const uint64_t kmer_buckets = heavy_kmers ? uint64_t(double(heavy_kmers) * slots_per_kmer / double(kmer_entries)) + 8 : 0;
     const uint64_t num_buckets = key_buckets + kmer_buckets;
     const uint64_t slot_bytes = wide ? 64 : 32;
-    /* k <= 63: an entry of the k-mers' region is 32 bytes (the k-mer itself instead of its super-k-mer's 128 bases) */
-    const uint64_t table_bytes = key_buckets * SK_BUCKET_SLOTS * slot_bytes + kmer_buckets * SK_BUCKET_SLOTS * 32;
+    const uint64_t table_bytes = key_buckets * SK_BUCKET_SLOTS * slot_bytes + kmer_buckets * 64;
     if (num_buckets >= (uint64_t(1) << 32)) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);
     {
         size_t free_bytes = 0, total_bytes = 0;
@@ -498,7 +534,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
         /* SSHASH_AMD_HBM_BUDGET (bytes): what ONE replica may hold -- how a deployment keeps room for several dictionaries,
            and how the tests make a dictionary "larger than the HBM" on a box whose HBM it would fit many times over */
         const uint64_t budget = hbm_budget();
-        if (budget && rep.bytes + table_bytes > budget) return absent(rep, SK_ABSENT_NO_MEMORY);
+        if (budget && rep.bytes + rep.bytes_still_to_come + table_bytes > budget) return absent(rep, SK_ABSENT_NO_MEMORY);
     }
     uint32_t* slots = tmp.alloc<uint32_t>(table_bytes / 4);
     if (const char* e = std::getenv("SSHASH_AMD_VERBOSE"); e && e[0] == '1')
@@ -525,7 +561,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
         } else {
             hipLaunchKernelGGL(sk_place_kernel<1>, g1, block, 0, 0, v, choice, T, keys_sorted, occ, flags, slots, uint32_t(key_buckets), placed, stats, lo, hi);
             if (heavy_kmers && with_heavy_kmers)
-                hipLaunchKernelGGL(sk_place_kernel<1>, g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, kmer_slots,
+                hipLaunchKernelGGL((sk_place_kernel<1, true>), g2, block, 0, 0, v, choice, heavy_kmers, kmer_keys, kmer_vals, (const uint8_t*)nullptr, kmer_slots,
                                    uint32_t(kmer_buckets), placed + T, stats, 0u, 63u);
         }
         HIP_CHECK(hipGetLastError());

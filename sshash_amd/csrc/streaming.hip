@@ -144,59 +144,50 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
                 starts = ((c_marks >> rel) & 1u) != 0;
             }
         };
+        /* (Round 4 tried to let every lane run ahead on its own -- consume bases while they extend a run, meet the other lanes only
+           at a seed: 34.9 -> 16.8 G k-mers/s on the high-hit set, 80.9 -> 60.4 on random reads, profiles/r04/
+           streaming_advance_seed_phases_ab.txt. A phase lasts as long as its LONGEST run (the maximum of 64 geometric run lengths is
+           four times their mean), and in these read sets 40 % of the lanes want a seed at any base anyway -- the k-mers over a
+           substitution or a string junction are negative seeds, 31 in a row: the base-by-base lockstep below is the better schedule.) */
         uint64_t eight = 0;  // the read's characters, eight per load (a byte load per base is a round trip per base)
-        /* Two phases, in turn, until the read is used up (round 4). ADVANCE: the lane consumes bases for as long as it needs no
-           memory -- k-mers that are invalid, or that extend the run it is in -- on its own, however far that takes it. SEED: the
-           first k-mer that does neither is looked up (election, table probe, or the complete path). A wave's lanes then meet at
-           their seeds: the dependent line fetch of a seed is one round trip for all the lanes that need one, and the lanes that
-           are extending do not sit through it once per base. (Rounds 2-3 walked the wave base by base: with 64 reads in step
-           nearly every step held some lane's seed -- 1 - (21/22)^64 = 95 % of the steps of a high-hit read set, one search per
-           21 extensions -- so every k-mer cost the wave an election and a round trip, although one lane in twenty needed them.) */
-        uint64_t j = 0;
-        for (;;) {
-            bool pending = false;  // the k-mer ending at base j - 1 is valid and does not extend the run
-            while (j < len && !pending) {
-                if ((j & 7u) == 0) {
-                    if (j + 8 <= len) {
-                        __builtin_memcpy(&eight, p + j, 8);
-                    } else {
-                        eight = 0;
-                        for (uint64_t b = j; b < len; ++b) eight |= uint64_t(uint8_t(p[b])) << (8 * (b - j));
-                    }
+        for (uint64_t j = 0; j < len; ++j) {
+            if ((j & 7u) == 0) {
+                if (j + 8 <= len) {
+                    __builtin_memcpy(&eight, p + j, 8);
+                } else {
+                    eight = 0;
+                    for (uint64_t b = j; b < len; ++b) eight |= uint64_t(uint8_t(p[b])) << (8 * (b - j));
                 }
-                const char c = char(eight >> (8 * (j & 7u)));
-                const uint64_t code = base_code(c);
-                x = kmer_roll<W>(x, code, k);
-                x_rc = kmer_roll_rc<W>(x_rc, code, k);
-                valid_len = base_is_valid(c) ? valid_len + 1 : 0;
-                ++j;
-                if (j < k) continue;
-                if (valid_len < k) {  // :59-65 -- invalid k-mer resets the whole state
-                    ++c_invalid;
-                    in_run = false;
-                    neg_unknown_mini = false;
+            }
+            const char c = char(eight >> (8 * (j & 7u)));
+            const uint64_t code = base_code(c);
+            x = kmer_roll<W>(x, code, k);
+            x_rc = kmer_roll_rc<W>(x_rc, code, k);
+            valid_len = base_is_valid(c) ? valid_len + 1 : 0;
+            if (j + 1 < k) continue;
+            if (valid_len < k) {  // :59-65 -- invalid k-mer resets the whole state
+                ++c_invalid;
+                in_run = false;
+                neg_unknown_mini = false;
+                continue;
+            }
+            if (in_run && !(ori < 0 && off == 0)) {  // :86-100
+                /* the string's next k-mer in the direction of the run: forward it gains the base at off + k, and leaves
+                   its string iff a string starts there; backward it gains the base at off - 1, and leaves its string iff
+                   a string starts at off (read_window's `crosses` for a window whose neighbour did not cross) */
+                const uint64_t next = ori > 0 ? off + 1 : off - 1;
+                uint32_t base, unused;
+                bool boundary;
+                string_base(ori > 0 ? off + k : off - 1, base, boundary);
+                if (ori < 0) string_base(off, unused, boundary);  // (the mark that matters is the one at off)
+                const kmer_w<W> t = ori > 0 ? kmer_roll<W>(at, base, k) : kmer_roll_rc<W>(at, base ^ 2u, k);
+                if (!boundary && (kmer_eq<W>(t, x) || kmer_eq<W>(t, x_rc))) {
+                    ++c_extensions;
+                    off = next;
+                    at = t;
                     continue;
                 }
-                if (in_run && !(ori < 0 && off == 0)) {  // :86-100
-                    /* the string's next k-mer in the direction of the run: forward it gains the base at off + k, and leaves
-                       its string iff a string starts there; backward it gains the base at off - 1, and leaves its string iff
-                       a string starts at off (read_window's `crosses` for a window whose neighbour did not cross) */
-                    const uint64_t next = ori > 0 ? off + 1 : off - 1;
-                    uint32_t base, unused;
-                    bool boundary;
-                    string_base(ori > 0 ? off + k : off - 1, base, boundary);
-                    if (ori < 0) string_base(off, unused, boundary);  // (the mark that matters is the one at off)
-                    const kmer_w<W> t = ori > 0 ? kmer_roll<W>(at, base, k) : kmer_roll_rc<W>(at, base ^ 2u, k);
-                    if (!boundary && (kmer_eq<W>(t, x) || kmer_eq<W>(t, x_rc))) {
-                        ++c_extensions;
-                        off = next;
-                        at = t;
-                        continue;
-                    }
-                }
-                pending = true;
             }
-            if (!pending) break;  // the read is used up
             /* seed() */
             if constexpr (SK) {
                 const sk_key_t kk = sk_key<W>(x, x_rc, k, d.m);

@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
             if (regular && (expect != in.file_bytes() || read != whole.num_reads()))
                 return printf("pieces of %llu bytes: chain complete but %llu of %llu reads, stopped at %llu of %llu\n", (unsigned long long)piece,
                               (unsigned long long)read, (unsigned long long)whole.num_reads(), (unsigned long long)expect, (unsigned long long)in.file_bytes()), 1;
-            printf("pieces %llu %s\n", (unsigned long long)piece, regular ? "regular" : "irregular");
+            fprintf(stderr, "pieces %llu %s\n", (unsigned long long)piece, regular ? "regular" : "irregular");
         }
     }
     uint64_t h = 1469598103934665603ull;  // FNV-1a over the bases and the read boundaries: equal files give equal lines

@@ -183,8 +183,11 @@ def test_query_file_readers_hand_over_bounded_batches(tmp_path):
     blob = bgzf_compress(raw, 1) + BGZF_EOF
     packed.write_bytes(blob)
     assert gzip.open(packed, "rb").read() == raw  # what any gzip reader makes of it
-    want = subprocess.run([exe, str(plain), "0", "31"], capture_output=True, text=True, timeout=300).stdout
+    whole = subprocess.run([exe, str(plain), "0", "31"], capture_output=True, text=True, timeout=300)
+    want = whole.stdout
     assert want.startswith("OK 120000 ")
+    # (an uncompressed FASTQ also went through the piecewise reader, five piece sizes: the same reads, every chain of pieces complete)
+    assert whole.stderr.count(" regular") == 5 and "irregular" not in whole.stderr, whole.stderr
     for threads in ("1", "7"):
         got = subprocess.run([exe, str(packed), "0", "31"], capture_output=True, text=True, timeout=300, env=dict(os.environ, SSHASH_AMD_READER_THREADS=threads))
         assert got.returncode == 0 and got.stdout == want, (threads, got.stdout, got.stderr)
@@ -220,6 +223,23 @@ def test_query_file_readers_hand_over_bounded_batches(tmp_path):
     liar.write_bytes(bytes(lie) + BGZF_EOF)
     got = subprocess.run([exe, str(liar), "0", "31"], capture_output=True, text=True, timeout=60)
     assert got.returncode != 0 and "BGZF" in got.stderr, (got.stdout, got.stderr)
+    # the piecewise reader on files that are not plain four-line records: qualities beginning with '@', CR LF, a last record cut short --
+    # same reads as the sequential reader --, and five lines per record: flagged irregular (the library then reads sequentially)
+    lines = record.split(b"\n")
+    recs = [lines[i:i + 4] for i in range(0, 4000, 4)]
+    variants = {"at": b"".join(b"\n".join([h, b, p, b"@" + q[1:]]) + b"\n" for h, b, p, q in recs),
+                "crlf": b"".join(b"\r\n".join(r) + b"\r\n" for r in recs),
+                "short": b"\n".join(b"\n".join(r) for r in recs)[:-80],
+                "five": b"".join(b"\n".join([h, b[:40], b[40:], p, q]) + b"\n" for h, b, p, q in recs)}
+    for name, blob in variants.items():
+        f = tmp_path / f"{name}.fastq"
+        f.write_bytes(blob)
+        got = subprocess.run([exe, str(f), "0", "31"], capture_output=True, text=True, timeout=300)
+        assert got.returncode == 0 and got.stdout.startswith("OK "), (name, got.stdout, got.stderr)
+        if name == "five":
+            assert "irregular" in got.stderr
+        else:
+            assert got.stderr.count(" regular") == 5 and "irregular" not in got.stderr, (name, got.stderr)
     txt = tmp_path / "reads.txt"
     txt.write_text("ACGT\n")
     p = subprocess.run([exe, str(txt), "0", "31"], capture_output=True, text=True, timeout=60)

@@ -16,10 +16,16 @@ what was tried: ANY 64-bit-typed VALU instruction with a 32-bit source in the la
 
 What this does: reads the device assembly of one translation unit (hipcc --cuda-device-only -S), finds every kernel that (1) uses
 the last register of its allocation and (2) names it as a 32-bit operand of an instruction whose mnemonic carries a 64-bit type, and
-gives such a kernel eight more registers (.amdhsa_next_free_vgpr, .amdhsa_accum_offset, .vgpr_count): the code is untouched, the
-register it names is no longer the last one. Writes the assembly back out and a JSON report; csrc/Makefile assembles what comes out.
+repairs it without touching what the kernel computes:
+  rename  the aligned block of 2, 4 or 8 registers that ends the allocation swaps NAMES with another block, throughout the kernel --
+          the same program (the experiment that found the hazard: profiles/r04/member_race_3_*.txt) --, chosen so that every register
+          tuple of the kernel stays contiguous and aligned, the workitem id stays in v0, and the register that ends up last is not
+          such an operand. Nothing is lost: same allocation, same occupancy;
+  pad     where no such block exists (or the kernel indexes registers through M0): eight more registers (.amdhsa_next_free_vgpr,
+          .amdhsa_accum_offset, .vgpr_count) -- the register named is no longer the last one; one wave per SIMD less may fit.
+Writes the assembly back out and a JSON report; csrc/Makefile assembles what comes out.
 
-    python3 tools/isa_guard.py in.s out.s [--report report.json] [--check]     (--check: exit 1 if anything had to be changed)
+    python3 tools/isa_guard.py in.s out.s [--report report.json] [--check] [--pad-only]     (--check: exit 1 if anything had to be changed)
 """
 import json
 import re
@@ -80,6 +86,66 @@ def hazards(lines, k):
     return alloc, found
 
 
+TUPLE = re.compile(r"\bv\[(\d+):(\d+)\]")
+SINGLE = re.compile(r"\bv(\d+)\b")
+
+
+def body_code(lines, k):
+    """(index, code) of the instruction lines of a kernel's body"""
+    for i in range(k["body"][0], k["body"][1]):
+        l = lines[i]
+        if l.lstrip().startswith(";;"):
+            continue
+        code = l.split(";")[0]
+        c = code.strip()
+        if c and not c.startswith(".") and not c.endswith(":"):
+            yield i, code
+
+
+def try_rename(lines, k, alloc):
+    """-> (new lines of the body as {index: text}, description) or None"""
+    last = alloc - 1
+    code = list(body_code(lines, k))
+    text = "\n".join(c for _, c in code)
+    if re.search(r"\bv_movrel|\bs_set_gpr_idx", text):
+        return None  # registers addressed through M0: names are not all there is
+    tuples = {(int(a), int(b)) for a, b in TUPLE.findall(text)}
+    ids = 1
+    for i in range(k["desc"], k["desc"] + 64):
+        m = re.match(r"\s*\.amdhsa_system_vgpr_workitem_id\s+(\d+)", lines[i])
+        if m:
+            ids = int(m.group(1)) + 1
+        if ".end_amdhsa_kernel" in lines[i]:
+            break
+
+    def block_ok(base, size):
+        return all(b < base or a >= base + size or (a >= base and b < base + size) for a, b in tuples)
+
+    for size in (2, 4, 8):
+        high = last // size * size
+        if not block_ok(high, size):
+            continue
+        for low in range(high - size, -1, -size):
+            if low < ids or not block_ok(low, size):
+                continue
+            delta = high - low
+
+            def swap(n):
+                return n - delta if high <= n < high + size else n + delta if low <= n < low + size else n
+
+            def rename(c):
+                c = TUPLE.sub(lambda m: "v[%d:%d]" % (swap(int(m.group(1))), swap(int(m.group(2)))), c)
+                return SINGLE.sub(lambda m: "v%d" % swap(int(m.group(1))), c)
+
+            new = {i: rename(c) for i, c in code}
+            trial = list(lines)
+            for i, c in new.items():
+                trial[i] = c
+            if not hazards(trial, k)[1]:
+                return new, "v[%d:%d] <-> v[%d:%d]" % (high, high + size - 1, low, low + size - 1)
+    return None
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     src, dst = args[0], args[1]
@@ -87,7 +153,7 @@ def main():
     if report_path in args:
         args.remove(report_path)
     lines = open(src).read().split("\n")
-    report = {"source": src, "kernels": 0, "use_their_last_register": 0, "padded": []}
+    report = {"source": src, "kernels": 0, "use_their_last_register": 0, "renamed": [], "padded": []}
     bumped = {}
     for k in kernels_of(lines):
         report["kernels"] += 1
@@ -97,6 +163,12 @@ def main():
         if k["next_free_vgpr"] == alloc:
             report["use_their_last_register"] += 1
         if not found:
+            continue
+        renamed = None if "--pad-only" in sys.argv else try_rename(lines, k, alloc)
+        if renamed:
+            for i, c in renamed[0].items():
+                lines[i] = c
+            report["renamed"].append({"kernel": k["name"], "allocation": alloc, "registers": renamed[1], "instructions": found[:8], "count": len(found)})
             continue
         new = alloc + GRANULE
         lines[k["vgpr_line"]] = re.sub(r"\d+\s*$", str(new), lines[k["vgpr_line"]])
@@ -116,10 +188,11 @@ def main():
     open(dst, "w").write("\n".join(lines))
     if report_path:
         json.dump(report, open(report_path, "w"), indent=1)
-    print("[isa_guard] %s: %d kernels, %d use the last register of their allocation, %d padded%s" % (
-        src, report["kernels"], report["use_their_last_register"], len(report["padded"]),
+    print("[isa_guard] %s: %d kernels, %d use the last register of their allocation, %d renamed, %d padded%s%s" % (
+        src, report["kernels"], report["use_their_last_register"], len(report["renamed"]), len(report["padded"]),
+        "".join("\n  " + p["kernel"][:100] + " %s: %s" % (p["registers"], p["instructions"][0]["instruction"]) for p in report["renamed"]),
         "".join("\n  " + p["kernel"][:100] + " %d -> %d: %s" % (p["allocation"], p["now"], p["instructions"][0]["instruction"]) for p in report["padded"])), file=sys.stderr)
-    if "--check" in sys.argv and report["padded"]:
+    if "--check" in sys.argv and (report["padded"] or report["renamed"]):
         sys.exit(1)
 
 
