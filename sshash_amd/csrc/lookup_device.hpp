@@ -436,7 +436,9 @@ __device__ __forceinline__ resolve_t fast_resolve(dict_view const& d, uint64_t m
         r.settled = !a.overflow;
     } else {
         const uint64_t id = mphf_eval(d.minimizers, city128_u64(minimizer, d.minimizers.seed));
-        const uint64_t entry = d.cw_packed ? packed_get(d.codewords, id, d.cw_width) : d.codewords[id];
+        /* the codeword is not read again before a few hundred million others have passed -- nontemporal, so that it does not push the
+           pilots (137 MB on C3, read by every probe) out of the caches */
+        const uint64_t entry = d.cw_packed ? packed_get(d.codewords, id, d.cw_width) : __builtin_nontemporal_load(d.codewords + id);
         r.code = entry & low_mask(d.cw_width);
         r.present = d.cw_packed || (entry >> d.cw_width) == minimizer_fingerprint(minimizer, d.m, d.canonical != 0, d.cw_width);
         r.settled = true;

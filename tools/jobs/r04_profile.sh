@@ -57,4 +57,5 @@ print(json.dumps(stats, indent=1))
 for k, d in summary.items():
     print(k, {c: round(v) for c, v in sorted(d.items())})
 PY
+rm -rf $OUT/trace $OUT/pmc     # (tens of megabytes of per-dispatch rows: what is kept is summary.json, kernel_stats.csv, bench.jsonl)
 tail -1 $OUT/bench.jsonl | cut -c1-300
