@@ -144,11 +144,19 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
                 starts = ((c_marks >> rel) & 1u) != 0;
             }
         };
-        /* (Round 4 tried to let every lane run ahead on its own -- consume bases while they extend a run, meet the other lanes only
-           at a seed: 34.9 -> 16.8 G k-mers/s on the high-hit set, 80.9 -> 60.4 on random reads, profiles/r04/
-           streaming_advance_seed_phases_ab.txt. A phase lasts as long as its LONGEST run (the maximum of 64 geometric run lengths is
-           four times their mean), and in these read sets 40 % of the lanes want a seed at any base anyway -- the k-mers over a
-           substitution or a string junction are negative seeds, 31 in a row: the base-by-base lockstep below is the better schedule.) */
+        /* The lanes of a wave walk their reads base by base, in step, and a step costs the wave every path SOME lane takes: 478 vector and
+           336 scalar instructions per base and wave, the vector ALUs 83 % busy -- this kernel is bound by instruction issue (0.25 HBM lines per
+           k-mer: a third of the line rate; profiles/r04/streaming_kernel_stats_and_pmc_lockstep_kernel.txt). Two other schedules were
+           built and measured in round 4, both correct, both slower, because a wave lasts as long as its slowest lane:
+             * every lane runs ahead on its own while its k-mers extend a run and the lanes meet only at their seeds: 34.9 -> 16.8 G k-mers/s
+               on a high-hit set, 80.9 -> 60.4 on random reads (profiles/r04/streaming_advance_seed_phases_ab.txt) -- a phase lasts as long
+               as its LONGEST run (the maximum of 64 geometric run lengths is four times their mean), and 40 % of the lanes want a seed at
+               any base anyway: the k-mers over a substitution or a string junction are negative seeds, k in a row;
+             * a seed that needs more than its key's first bucket (one in twenty) waits, and the wave serves its waiting lanes one more bucket
+               every second / fourth / eighth step, so that the instructions of sk_probe's inner loop run at a fraction of the steps instead of
+               86 % of them: 44.0 -> 35.7 / 31.7 / 26.1 (streaming_waiting_seeds_ab.txt) -- the waiting lanes finish their reads later, and the
+               wave with them.
+           What helped this kernel in round 4 is what made the table's key cheaper (device_layout.hpp: 2.5 instructions per candidate). */
         uint64_t eight = 0;  // the read's characters, eight per load (a byte load per base is a round trip per base)
         for (uint64_t j = 0; j < len; ++j) {
             if ((j & 7u) == 0) {
