@@ -1114,6 +1114,53 @@ __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<
     uint32_t go_on = 0;
     bool marker = false, key_seen = false;
     sk_probe_bucket_wave<W>(d, Q, usable ? h.bucket[0] : 0u, 0u, usable, wave_stage, r, key_seen, marker, go_on);
+    if constexpr (W == 2) {
+        /* k <= 63, the heavy keys (a tenth of C4's k-mers): the k-mer's OWN first bucket, fetched in the wave (round 4). At k <= 63 the
+           stragglers keep their compacted pass -- finishing every probe in the wave costs the registers of the whole walk and with them
+           three waves per SIMD, -5.5 % --, but two thirds of the stragglers are lanes that met their key's marker, and what those need
+           next is one line of two compact entries under a key that takes three registers to make: the k-mer's key, the first bucket of
+           its sequence, its fingerprint. So that one hop is made here, with ranked fetches (as for slot 1's line), and only what is still
+           open behind it -- the k-mer's first choice was full, or the marker was another key's with an equal fingerprint and the key's own
+           sequence goes on -- joins the resume queue: fewer entries, fewer masked id rewrites. */
+        bool hop = usable && r.outcome == FAST_MISS && marker;
+        if (__ballot(hop) != 0) {  // wave-uniform
+            const sk_hash_t hk = sk_hash_kmer_region(sk_kmer_key<W>(x, x_rc), d.sk.num_buckets, d.sk.kmer_buckets);  // (bucket[0] and the fingerprint: the rest is not computed)
+            sk_query_t<W> Qk = Q;
+            Qk.fingerprint = hk.fingerprint;
+            const uint32_t lane = threadIdx.x & 63u;
+            uint32_t* posted = reinterpret_cast<uint32_t*>(wave_stage + 64);
+            char const* slots = static_cast<char const*>(d.sk.slots);
+            uint32_t kmer_go_on = 0;
+            bool pending = hop;
+#pragma unroll 1
+            for (;;) {
+                sk_wave_sync();
+                const uint64_t mask = __ballot(pending);
+                if (mask == 0) break;  // wave-uniform
+                const uint32_t rank = uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
+                const bool served = pending && rank < 16;
+                if (lane < 16) posted[lane] = 0u;
+                sk_wave_sync();
+                if (served) posted[rank] = 2 * d.sk.num_buckets + (hk.bucket[0] - d.sk.num_buckets);  // a 64-byte line NUMBER: the keys' region is two lines a bucket
+                sk_wave_sync();
+                const uint32_t line = posted[lane >> 2];
+                wave_stage[lane] = sk_load_piece(slots + uint64_t(line) * 64 + 16 * (lane & 3u));
+                sk_wave_sync();
+                if (served) {
+                    const uint4* mine = wave_stage + 4 * rank;
+                    sk_bucket_flags flags;
+                    sk_examine_kmer_entry<true>(Qk, 0u, [mine](uint32_t i) { return mine[i]; }, r, flags);
+                    sk_examine_kmer_entry<false>(Qk, 0u, [mine](uint32_t i) { return mine[2 + i]; }, r, flags);
+                    kmer_go_on = flags.go_on;
+                    pending = false;
+                }
+            }
+            if (hop && r.outcome == FAST_MISS && kmer_go_on == 0) {
+                /* the k-mer is not under its own key (sk_walk_step): what is left is the rest of the key's sequence, if it goes on */
+                marker = false;
+            }
+        }
+    }
     if (usable) {
         if (r.outcome == FAST_MISS) {
             if (marker) {
