@@ -453,7 +453,7 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
                    const result_view out, uint8_t* __restrict__ member, const pass_queues q,
                    const uint8_t* __restrict__ lane_valid /* null, or bit 0 of entry i: place i holds a query */) {
     /* LDS: the ASCII tile (256 * k characters) and, afterwards, the staged bucket lines (64 * W bytes per lane) */
-    constexpr uint32_t TILE_WORDS = ASCII ? 64 * (W == 1 ? 31 : 63) + 8 : 0;
+    constexpr uint32_t TILE_WORDS = ASCII ? 64 * (W == 1 ? 31 : 63) + 24 : 0;  // (+ slack: the packing reads whole groups of 16 characters)
     constexpr uint32_t STAGE_WORDS = SK ? 256 * 16 : 0;
     __shared__ uint4 lds[(TILE_WORDS > STAGE_WORDS ? TILE_WORDS : STAGE_WORDS) / 4 + 1];
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -481,16 +481,30 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
         }
         __syncthreads();
         if (active) {
+            /* sixteen characters -> one 32-bit word of 2-bit codes: four characters at a time are cut out of the tile (alignbyte), turned into
+               four 2-bit codes in four bytes ((c >> 1) & 3) and gathered into one byte by a multiplication (the four partial products
+               b0 << 24, b1 << 26, b2 << 28, b3 << 30 do not overlap); 19 instructions per 16 characters (rounds 1-3: 80). What lies
+               beyond the k-th character (the next query's, or the tile's slack) is cut off at the end. */
             const uint32_t start = threadIdx.x * d.k, w0 = start >> 2, sh = start & 3;
-            for (uint32_t j = 0; 4 * j < d.k; ++j) {
-                const uint32_t four = __builtin_amdgcn_alignbyte(tile[w0 + j + 1], tile[w0 + j], sh);
-                uint32_t c = (four >> 1) & 0x03030303u;  // (c >> 1) & 3 for four characters at once
-                c = (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xFFu;
-                const uint32_t rem = d.k - 4 * j;
-                if (rem < 4) c &= (1u << (2 * rem)) - 1;
-                if (8 * j < 64) x.w[0] |= uint64_t(c) << (8 * j);
-                else if constexpr (W == 2) x.w[1] |= uint64_t(c) << (8 * j - 64);
+            uint32_t acc[2 * W];
+#pragma unroll
+            for (int t = 0; t < 2 * W; ++t) {
+                acc[t] = 0;
+                if (16u * uint32_t(t) < d.k) {  // uniform
+                    uint32_t prev = tile[w0 + 4 * t];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t next = tile[w0 + 4 * t + j + 1];
+                        const uint32_t four = __builtin_amdgcn_alignbyte(next, prev, sh);
+                        prev = next;
+                        const uint32_t c = (((four >> 1) & 0x03030303u) * 0x01041040u) >> 24;
+                        acc[t] |= c << (8 * j);
+                    }
+                }
             }
+            x.w[0] = uint64_t(acc[0]) | (uint64_t(acc[1]) << 32);
+            if constexpr (W == 2) x.w[1] = uint64_t(acc[2]) | (uint64_t(acc[3]) << 32);
+            x = kmer_take_chars<W>(x, d.k);
         }
         if constexpr (SK) __syncthreads();  // the tile's LDS is reused for the bucket lines
     } else {

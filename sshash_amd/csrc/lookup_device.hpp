@@ -1160,6 +1160,10 @@ __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<
                 marker = false;
             }
         }
+        /* (The other third of the stragglers -- the key's first bucket was full when the key was placed -- given one look at slot 0 of the
+           key's second choice in the wave as well: measured in round 4 and not kept, 31.35 / 31.34 / 31.26 against 31.35 / 31.34 / 31.30 /
+           31.34 G lookups/s, profiles/r04/second_choice_in_wave_k63_ab.txt: a 128-base slot comparison for the whole wave costs what the
+           smaller resume pass gives back.) */
     }
     if (usable) {
         if (r.outcome == FAST_MISS) {
