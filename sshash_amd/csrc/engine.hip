@@ -447,8 +447,11 @@ __device__ __forceinline__ kmer_w<W> load_query(const void* __restrict__ queries
    cannot settle are appended to `queue` (their index in the batch). SK: through the super-k-mer table
    (device_layout.hpp (5)) instead of directory + atoms; the four lanes of a quad fetch each other's buckets
    together, through LDS (sk_probe_wave), so no lane leaves before the probe. */
+/* (k <= 63 through the table: eight waves per SIMD asked for -- the pass runs at the random-line rate and wants the waves; the compiler fits
+   its 66 registers into 64 without scratch: 31.8 -> 32.2 G lookups/s on C4, profiles/r04/eight_waves_ab.txt. The k <= 31 kernel needs 67, spills
+   three of them when held to 64, and loses 4 %: it keeps its seven waves.) */
 template <int W, bool CANON, int MODE, bool ASCII, bool SK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (W == 2 && SK) ? 8 : 1)
 fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const uint64_t n, const bool check_rc,
                    const result_view out, uint8_t* __restrict__ member, const pass_queues q,
                    const uint8_t* __restrict__ lane_valid /* null, or bit 0 of entry i: place i holds a query */) {
