@@ -81,9 +81,10 @@ public:
 
     /* the same routing, bucketed on the device (see sshash_route_bucket_device in include/sshash_amd.h) */
     void route_bucket_device(int device, uint64_t const* d_kmers, uint64_t n, uint32_t num_shards, bool check_rc,
-                             bool by_table_key, uint64_t* d_cursors, uint64_t* d_send, uint32_t* d_slots, void* stream) const;
+                             bool by_table_key, uint64_t* d_cursors, uint64_t* d_send, uint32_t* d_slots, void* stream,
+                             uint32_t* d_known_owners = nullptr) const;  // n words kept between the counting and the scattering launch
     void route_combine_device(int device, uint64_t const* d_replies, uint32_t const* d_slots, uint64_t m, uint64_t* d_out,
-                              void* stream) const;
+                              void* stream, bool one_reply_per_query = false) const;
 
     /* lookup_packed_device over the places i with bit 0 of d_lane_valid[i] set; the outputs of the other places are
        left untouched (the position-parallel streaming lookup, streaming.hip) */

@@ -96,6 +96,8 @@ class ShardedDictionary:
         import torch
         import torch.distributed as dist
 
+        if self.world == 1:
+            return [int(x) for x in send_counts]
         s = torch.tensor(send_counts, dtype=torch.int64, device="cpu" if self._on_host else self._dev)
         r = torch.empty_like(s)
         dist.all_to_all_single(r, s, group=self.group)
@@ -111,7 +113,9 @@ class ShardedDictionary:
         recv = self._tensor(recv_ptr, sum(recv_counts) * elem_bytes)
         s_split = [c * elem_bytes for c in send_counts]
         r_split = [c * elem_bytes for c in recv_counts]
-        if self._on_host:
+        if self.world == 1:  # a group of one: what is sent is what arrives
+            recv.copy_(send)
+        elif self._on_host:
             r = torch.empty(recv.numel(), dtype=torch.uint8)
             dist.all_to_all_single(r, send.cpu(), r_split, s_split, group=self.group)
             recv.copy_(r)
