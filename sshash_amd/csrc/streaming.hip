@@ -92,10 +92,23 @@ __device__ __forceinline__ void block_report(uint64_t c_kmers, uint64_t c_invali
     atomicAdd(reinterpret_cast<unsigned long long*>(report + 5), (unsigned long long)t[4]);
 }
 
-template <int W, bool CANON, bool SK>
+/* a lane's private column of the rolling election (device_layout.hpp: sk_roll_*): n word pairs in LDS, place-major so that the 64
+   lanes of a wave touch 512 contiguous bytes */
+struct roll_column {
+    uint2* base;  // this lane's place 0
+    __device__ __forceinline__ uint2 load(uint32_t i) const { return base[i * 256u]; }
+    __device__ __forceinline__ void store(uint32_t i, uint32_t x, uint32_t y) const { base[i * 256u] = make_uint2(x, y); }
+};
+constexpr uint32_t ROLL_LDS_LIMIT = 64u << 10;  // what a launch may ask for without further ado; n <= 32 at 256 lanes
+
+/* ROLL (SK only): the table key of a read's k-mers is elected incrementally -- two new candidates a base instead of all
+   2 (k - m + 1) at every seed; needs (k - m + 1) * 8 bytes of LDS per lane (the launch passes them) */
+template <int W, bool CANON, bool SK, bool ROLL>
 __global__ void __launch_bounds__(256)
 streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const char* __restrict__ bases,
                  const uint64_t* __restrict__ offsets, const uint64_t n_reads, uint64_t* __restrict__ report) {
+    extern __shared__ uint2 roll_lds[];
+    roll_column column{roll_lds + threadIdx.x};
     uint64_t c_kmers = 0, c_invalid = 0, c_negative = 0, c_searches = 0, c_extensions = 0;
     const uint32_t k = d.k;
     const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
@@ -117,6 +130,8 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
            dependent memory access per k-mer of a high-hit read; this is one per 32-64 extensions. */
         kmer_w<W> at = kmer_zero<W>();
         sk_line_cache line_cache;
+        sk_roll_state roll;
+        if constexpr (ROLL) sk_roll_start(roll, k, d.m);
         uint64_t c_idx = ~uint64_t(0) - 1, c_b0 = 0, c_b1 = 0, c_marks = 0;  // (neither c_idx nor c_idx + 1 is a block)
         auto string_base = [&](uint64_t pb, uint32_t& base, bool& starts) {
             const uint64_t idx = pb >> 5;
@@ -172,6 +187,9 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
             x = kmer_roll<W>(x, code, k);
             x_rc = kmer_roll_rc<W>(x_rc, code, k);
             valid_len = base_is_valid(c) ? valid_len + 1 : 0;
+            if constexpr (ROLL) {
+                if (j + 1 >= d.m) sk_roll_push<W>(roll, x, x_rc, k, d.m, column);
+            }
             if (j + 1 < k) continue;
             if (valid_len < k) {  // :59-65 -- invalid k-mer resets the whole state
                 ++c_invalid;
@@ -198,7 +216,7 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
             }
             /* seed() */
             if constexpr (SK) {
-                const sk_key_t kk = sk_key<W>(x, x_rc, k, d.m);
+                const sk_key_t kk = ROLL ? sk_roll_key<W>(roll, x, x_rc, k, d.m) : sk_key<W>(x, x_rc, k, d.m);
                 if (sk_usable(d, kk)) {
                     if (neg_unknown_mini && kk.key == prev_f) {
                         ++c_negative;
@@ -261,11 +279,19 @@ void launch_streaming(dict_view const& d, skew_part_dev const* skew, char const*
     const uint32_t block = 256;
     uint64_t blocks = (n_reads + block - 1) / block;
     if (blocks > (uint64_t(1) << 20)) blocks = uint64_t(1) << 20;
-    if (d.sk.enabled)
-        hipLaunchKernelGGL((streaming_kernel<W, CANON, true>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
+    const uint32_t roll_bytes = (d.k - d.m + 1) * block * uint32_t(sizeof(uint2));
+    static const bool rolling = [] {
+        char const* e = std::getenv("SSHASH_AMD_STREAM_ROLLING");  // 0: every seed elects its key from scratch (sk_key), as until round 4
+        return !(e && e[0] == '0');
+    }();
+    if (d.sk.enabled && rolling && roll_bytes <= ROLL_LDS_LIMIT)
+        hipLaunchKernelGGL((streaming_kernel<W, CANON, true, true>), dim3(uint32_t(blocks)), dim3(block), roll_bytes, s, d, skew, bases,
+                           offsets, n_reads, report);
+    else if (d.sk.enabled)
+        hipLaunchKernelGGL((streaming_kernel<W, CANON, true, false>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
                            offsets, n_reads, report);
     else
-        hipLaunchKernelGGL((streaming_kernel<W, CANON, false>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
+        hipLaunchKernelGGL((streaming_kernel<W, CANON, false, false>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
                            offsets, n_reads, report);
     HIP_CHECK(hipGetLastError());
 }

@@ -52,6 +52,39 @@ static int check(uint32_t k, uint32_t m, uint64_t trials, std::mt19937_64& rng, 
     return 0;
 }
 
+/* the rolling election of the streaming query (sk_roll_*) against sk_key, base by base along random and low-complexity reads */
+struct host_column {
+    struct pair { uint32_t x, y; };
+    pair at[64];
+    pair load(uint32_t i) const { return at[i]; }
+    void store(uint32_t i, uint32_t x, uint32_t y) { at[i] = {x, y}; }
+};
+
+template <int W>
+static int check_rolling(uint32_t k, uint32_t m, uint64_t reads, std::mt19937_64& rng, uint64_t& kmers) {
+    for (uint64_t t = 0; t < reads; ++t) {
+        const uint32_t len = k + uint32_t(rng() % 200);
+        const uint32_t alphabet = t % 5 == 0 ? 2 : 4;  // two-letter reads: equal hashes inside one window, on both strands
+        kmer_w<W> x = kmer_zero<W>(), y = kmer_zero<W>();
+        sk_roll_state st;
+        host_column column;
+        sk_roll_start(st, k, m);
+        for (uint32_t j = 0; j < len; ++j) {
+            const uint64_t code = t % 11 == 0 && (j / 40) % 2 ? 0 : rng() % alphabet;  // and stretches of one letter
+            x = kmer_roll<W>(x, code, k);
+            y = kmer_roll_rc<W>(y, code, k);
+            if (j + 1 >= m) sk_roll_push<W>(st, x, y, k, m, column);
+            if (j + 1 < k) continue;
+            const sk_key_t a = sk_key<W>(x, y, k, m), b = sk_roll_key<W>(st, x, y, k, m);
+            if (a.tie != b.tie || a.rc != b.rc || a.pos != b.pos || a.key != b.key)
+                return printf("rolling election differs from sk_key (k=%u m=%u read %llu base %u: tie %d/%d rc %d/%d pos %u/%u)\n", k, m,
+                              (unsigned long long)t, j, a.tie, b.tie, a.rc, b.rc, a.pos, b.pos), 1;
+            ++kmers;
+        }
+    }
+    return 0;
+}
+
 int main() {
     std::mt19937_64 rng(12345);
     uint64_t ties = 0, checked = 0;
@@ -64,6 +97,10 @@ int main() {
         checked += trials;
         fprintf(stderr, "k=%u m=%u: %llu ties in %llu k-mers\n", c[0], c[1], (unsigned long long)(ties - before), (unsigned long long)trials);
     }
+    uint64_t rolled = 0;
+    for (auto const& c : cases)
+        if (c[0] <= 31 ? check_rolling<1>(c[0], c[1], 3000, rng, rolled) : check_rolling<2>(c[0], c[1], 3000, rng, rolled)) return 1;
+    fprintf(stderr, "rolling election: %llu k-mers equal to sk_key\n", (unsigned long long)rolled);
     /* bucket hashing: every choice inside the table */
     for (uint64_t key = 1; key < 100000; key += 7) {
         const sk_hash_t h = sk_hash(key * 0x9E3779B97F4A7C15ULL >> 22, 1000003u);
