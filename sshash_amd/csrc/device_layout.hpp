@@ -443,15 +443,10 @@ SSH_HD void sk_roll_start(sk_roll_state& st, uint32_t k, uint32_t m) {
     st.pf = st.pr = st.sf = st.sr = 0xFFFFFFFFu;
 }
 
-/* after the read's base has entered x (at its last place) and x_rc (at its first), from the (m - 1)-th base of the read on */
-template <int W, class Column>
-SSH_HD void sk_roll_push(sk_roll_state& st, kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m, Column& column) {
-    const uint32_t n = k - m + 1, mul = sk_select_mul();
-    const uint32_t b = st.b + 1 == n ? 0u : st.b + 1;
-    st.b = b;
-    /* the newest occurrence: the last m bases of x, the first m of x_rc */
+/* the newest occurrence -- the last m bases of x, the first m of x_rc -- as sk_elect hands its candidates to sk_select_hash */
+template <int W>
+SSH_HD void sk_roll_newest(kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m, uint32_t& wf, uint32_t& wr) {
     const uint32_t s = 2 * (k - m);  // uniform
-    uint32_t wf;
     if constexpr (W == 1) {
         const uint32_t lo = uint32_t(x.w[0]), hi = uint32_t(x.w[0] >> 32);
         wf = s < 32 ? funnel32(lo, hi, s) : hi >> (s - 32);
@@ -462,13 +457,23 @@ SSH_HD void sk_roll_push(sk_roll_state& st, kmer_w<W> const& x, kmer_w<W> const&
         const uint32_t hi = j == 0 ? w1 : j == 1 ? w2 : j == 2 ? w3 : 0u;
         wf = funnel32(lo, hi, t);
     }
-    uint32_t wr = uint32_t(x_rc.w[0]);
+    wr = uint32_t(x_rc.w[0]);
     wf ^= sk_select_salt<W>();
     wr ^= sk_select_salt<W>();
     if (m < 12) {  // uniform: see sk_elect, MASKED
         wf <<= 24 - 2 * m;
         wr <<= 24 - 2 * m;
     }
+}
+
+/* after the read's base has entered x (at its last place) and x_rc (at its first), from the (m - 1)-th base of the read on */
+template <int W, class Column>
+SSH_HD void sk_roll_push(sk_roll_state& st, kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m, Column& column) {
+    const uint32_t n = k - m + 1, mul = sk_select_mul();
+    const uint32_t b = st.b + 1 == n ? 0u : st.b + 1;
+    st.b = b;
+    uint32_t wf, wr;
+    sk_roll_newest<W>(x, x_rc, k, m, wf, wr);
     const uint32_t hf = sk_select_hash(wf, b, mul);        // equal hashes: the smaller b, the older occurrence
     const uint32_t hr = sk_select_hash(wr, 63u - b, mul);  // equal hashes: the larger b, the newer occurrence
     st.pf = b == 0 ? hf : (hf < st.pf ? hf : st.pf);
@@ -510,6 +515,68 @@ SSH_HD sk_key_t sk_roll_key(sk_roll_state const& st, kmer_w<W> const& x, kmer_w<
     out.pos = out.rc ? pos_r : pos_f;
     out.key = kmer_shr_chars<W>(out.rc ? x_rc : x, out.pos).w[0] & low_mask(2 * m);
     return out;
+}
+
+/* The same with ONE word per place -- half the LDS, which is what decides at k <= 63 (n = 39 at m = 25: 80 KB a workgroup with
+   word pairs left two waves a SIMD and the kernel a third slower than electing from scratch). A place keeps the smaller of its two
+   strands' hashes: 24 hash bits | ambiguous | strand | place. The minimum over the window then names strand and place of the winner
+   directly -- PROVIDED it is the only candidate with its 24 hash bits: wherever two equal hash prefixes meet in a minimum the entry
+   is marked ambiguous (the marks travel with the minima), and a k-mer whose window minimum is so marked is elected from scratch
+   (sk_key): equal hashes are where sk_key's rules -- leftmost per strand, tie between the strands -- matter, and they are rare
+   (a 12-mer repeated inside the window, on either strand). */
+constexpr uint32_t SK_ROLL1_AMBIGUOUS = 0x80u, SK_ROLL1_RC = 0x40u, SK_ROLL1_NONE = 0xFFFFFFFFu;
+struct sk_roll1_state {
+    uint32_t b;  // block index of the newest occurrence
+    uint32_t p;  // minimum of the running block so far
+    uint32_t s;  // minimum of the block before, from where this base's window starts (SK_ROLL1_NONE: the window is the running block)
+};
+
+SSH_HD uint32_t sk_roll1_combine(uint32_t a, uint32_t b) {
+    const uint32_t least = a < b ? a : b;
+    return ((a ^ b) >> 8) == 0 ? least | SK_ROLL1_AMBIGUOUS : least;
+}
+
+SSH_HD void sk_roll1_start(sk_roll1_state& st, uint32_t k, uint32_t m) {
+    st.b = k - m;
+    st.p = st.s = SK_ROLL1_NONE;
+}
+
+/* Column: words indexed 0 .. n-1; load(i), store(i, word) */
+template <int W, class Column>
+SSH_HD void sk_roll1_push(sk_roll1_state& st, kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m, Column& column) {
+    const uint32_t n = k - m + 1, mul = sk_select_mul();
+    const uint32_t b = st.b + 1 == n ? 0u : st.b + 1;
+    st.b = b;
+    uint32_t wf, wr;
+    sk_roll_newest<W>(x, x_rc, k, m, wf, wr);
+    const uint32_t ef = (sk_select_hash(wf, 0u, mul) & 0xFFFFFF00u) | b;
+    const uint32_t er = (sk_select_hash(wr, 0u, mul) & 0xFFFFFF00u) | SK_ROLL1_RC | b;
+    const uint32_t here = sk_roll1_combine(ef, er);
+    st.p = b == 0 ? here : sk_roll1_combine(st.p, here);
+    st.s = b + 1 < n ? column.load(b + 1) : SK_ROLL1_NONE;
+    column.store(b, here);
+    if (b + 1 == n) {  // the block is complete: its suffix minima, in place (the last place is its own)
+        uint32_t least = here;
+        for (uint32_t i = n - 1; i-- > 0;) {
+            least = sk_roll1_combine(column.load(i), least);
+            column.store(i, least);
+        }
+    }
+}
+
+/* the key of the k-mer that ends at the base pushed last; false: ambiguous, ask sk_key */
+template <int W>
+SSH_HD bool sk_roll1_key(sk_roll1_state const& st, kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m, sk_key_t& out) {
+    const uint32_t n = k - m + 1, b = st.b;
+    const uint32_t least = st.s == SK_ROLL1_NONE ? st.p : sk_roll1_combine(st.s, st.p);
+    if (least & SK_ROLL1_AMBIGUOUS) return false;
+    const uint32_t place = least & 63u;
+    const bool before = place > b;  // a place of the block before (they are b + 1 .. n - 1)
+    out.rc = (least & SK_ROLL1_RC) != 0;
+    out.tie = false;
+    out.pos = out.rc ? (before ? b + n - place : b - place) : (before ? place - b - 1 : n - 1 - b + place);
+    out.key = kmer_shr_chars<W>(out.rc ? x_rc : x, out.pos).w[0] & low_mask(2 * m);
+    return true;
 }
 
 struct dict_view {

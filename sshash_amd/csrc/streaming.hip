@@ -99,16 +99,26 @@ struct roll_column {
     __device__ __forceinline__ uint2 load(uint32_t i) const { return base[i * 256u]; }
     __device__ __forceinline__ void store(uint32_t i, uint32_t x, uint32_t y) const { base[i * 256u] = make_uint2(x, y); }
 };
-constexpr uint32_t ROLL_LDS_LIMIT = 64u << 10;  // what a launch may ask for without further ado; n <= 32 at 256 lanes
+struct roll_column1 {  // one word a place (sk_roll1_*)
+    uint32_t* base;
+    __device__ __forceinline__ uint32_t load(uint32_t i) const { return base[i * 256u]; }
+    __device__ __forceinline__ void store(uint32_t i, uint32_t v) const { base[i * 256u] = v; }
+};
+/* LDS a workgroup may take for the election: k <= 31 keeps word pairs (exact by itself; n = 11 at m = 21: 22.5 KB), k <= 63 one word
+   a place (n = 39 at m = 25: 39 KB, three workgroups a CU -- as many waves as the kernel's registers allow anyway). Word pairs at
+   k = 63 (80 KB, two workgroups a CU): 31.6 -> 20.6 G k-mers/s (profiles/r04/streaming_rolling_election_k63_pairs_ab.txt). */
+constexpr uint32_t ROLL_LDS_LIMIT = 40u << 10;
 
 /* ROLL (SK only): the table key of a read's k-mers is elected incrementally -- two new candidates a base instead of all
    2 (k - m + 1) at every seed; needs (k - m + 1) * 8 bytes of LDS per lane (the launch passes them) */
 template <int W, bool CANON, bool SK, bool ROLL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (ROLL && W == 2) ? 4 : 1)  // (four waves a SIMD, as without ROLL: 128 registers)
 streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const char* __restrict__ bases,
                  const uint64_t* __restrict__ offsets, const uint64_t n_reads, uint64_t* __restrict__ report) {
     extern __shared__ uint2 roll_lds[];
+    constexpr bool PAIRS = W == 1;
     roll_column column{roll_lds + threadIdx.x};
+    roll_column1 column1{reinterpret_cast<uint32_t*>(roll_lds) + threadIdx.x};
     uint64_t c_kmers = 0, c_invalid = 0, c_negative = 0, c_searches = 0, c_extensions = 0;
     const uint32_t k = d.k;
     const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
@@ -131,7 +141,9 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
         kmer_w<W> at = kmer_zero<W>();
         sk_line_cache line_cache;
         sk_roll_state roll;
-        if constexpr (ROLL) sk_roll_start(roll, k, d.m);
+        sk_roll1_state roll1;
+        if constexpr (ROLL && PAIRS) sk_roll_start(roll, k, d.m);
+        if constexpr (ROLL && !PAIRS) sk_roll1_start(roll1, k, d.m);
         uint64_t c_idx = ~uint64_t(0) - 1, c_b0 = 0, c_b1 = 0, c_marks = 0;  // (neither c_idx nor c_idx + 1 is a block)
         auto string_base = [&](uint64_t pb, uint32_t& base, bool& starts) {
             const uint64_t idx = pb >> 5;
@@ -188,7 +200,10 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
             x_rc = kmer_roll_rc<W>(x_rc, code, k);
             valid_len = base_is_valid(c) ? valid_len + 1 : 0;
             if constexpr (ROLL) {
-                if (j + 1 >= d.m) sk_roll_push<W>(roll, x, x_rc, k, d.m, column);
+                if (j + 1 >= d.m) {
+                    if constexpr (PAIRS) sk_roll_push<W>(roll, x, x_rc, k, d.m, column);
+                    else sk_roll1_push<W>(roll1, x, x_rc, k, d.m, column1);
+                }
             }
             if (j + 1 < k) continue;
             if (valid_len < k) {  // :59-65 -- invalid k-mer resets the whole state
@@ -216,7 +231,14 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
             }
             /* seed() */
             if constexpr (SK) {
-                const sk_key_t kk = ROLL ? sk_roll_key<W>(roll, x, x_rc, k, d.m) : sk_key<W>(x, x_rc, k, d.m);
+                sk_key_t kk;
+                if constexpr (ROLL && PAIRS) {
+                    kk = sk_roll_key<W>(roll, x, x_rc, k, d.m);
+                } else if constexpr (ROLL) {
+                    if (!sk_roll1_key<W>(roll1, x, x_rc, k, d.m, kk)) kk = sk_key<W>(x, x_rc, k, d.m);  // equal hash prefixes: rare
+                } else {
+                    kk = sk_key<W>(x, x_rc, k, d.m);
+                }
                 if (sk_usable(d, kk)) {
                     if (neg_unknown_mini && kk.key == prev_f) {
                         ++c_negative;
@@ -279,15 +301,23 @@ void launch_streaming(dict_view const& d, skew_part_dev const* skew, char const*
     const uint32_t block = 256;
     uint64_t blocks = (n_reads + block - 1) / block;
     if (blocks > (uint64_t(1) << 20)) blocks = uint64_t(1) << 20;
-    const uint32_t roll_bytes = (d.k - d.m + 1) * block * uint32_t(sizeof(uint2));
-    static const bool rolling = [] {
-        char const* e = std::getenv("SSHASH_AMD_STREAM_ROLLING");  // 0: every seed elects its key from scratch (sk_key), as until round 4
-        return !(e && e[0] == '0');
-    }();
-    if (d.sk.enabled && rolling && roll_bytes <= ROLL_LDS_LIMIT)
+    const uint32_t roll_bytes = (d.k - d.m + 1) * block * uint32_t(W == 1 ? sizeof(uint2) : sizeof(uint32_t));
+    /* SSHASH_AMD_STREAM_ROLLING: 0 = every seed elects its key from scratch (sk_key), as until round 4; 1 = incrementally wherever the
+       LDS allows. Default: incrementally at k <= 31 (high-hit reads 44.0 -> 48.9 G k-mers/s, random reads 82 -> 104); at k <= 63 only
+       on request -- random reads gain as much (63 -> 78) but reads that hit lose 3-4 % (31.7 -> 30.8 on config C4's set): there a
+       step waits for the slowest lane's memory access, not for the election, and the kernel no longer fits its 128 registers
+       (20 bytes of scratch). profiles/r04/streaming_rolling_election_k63_ab.txt */
+    char const* choice = std::getenv("SSHASH_AMD_STREAM_ROLLING");  // (read at every launch: the tests switch it inside one process)
+    const bool rolling = choice && (choice[0] == '0' || choice[0] == '1') ? choice[0] == '1' : W == 1;
+    char const* lds = std::getenv("SSHASH_AMD_STREAM_ROLLING_LDS");  // bytes of LDS a workgroup may take for it (A/B runs, tests)
+    const uint32_t roll_limit = lds ? uint32_t(std::strtoul(lds, nullptr, 10)) : ROLL_LDS_LIMIT;
+    if (d.sk.enabled && rolling && roll_bytes <= roll_limit) {
+        if (roll_bytes > (64u << 10))  // beyond what a launch may ask for without saying so first
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&streaming_kernel<W, CANON, true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(roll_bytes)));
         hipLaunchKernelGGL((streaming_kernel<W, CANON, true, true>), dim3(uint32_t(blocks)), dim3(block), roll_bytes, s, d, skew, bases,
                            offsets, n_reads, report);
-    else if (d.sk.enabled)
+    } else if (d.sk.enabled)
         hipLaunchKernelGGL((streaming_kernel<W, CANON, true, false>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
                            offsets, n_reads, report);
     else

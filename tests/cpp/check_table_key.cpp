@@ -60,6 +60,43 @@ struct host_column {
     void store(uint32_t i, uint32_t x, uint32_t y) { at[i] = {x, y}; }
 };
 
+struct host_column1 {
+    uint32_t at[64];
+    uint32_t load(uint32_t i) const { return at[i]; }
+    void store(uint32_t i, uint32_t v) { at[i] = v; }
+};
+
+/* the one-word form: equal to sk_key wherever it commits itself; how often it does not is printed */
+template <int W>
+static int check_rolling1(uint32_t k, uint32_t m, uint64_t reads, std::mt19937_64& rng, uint64_t& kmers, uint64_t& ambiguous) {
+    for (uint64_t t = 0; t < reads; ++t) {
+        const uint32_t len = k + uint32_t(rng() % 200);
+        const uint32_t alphabet = t % 5 == 0 ? 2 : 4;
+        kmer_w<W> x = kmer_zero<W>(), y = kmer_zero<W>();
+        sk_roll1_state st;
+        host_column1 column;
+        sk_roll1_start(st, k, m);
+        for (uint32_t j = 0; j < len; ++j) {
+            const uint64_t code = t % 11 == 0 && (j / 40) % 2 ? 0 : rng() % alphabet;
+            x = kmer_roll<W>(x, code, k);
+            y = kmer_roll_rc<W>(y, code, k);
+            if (j + 1 >= m) sk_roll1_push<W>(st, x, y, k, m, column);
+            if (j + 1 < k) continue;
+            ++kmers;
+            const sk_key_t a = sk_key<W>(x, y, k, m);
+            sk_key_t b;
+            if (!sk_roll1_key<W>(st, x, y, k, m, b)) {
+                ++ambiguous;
+                continue;
+            }
+            if (a.tie || a.rc != b.rc || a.pos != b.pos || a.key != b.key)
+                return printf("one-word rolling election differs from sk_key (k=%u m=%u read %llu base %u: tie %d rc %d/%d pos %u/%u)\n", k, m,
+                              (unsigned long long)t, j, a.tie, a.rc, b.rc, a.pos, b.pos), 1;
+        }
+    }
+    return 0;
+}
+
 template <int W>
 static int check_rolling(uint32_t k, uint32_t m, uint64_t reads, std::mt19937_64& rng, uint64_t& kmers) {
     for (uint64_t t = 0; t < reads; ++t) {
@@ -101,6 +138,12 @@ int main() {
     for (auto const& c : cases)
         if (c[0] <= 31 ? check_rolling<1>(c[0], c[1], 3000, rng, rolled) : check_rolling<2>(c[0], c[1], 3000, rng, rolled)) return 1;
     fprintf(stderr, "rolling election: %llu k-mers equal to sk_key\n", (unsigned long long)rolled);
+    for (auto const& c : cases) {
+        uint64_t seen = 0, ambiguous = 0;
+        if (c[0] <= 31 ? check_rolling1<1>(c[0], c[1], 3000, rng, seen, ambiguous) : check_rolling1<2>(c[0], c[1], 3000, rng, seen, ambiguous)) return 1;
+        fprintf(stderr, "one-word rolling election k=%u m=%u: %llu k-mers, %llu left to sk_key\n", c[0], c[1], (unsigned long long)seen,
+                (unsigned long long)ambiguous);
+    }
     /* bucket hashing: every choice inside the table */
     for (uint64_t key = 1; key < 100000; key += 7) {
         const sk_hash_t h = sk_hash(key * 0x9E3779B97F4A7C15ULL >> 22, 1000003u);

@@ -60,6 +60,24 @@ def test_streaming_counters_match_oracle(case_name, request):
     assert got["num_extensions"] > 0 and got["num_invalid_kmers"] > 0
 
 
+@pytest.mark.parametrize("rolling", ["0", "1"])
+@pytest.mark.parametrize("case_name", ["case_se_regular", "case_se_canonical", "case_skew_regular", "case_k63_canonical", "case_k63_regular",
+                                       "case_small_k", "case_m_equals_k"])
+def test_streaming_counters_with_the_key_elected_from_scratch_and_incrementally(case_name, rolling, request, monkeypatch):
+    """SSHASH_AMD_STREAM_ROLLING: 0 = sk_key at every seed, 1 = the sliding election (device_layout.hpp: sk_roll_*; word pairs at k <= 31, one
+    word a place with the ambiguous windows handed to sk_key at k <= 63 -- off by default there), with room for the widest window of
+    the cases (k = 63, m = 17: 47 places). Low-complexity reads put equal hashes into one window."""
+    case = request.getfixturevalue(case_name)
+    monkeypatch.setenv("SSHASH_AMD_STREAM_ROLLING", rolling)
+    monkeypatch.setenv("SSHASH_AMD_STREAM_ROLLING_LDS", str(64 << 10))
+    d = case.dict.to_device(0)
+    rng = np.random.default_rng(5)
+    reads = _synthetic_reads(case, 2000, seed=23)
+    reads += ["".join(rng.choice(list("AC"), size=200)) for _ in range(50)] + ["A" * 300, "ACGT" * 60, ("A" * 40 + "C" * 40) * 3]
+    got = _as_dict(d.streaming_query(reads))
+    assert got == case.oracle.streaming_query(reads)
+
+
 def test_streaming_query_from_fastq_file(case_se_regular, case_se_canonical):
     """README.md:222-223 known answer num_kmers = 460000 for SRR5833294.10K at k=31; the other counters
     against the oracle, and num_positive against a brute-force set (test/check.cpp:61-98)."""
