@@ -183,7 +183,9 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
                every second / fourth / eighth step, so that the instructions of sk_probe's inner loop run at a fraction of the steps instead of
                86 % of them: 44.0 -> 35.7 / 31.7 / 26.1 (streaming_waiting_seeds_ab.txt) -- the waiting lanes finish their reads later, and the
                wave with them.
-           What helped this kernel in round 4 is what made the table's key cheaper (device_layout.hpp: 2.5 instructions per candidate). */
+           What helped this kernel in round 4 is what made the table's key cheaper (device_layout.hpp: 2.5 instructions per candidate) and
+           then ROLL: the key elected incrementally along the read (397 vector instructions per base and wave, 44.0 -> 48.9 G k-mers/s on
+           the high-hit set, 82 -> 104 on random reads; profiles/r04/streaming_rolling_election_ab.txt). */
         uint64_t eight = 0;  // the read's characters, eight per load (a byte load per base is a round trip per base)
         for (uint64_t j = 0; j < len; ++j) {
             if ((j & 7u) == 0) {
