@@ -13,7 +13,7 @@ the ranks ("scaling": "strong"). `--workload c2` selects configs[1] (S. enterica
     python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2|c4] [--bases B --queries Q] [--canonical]
     python bench.py --workload c4 --streaming [--gpus N --reads R]      the streaming query of configs[3], read-sharded
 
-The default run (C3, one GPU) appends `other_workloads`: the C2 line, the C4 (k = 63) line and the C4 streaming line, each a
+The default run (C3, one GPU) appends `other_workloads`: the C2 line, the C4 (k = 63) line, the C4 streaming line and the k = 31 streaming line, each a
 child run of this script with its own oracle check, roofline and cpu_baseline.
 
 `--gpus N` with N > 1 starts the N ranks itself (python -m torch.distributed.run, rendezvous on 127.0.0.1);
@@ -760,7 +760,10 @@ def main():
             torch.cuda.empty_cache()
             other_workloads = {}
             for name, extra in (("c2", ["--workload", "c2"]), ("c4", ["--workload", "c4"]),
-                                ("c4_streaming", ["--workload", "c4", "--streaming", "--reads", str(args.other_streaming_reads)])):
+                                ("c4_streaming", ["--workload", "c4", "--streaming", "--reads", str(args.other_streaming_reads)]),
+                                # the streaming query at k = 31 in the regime the reference publishes (high-hit: 95 % of the reads spell
+                                # k-mers of the dictionary), on the headline's own dictionary
+                                ("c3_streaming_high_hit", ["--workload", "c3", "--streaming", "--positive", "0.95", "--reads", str(args.other_streaming_reads)])):
                 if reduced:
                     b_, q_, r_ = reduced.split(",")
                     extra = extra + ["--bases", b_, "--cpu-sample", "100000"] + (["--reads", r_, "--stream-oracle-reads", "5000"] if "--streaming" in extra else ["--queries", q_])

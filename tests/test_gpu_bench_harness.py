@@ -130,7 +130,7 @@ def test_streaming_mode_one_rank_and_two(tmp_path):
 
 def test_default_run_appends_the_other_baseline_configurations(tmp_path):
     """The driver's command measures C3 and, behind it, BASELINE.json's other single-GPU configurations as child runs of the same script
-    (`other_workloads`: C2, C4, C4's streaming query), each with its own oracle check, roofline and cpu_baseline -- here at reduced size."""
+    (`other_workloads`: C2, C4, C4's streaming query, the k = 31 streaming query on high-hit reads), each with its own oracle check, roofline and cpu_baseline -- here at reduced size."""
     env = dict(os.environ, SSHASH_BENCH_CACHE=str(tmp_path), SSHASH_BENCH_TEST_OTHER_WORKLOADS="24000000,2000000,200000")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -141,11 +141,13 @@ def test_default_run_appends_the_other_baseline_configurations(tmp_path):
     assert len(out) == 1
     r = json.loads(out[0])
     others = r["other_workloads"]
-    assert set(others) == {"c2", "c4", "c4_streaming"}
+    assert set(others) == {"c2", "c4", "c4_streaming", "c3_streaming_high_hit"}
     for name, line in others.items():
         assert "error" not in line, line
         for key in CONTRACT:
             assert key in line, (name, key)
         assert line["value"] > 0 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0 and line["n_gpus"] == 1
     assert others["c2"]["config"]["k"] == 31 and others["c4"]["config"]["k"] == 63 and others["c4_streaming"]["unit"] == "k-mers/s"
+    high = others["c3_streaming_high_hit"]
+    assert high["unit"] == "k-mers/s" and high["config"]["k"] == 31 and high["config"]["positive_fraction_of_kmers"] > 0.5
     assert others["c2"]["config"]["recipe"] == "se_k31" and others["c4"]["config"]["recipe"] == "human_k63"
