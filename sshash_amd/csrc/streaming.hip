@@ -185,7 +185,13 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
                wave with them.
            What helped this kernel in round 4 is what made the table's key cheaper (device_layout.hpp: 2.5 instructions per candidate) and
            then ROLL: the key elected incrementally along the read (397 vector instructions per base and wave, 44.0 -> 48.9 G k-mers/s on
-           the high-hit set, 82 -> 104 on random reads; profiles/r04/streaming_rolling_election_ab.txt). */
+           the high-hit set, 82 -> 104 on random reads; profiles/r04/streaming_rolling_election_ab.txt). With that the vector ALUs are
+           62 % busy and a wave spends 59 % of its time waiting (SQ_WAIT_ANY; no instruction-cache misses): a step now waits for its
+           slowest lane's memory access -- first the extension's (a block of the strings), then the seed's (a bucket line). A third
+           schedule, measured and not kept: the key elected and its bucket's line requested BEFORE the run is tried, so that the two
+           waits overlap -- 49.2 -> 40.7 high-hit, 104.6 -> 94.1 on random reads, 31.8 -> 26.2 on C4's set
+           (streaming_bucket_prefetch_before_extension_ab.txt): the key held across the extension costs 15 registers, the kernel
+           either drops to three waves a SIMD or spills, and either costs more than the overlap gives. */
         uint64_t eight = 0;  // the read's characters, eight per load (a byte load per base is a round trip per base)
         for (uint64_t j = 0; j < len; ++j) {
             if ((j & 7u) == 0) {
