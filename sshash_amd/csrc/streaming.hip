@@ -192,14 +192,26 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
            waits overlap -- 49.2 -> 40.7 high-hit, 104.6 -> 94.1 on random reads, 31.8 -> 26.2 on C4's set
            (streaming_bucket_prefetch_before_extension_ab.txt): the key held across the extension costs 15 registers, the kernel
            either drops to three waves a SIMD or spills, and either costs more than the overlap gives. */
-        uint64_t eight = 0;  // the read's characters, eight per load (a byte load per base is a round trip per base)
+        /* the read's characters, eight per load (a byte load per base is a round trip per base), and (k <= 31) loaded eight bases ahead of
+           their use: the wave does not wait for them */
+        auto characters = [&](uint64_t j) {
+            uint64_t eight = 0;
+            if (j + 8 <= len) {
+                __builtin_memcpy(&eight, p + j, 8);
+            } else {
+                for (uint64_t b = j; b < len; ++b) eight |= uint64_t(uint8_t(p[b])) << (8 * (b - j));
+            }
+            return eight;
+        };
+        constexpr bool AHEAD = W == 1;  // (k <= 63: the two registers more would cost the kernel its fourth wave)
+        uint64_t eight = 0, ahead = AHEAD ? characters(0) : 0;
         for (uint64_t j = 0; j < len; ++j) {
             if ((j & 7u) == 0) {
-                if (j + 8 <= len) {
-                    __builtin_memcpy(&eight, p + j, 8);
+                if constexpr (AHEAD) {
+                    eight = ahead;
+                    if (j + 8 < len) ahead = characters(j + 8);
                 } else {
-                    eight = 0;
-                    for (uint64_t b = j; b < len; ++b) eight |= uint64_t(uint8_t(p[b])) << (8 * (b - j));
+                    eight = characters(j);
                 }
             }
             const char c = char(eight >> (8 * (j & 7u)));
