@@ -212,7 +212,10 @@ struct sk_view {
        factor (SK_SLOTS_PER_KMER): a probe gets there only after its key's marker, one positive lookup in ten or twenty,
        and what a fuller region costs (more second choices) is paid by those alone */
     uint32_t kmer_buckets;
-    uint32_t spare;
+    /* length of the table's key m-mers. The table elects its own key (sk_key), so it need not be the dictionary's minimizer length:
+       a shorter key makes longer super-k-mers (up to k - m + 1 k-mers an item) and so fewer items -- what the table's size is
+       proportional to. Set by build_sk_table; every table-side function reads it from here, never dict_view::m */
+    uint32_t m;
     /* table shard (multi-GPU, sharded.py): this replica's table holds only the keys with
        sk_owner(key, num_shards) == shard_id; lookups of other keys take the complete path */
     uint32_t num_shards;

@@ -1203,7 +1203,7 @@ route_bucket_kernel(const dict_view d, const uint64_t* __restrict__ kmers, const
             if constexpr (BY_KEY) {
                 /* table shards: the owner of the k-mer's table key; a k-mer without a key (tie) can go to any
                    replica -- they all hold the complete path -- so it goes where its smaller strand hashes */
-                const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
+                const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.sk.m);
                 owner_f = owner_r = sk_owner(kk.tie ? (kmer_less<W>(x_rc, x) ? x_rc.w[0] : x.w[0]) : kk.key, num_shards);
             } else {
                 uint64_t f = compute_minimizer<W>(x, d.k, d.m, d.hash_magic).value;

@@ -693,7 +693,7 @@ struct sk_bucket_flags {
 template <int W, bool FIRST, class Piece>
 __device__ __forceinline__ void sk_examine_slot(dict_view const& d, sk_query_t<W> const Q, uint32_t c, Piece piece, fast_t& r,
                                                 bool& key_seen, bool& marker, sk_bucket_flags& flags) {
-    const uint32_t km = d.k - d.m;
+    const uint32_t km = d.k - d.sk.m;
     const uint32_t j = Q.j;
     /* values, not references into Q: a select between two members of a by-reference struct is compiled into an
        indexed load, which pins the struct in scratch memory */
@@ -1106,7 +1106,7 @@ template <int W>
 __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<W> const& x, bool active, bool allow_rc,
                                                      int8_t miss_orientation, uint4* wave_stage) {
     const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
-    const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
+    const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.sk.m);
     const bool usable = active && sk_usable(d, kk);  // else: no strand-symmetric key, or a key of another table shard
     const sk_hash_t h = sk_hash(kk.key, d.sk.num_buckets);
     const sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, h.fingerprint);
@@ -1301,7 +1301,7 @@ template <int W>
 __device__ __forceinline__ fast_t sk_lookup_in_wave(dict_view const& d, kmer_w<W> const& x, bool active, bool allow_rc, int8_t miss_orientation,
                                                     uint4* wave_stage) {
     const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
-    const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
+    const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.sk.m);
     const bool usable = active && sk_usable(d, kk);
     sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), 0);
     sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, w.h.fingerprint);
@@ -1325,7 +1325,7 @@ template <int W>
 __device__ __forceinline__ fast_t sk_second_pass_wave(dict_view const& d, kmer_w<W> const& x, bool active, uint32_t entry, bool allow_rc,
                                                       int8_t miss_orientation, uint4* wave_stage) {
     const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
-    const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
+    const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.sk.m);
     sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), (entry >> RESUME_CHOICE_SHIFT) & 7u);
     sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, w.h.fingerprint);
     if (entry & RESUME_HEAVY) sk_walk_to_kmer_sequence<W>(d, x, x_rc, w, Q, (entry & RESUME_GO_ON) != 0);

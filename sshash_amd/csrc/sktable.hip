@@ -53,10 +53,10 @@ sk_scan_kernel(const dict_view d, const uint64_t first_wave, const uint64_t num_
         if (!w.crosses) {
             const kmer_w<W> x = w.kmer;
             const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);
-            const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
+            const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.sk.m);
             if (sk_usable(d, kk)) {  // (another table shard's key is left out like a tie)
                 key = kk.key;
-                const uint64_t p = uint64_t(i) + (kk.rc ? (d.k - d.m) - kk.pos : kk.pos);
+                const uint64_t p = uint64_t(i) + (kk.rc ? (d.k - d.sk.m) - kk.pos : kk.pos);
                 val = (p << 1) | (kk.rc ? 1u : 0u);
             }
         }
@@ -71,7 +71,7 @@ sk_scan_kernel(const dict_view d, const uint64_t first_wave, const uint64_t num_
             const uint64_t at = offsets[wave] + uint64_t(__popcll(ballot & ((uint64_t(1) << lane) - 1)));
             const uint64_t later = lane < 63 ? ballot >> (lane + 1) : 0;
             const uint32_t run = later ? uint32_t(__ffsll((unsigned long long)later)) : WAVE - lane;  // k-mers up to the next start
-            const uint32_t most = d.k - d.m + 1;
+            const uint32_t most = d.k - d.sk.m + 1;
             keys[at] = key;
             vals[at] = val | (uint64_t(run < most ? run : most) << SK_LEN_SHIFT);
         }
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256)
 sk_heavy_kmers_kernel(const dict_view d, const uint64_t first_tuple, const uint64_t num_tuples, const uint8_t* __restrict__ flags,
                       const uint64_t* __restrict__ occ, unsigned long long* __restrict__ cursor, uint64_t* __restrict__ item_keys,
                       uint64_t* __restrict__ item_vals) {
-    const uint32_t km = d.k - d.m, per = km + 1;
+    const uint32_t km = d.k - d.sk.m, per = km + 1;
     const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const uint64_t t = first_tuple + g / per;
     const uint32_t a = uint32_t(g % per);
@@ -180,7 +180,7 @@ sk_heavy_kmers_kernel(const dict_view d, const uint64_t first_tuple, const uint6
             const window_t<W> w = read_window<W>(d.granules, p + a - km, d.k);
             if (!w.crosses) {
                 const kmer_w<W> x = w.kmer, x_rc = kmer_revcomp<W>(x, d.k);
-                const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.m);
+                const sk_key_t kk = sk_key<W>(x, x_rc, d.k, d.sk.m);
                 if (sk_usable(d, kk)) {
                     const uint64_t q = (p + a - km) + (kk.rc ? km - kk.pos : kk.pos);  // where this k-mer's key occurrence lies
                     mine = q == p && (kk.rc ? 1u : 0u) == uint32_t(v & 1);
@@ -250,7 +250,7 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
                 } else {
                     placed[t] = 1;
                     used = true;
-                    const uint64_t start = ((item_vals[t] & SK_VAL_MASK) >> 1) + (item_vals[t] >> SK_LEN_SHIFT) - (d.k - d.m);
+                    const uint64_t start = ((item_vals[t] & SK_VAL_MASK) >> 1) + (item_vals[t] >> SK_LEN_SHIFT) - (d.k - d.sk.m);
                     const window_t<1> w = read_window<1>(d.granules, start, d.k);
                     uint32_t* E = B + 1 + SK_KMER_ENTRY_WORDS * mine;
                     E[0] = uint32_t(w.kmer.w[0]);
@@ -299,18 +299,18 @@ sk_place_kernel(const dict_view d, const uint32_t choice, const uint64_t num_ite
                 const uint64_t v = item_vals[t] & SK_VAL_MASK;
                 const uint64_t p = v >> 1;
                 if constexpr (COMPACT) {
-                    const uint64_t start = p + (item_vals[t] >> SK_LEN_SHIFT) - (d.k - d.m);
+                    const uint64_t start = p + (item_vals[t] >> SK_LEN_SHIFT) - (d.k - d.sk.m);
                     const window_t<W> w = read_window<W>(d.granules, start, d.k);
                     meta = 0;
                     d1 = w.string_id;
                     w1 = start | (uint64_t(h.fingerprint) << 40);
                     for (int i = 0; i < W; ++i) body[i] = w.kmer.w[i];
                 } else if (kind == SK_ITEM_INLINE) {
-                    const uint32_t km = d.k - d.m;
+                    const uint32_t km = d.k - d.sk.m;
                     const uint32_t sid = read_window<W>(d.granules, p, 1).string_id;
                     const uint64_t s_begin = d.endpoints[sid], s_end = d.endpoints[sid + 1];
                     const uint64_t left = p - s_begin < km ? p - s_begin : km;
-                    const uint64_t right = s_end - (p + d.m) < km ? s_end - (p + d.m) : km;
+                    const uint64_t right = s_end - (p + d.sk.m) < km ? s_end - (p + d.sk.m) : km;
                     meta = (uint32_t(v & 1) ? SK_STRAND : 0u) | (uint32_t(left) << SK_LEFT_SHIFT) | (uint32_t(right) << SK_RIGHT_SHIFT);
                     d1 = sid;
                     w1 = p | (uint64_t(h.fingerprint) << 40);
@@ -377,12 +377,39 @@ uint64_t hbm_budget() {
     return 0;
 }
 
+/* Length of the table's key m-mers (sk_view::m). The table elects its own key, so this need not be the dictionary's m:
+     k <= 31  the dictionary's m. Same-box sweep on C3 (m = 21; profiles/r04/table_key_length_sweep.txt): shorter keys make fewer,
+              longer super-k-mers but put more k-mers under heavy keys -- 19: 15.7 B/k-mer instead of 16.8 for -3 % (streaming
+              query -10 %), 17: 15.5 for -8 %, 15: worse on both counts --, longer keys the opposite (23: 18.9 B/k-mer for +2-5 %);
+     k > 31   at least k - 32, so that a super-k-mer holds at most 33 k-mers: C4 (k = 63, m = 25 -> 31) has 166 M k-mers under heavy
+              keys instead of 271 M and 64 candidates to elect instead of 78 -- 13.35 B/k-mer instead of 13.86, lookups +2 %, the
+              streaming query 31.5 -> 35.6 G k-mers/s (profiles/r04/table_key_length_sweep_c4.txt).
+   SSHASH_AMD_SK_M asks for another one: between 12 (the election hashes an occurrence's first 12 bases) and min(k - 1, 31) (a key
+   is one word, and all ones means no key), and long enough that a super-k-mer's 2k - m bases fit a slot's 64 (k <= 31) or 128
+   (k <= 63). Every rank of a sharded lookup must use the same. */
+uint32_t sk_table_m(uint32_t k, uint32_t m) {
+    const uint32_t bases_in_slot = k <= 31 ? 64 : 128;
+    uint32_t lowest = 12;
+    if (2 * k > bases_in_slot + lowest) lowest = 2 * k - bases_in_slot;
+    if (k - lowest > 62) lowest = k - 62;  // positions take six bits
+    const uint32_t highest = k - 1 < 31 ? k - 1 : 31;
+    uint32_t chosen = m;
+    if (k > 31 && m + 32 < k) chosen = k - 32;
+    if (chosen < lowest || chosen > highest) chosen = m;  // (cannot happen for k <= 63; a dictionary's own m is always usable)
+    if (const char* e = std::getenv("SSHASH_AMD_SK_M")) {  // measurement knob, tests
+        const uint32_t want = uint32_t(std::atoi(e));
+        if (want >= lowest && want <= highest) chosen = want;
+    }
+    return chosen;
+}
+
 void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_shards, uint32_t table_shard_id) {
     dict_view& v = rep.view;
     v.sk.slots = nullptr;
     v.sk.num_buckets = 0;
     v.sk.kmer_buckets = 0;
     v.sk.enabled = 0;
+    v.sk.m = sk_table_m(idx.k, idx.m);  // (before any return: the routing kernel of a table-sharded lookup elects keys on a replica without a table too)
     v.sk.num_shards = table_shards;  // read by the scan kernel's filter
     v.sk.shard_id = table_shard_id;
     const char* env = std::getenv("SSHASH_AMD_SKTABLE");
@@ -439,9 +466,9 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     uint64_t* occ = tmp.alloc<uint64_t>(T);
     {
         size_t bytes = 0;
-        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys_sorted, vals, occ, int(T), 0, int(2 * idx.m)));
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys_sorted, vals, occ, int(T), 0, int(2 * v.sk.m)));
         void* scratch = tmp.alloc<uint8_t>(bytes);
-        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(scratch, bytes, keys, keys_sorted, vals, occ, int(T), 0, int(2 * idx.m)));
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(scratch, bytes, keys, keys_sorted, vals, occ, int(T), 0, int(2 * v.sk.m)));
         HIP_CHECK(hipDeviceSynchronize());
         tmp.release(scratch);
     }
@@ -485,7 +512,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     tmp.release(keys);
     /* the k-mers of the heavy keys, keyed one by one: count, then emit. A launch of 2^32 threads or more is not carried
        out (and reports no error), so the tuples are walked in pieces. */
-    const uint64_t per = idx.k - idx.m + 1;
+    const uint64_t per = idx.k - v.sk.m + 1;
     const uint64_t tuples_per_launch = (uint64_t(1) << 30) / per;
     auto heavy_pass = [&](bool emit, unsigned long long* cursor, uint64_t* item_keys, uint64_t* item_vals) {
         for (uint64_t first = 0; first < T; first += tuples_per_launch) {
@@ -548,7 +575,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
        matters: a query is a k-mer, and an item answers as many queries as its super-k-mer holds k-mers (1 .. k-m+1, a
        quarter of them the full k-m+1). Served in order of length, the overflowing 7.2 % of the items hold 3.9 % of the
        k-mers instead of 7.2 % -- that many fewer positive queries need a second bucket (resume pass). */
-    const uint32_t most = idx.k - idx.m + 1;
+    const uint32_t most = idx.k - v.sk.m + 1;
     const uint32_t turns[3][2] = {{(7 * most + 9) / 10, 63u}, {(35 * most + 99) / 100, (7 * most + 9) / 10 - 1}, {0u, (35 * most + 99) / 100 - 1}};
     uint32_t* kmer_slots = slots + key_buckets * SK_BUCKET_SLOTS * (slot_bytes / 4);  // the k-mers' region
     auto place = [&](uint32_t choice, uint32_t lo, uint32_t hi, bool with_heavy_kmers) {

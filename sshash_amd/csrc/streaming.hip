@@ -142,8 +142,8 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
         sk_line_cache line_cache;
         sk_roll_state roll;
         sk_roll1_state roll1;
-        if constexpr (ROLL && PAIRS) sk_roll_start(roll, k, d.m);
-        if constexpr (ROLL && !PAIRS) sk_roll1_start(roll1, k, d.m);
+        if constexpr (ROLL && PAIRS) sk_roll_start(roll, k, d.sk.m);
+        if constexpr (ROLL && !PAIRS) sk_roll1_start(roll1, k, d.sk.m);
         uint64_t c_idx = ~uint64_t(0) - 1, c_b0 = 0, c_b1 = 0, c_marks = 0;  // (neither c_idx nor c_idx + 1 is a block)
         auto string_base = [&](uint64_t pb, uint32_t& base, bool& starts) {
             const uint64_t idx = pb >> 5;
@@ -220,9 +220,9 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
             x_rc = kmer_roll_rc<W>(x_rc, code, k);
             valid_len = base_is_valid(c) ? valid_len + 1 : 0;
             if constexpr (ROLL) {
-                if (j + 1 >= d.m) {
-                    if constexpr (PAIRS) sk_roll_push<W>(roll, x, x_rc, k, d.m, column);
-                    else sk_roll1_push<W>(roll1, x, x_rc, k, d.m, column1);
+                if (j + 1 >= d.sk.m) {
+                    if constexpr (PAIRS) sk_roll_push<W>(roll, x, x_rc, k, d.sk.m, column);
+                    else sk_roll1_push<W>(roll1, x, x_rc, k, d.sk.m, column1);
                 }
             }
             if (j + 1 < k) continue;
@@ -253,11 +253,11 @@ streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, cons
             if constexpr (SK) {
                 sk_key_t kk;
                 if constexpr (ROLL && PAIRS) {
-                    kk = sk_roll_key<W>(roll, x, x_rc, k, d.m);
+                    kk = sk_roll_key<W>(roll, x, x_rc, k, d.sk.m);
                 } else if constexpr (ROLL) {
-                    if (!sk_roll1_key<W>(roll1, x, x_rc, k, d.m, kk)) kk = sk_key<W>(x, x_rc, k, d.m);  // equal hash prefixes: rare
+                    if (!sk_roll1_key<W>(roll1, x, x_rc, k, d.sk.m, kk)) kk = sk_key<W>(x, x_rc, k, d.sk.m);  // equal hash prefixes: rare
                 } else {
-                    kk = sk_key<W>(x, x_rc, k, d.m);
+                    kk = sk_key<W>(x, x_rc, k, d.sk.m);
                 }
                 if (sk_usable(d, kk)) {
                     if (neg_unknown_mini && kk.key == prev_f) {
@@ -321,7 +321,7 @@ void launch_streaming(dict_view const& d, skew_part_dev const* skew, char const*
     const uint32_t block = 256;
     uint64_t blocks = (n_reads + block - 1) / block;
     if (blocks > (uint64_t(1) << 20)) blocks = uint64_t(1) << 20;
-    const uint32_t roll_bytes = (d.k - d.m + 1) * block * uint32_t(W == 1 ? sizeof(uint2) : sizeof(uint32_t));
+    const uint32_t roll_bytes = (d.k - d.sk.m + 1) * block * uint32_t(W == 1 ? sizeof(uint2) : sizeof(uint32_t));
     /* SSHASH_AMD_STREAM_ROLLING: 0 = every seed elects its key from scratch (sk_key), as until round 4; 1 = incrementally wherever the
        LDS allows. Default: incrementally at k <= 31 (high-hit reads 44.0 -> 48.9 G k-mers/s, random reads 82 -> 104); at k <= 63 only
        on request -- random reads gain as much (63 -> 78) but reads that hit lose 3-4 % (31.7 -> 30.8 on config C4's set): there a

@@ -23,6 +23,8 @@ SETTINGS = [
     ("overlap_always_resume_pass", {"SSHASH_AMD_OVERLAP": "1", "SSHASH_AMD_INWAVE": "0"}, 3),
     ("packed_table", {"SSHASH_AMD_SK_SLOTS_PER_KEY": "1.4", "SSHASH_AMD_SK_SLOTS_PER_KMER": "1.3"}, 3),
     ("small_pieces", {"SSHASH_AMD_PIECE": "1000000"}, 3),
+    ("table_key_17", {"SSHASH_AMD_SK_M": "17"}, 3),   # the table's own key length (sk_view::m): shorter and longer than the
+    ("table_key_25", {"SSHASH_AMD_SK_M": "25"}, 3),   # dictionary's minimizers (m = 21 here)
     ("directory", {"SSHASH_AMD_SKTABLE": "0", "SSHASH_AMD_DIRECTORY": "1"}, 3),
     ("mphf", {"SSHASH_AMD_SKTABLE": "0", "SSHASH_AMD_DIRECTORY": "0"}, 3),
 ]
