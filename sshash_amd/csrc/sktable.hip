@@ -382,7 +382,7 @@ uint64_t hbm_budget() {
               longer super-k-mers but put more k-mers under heavy keys -- 19: 15.7 B/k-mer instead of 16.8 for -3 % (streaming
               query -10 %), 17: 15.5 for -8 %, 15: worse on both counts --, longer keys the opposite (23: 18.9 B/k-mer for +2-5 %);
      k > 31   at least k - 32, so that a super-k-mer holds at most 33 k-mers: C4 (k = 63, m = 25 -> 31) has 166 M k-mers under heavy
-              keys instead of 271 M and 64 candidates to elect instead of 78 -- 13.35 B/k-mer instead of 13.86, lookups +2 %, the
+              keys instead of 271 M and 66 candidates to elect instead of 78 -- 13.35 B/k-mer instead of 13.86, lookups +2 %, the
               streaming query 31.5 -> 35.6 G k-mers/s (profiles/r04/table_key_length_sweep_c4.txt).
    SSHASH_AMD_SK_M asks for another one: between 12 (the election hashes an occurrence's first 12 bases) and min(k - 1, 31) (a key
    is one word, and all ones means no key), and long enough that a super-k-mer's 2k - m bases fit a slot's 64 (k <= 31) or 128
