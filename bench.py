@@ -281,11 +281,32 @@ def traffic_record(d, n_local: int, args):
                                             "counters": rec.get("counters"), "note": rec.get("note"), "source": rec.get("source")}
 
 
+def random_line_probe():
+    """What THIS box's memory system sustains when a kernel does nothing but one random 64-byte read per lane group: tools/tlb_probe
+    (built by `make -C sshash_amd/csrc`), 2^27 independent reads of a 32 GiB array, every line fetched by four adjacent lanes with one
+    load instruction -- the access pattern of the table's bucket fetch. The boxes of the pool differ by 10 % on the headline; this
+    puts the line's own box under roofline.random_unit_bound next to the figure the constant above was calibrated with. A side
+    measurement in a process of its own, after everything else."""
+    tool = os.path.join(ROOT, "tools", "tlb_probe")
+    if not os.path.exists(tool):
+        return {"error": "tools/tlb_probe is not built (make -C sshash_amd/csrc)"}
+    try:
+        p = subprocess.run([tool, "32768", "64", "malloc", "0", "0", str(1 << 27), "5", "coop"], capture_output=True, text=True, timeout=300)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"error": f"tools/tlb_probe: exit code {p.returncode}: {p.stderr[-300:]}"}
+        r = json.loads(lines[-1])
+        return {"probe_units_per_s": r["Greads_per_s"] * 1e9, "ms_best": r["ms_best"], "ms_avg": r["ms_avg"],
+                "what": "tools/tlb_probe 32768 64 malloc 0 0 134217728 5 coop: 2^27 random 64-byte lines of a 32 GiB array, best of 5 launches"}
+    except Exception as e:  # noqa: BLE001 -- a side measurement must not cost the line
+        return {"error": f"tools/tlb_probe: {e!r}"}
+
+
 def run_other_workload(args, extra):
     """`python bench.py --workload ...` as a child process (its own index, replica and batch; this process has released its GPU
     memory): the child's JSON line, or the reason there is none."""
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cache-dir", args.cache_dir,
-           "--seed", str(args.seed), "--no-extra-mixes", "--no-other-paths", "--no-file-query", "--no-other-workloads"] + extra
+           "--seed", str(args.seed), "--no-extra-mixes", "--no-other-paths", "--no-file-query", "--no-other-workloads", "--no-line-probe"] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     t0 = time.time()
     p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)  # (its log goes where this process's log goes)
@@ -460,6 +481,7 @@ def main():
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="default run (C3, one GPU): do not append the C2 and C4 lines (`other_workloads`: child runs of this script)")
     ap.add_argument("--other-streaming-reads", type=int, default=20_000_000, help="reads of the C4 streaming line inside `other_workloads`")
+    ap.add_argument("--no-line-probe", action="store_true", help="skip the random-line probe of this box (tools/tlb_probe; side measurement after everything else)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
     bases, recipe, queries, what = WORKLOADS[args.workload]
@@ -771,6 +793,16 @@ def main():
                 other_workloads[name] = run_other_workload(args, extra)
                 log(f"other workload {name}: {other_workloads[name].get('value')} {other_workloads[name].get('unit')}")
         result["other_workloads"] = other_workloads
+        if world == 1 and sharded is None and not args.no_line_probe and isinstance(result.get("roofline"), dict) and "random_unit_bound" in result["roofline"]:
+            log("random-line probe of this box ...")
+            probe = random_line_probe()
+            for line in [result] + [w for w in (other_workloads or {}).values() if isinstance(w, dict)]:
+                bound = (line.get("roofline") or {}).get("random_unit_bound")
+                if bound is not None:
+                    bound["this_box"] = dict(probe)
+                    if "probe_units_per_s" in probe:
+                        bound["this_box"]["frac"] = round(bound["lookups_per_s_this_gpu"] / probe["probe_units_per_s"], 4)
+            log(f"random-line probe: {probe}")
     barrier()
     if use_dist:
         dist.destroy_process_group()

@@ -151,3 +151,8 @@ def test_default_run_appends_the_other_baseline_configurations(tmp_path):
     high = others["c3_streaming_high_hit"]
     assert high["unit"] == "k-mers/s" and high["config"]["k"] == 31 and high["config"]["positive_fraction_of_kmers"] > 0.5
     assert others["c2"]["config"]["recipe"] == "se_k31" and others["c4"]["config"]["recipe"] == "human_k63"
+    # the random-line probe of the box the line was measured on (tools/tlb_probe), attached to every lookup line's random_unit_bound
+    for line in (r, others["c2"], others["c4"]):
+        box = line["roofline"]["random_unit_bound"]["this_box"]
+        assert "error" not in box, box
+        assert 2e10 < box["probe_units_per_s"] < 8e10 and box["frac"] > 0
