@@ -188,6 +188,11 @@ static_assert(SK_CHOICES == 5, "sk_hash and sk_choice spell out five choices");
 constexpr uint32_t SK_INLINE_MAX = 4;         // a key with up to this many occurrences holds one inline slot per occurrence;
                                               // a heavier key holds a marker and its k-mers are keyed one by one
 constexpr double SK_SLOTS_PER_KEY = 2.5;  // slots per item: load factor 0.4 (1.6 ... 4.0 measured)
+/* k <= 63: 3.0 (load factor 0.33). A bucket there is two lines, an item in slot 1 or past its first bucket costs a second one, and since the
+   table's keys are 31 bases long (sk_table_m) the k-mers' region is small enough to pay for it: same-box, four alternating rounds
+   (profiles/r04/slots_per_key_c4_table_key_31.txt) 2.5 -> 3.0 -> 3.5 slots = 30.0 -> 31.4 -> 32.0 G lookups/s (medians) for 13.35 -> 15.17 ->
+   16.99 B/k-mer; with the 25-base key 3.0 bought 0.5 % (slots_per_key_c4.txt) */
+constexpr double SK_SLOTS_PER_KEY_WIDE = 3.0;
 /* the same for the region of the heavy keys' k-mers (sk_view::kmer_buckets): fuller, since only the probes that met a marker pay for it.
    Same-box sweep (profiles/r03/kmer_region_load_ab.txt): C3 2.5 -> 2.0 -> 1.75 -> 1.5 slots per k-mer = 47.9 -> 45.7 -> 44.6 -> 43.5 GB and
    37.8 -> 37.6 -> 37.25 -> 36.6 G lookups/s; C4 (k = 63, 64-byte slots, 9.9 % of the k-mers under heavy keys) 66.7 -> 58.0 -> 53.6 ->

@@ -486,7 +486,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     }
     uint64_t K = 0;
     HIP_CHECK(hipMemcpy(&K, d_num_runs, 8, hipMemcpyDeviceToHost));
-    double slots_per_key = SK_SLOTS_PER_KEY;
+    double slots_per_key = wide ? SK_SLOTS_PER_KEY_WIDE : SK_SLOTS_PER_KEY;
     if (const char* e = std::getenv("SSHASH_AMD_SK_SLOTS_PER_KEY")) {  // measurement knob
         const double want = std::atof(e);
         if (want >= 1.2 && want <= 16.0) slots_per_key = want;
