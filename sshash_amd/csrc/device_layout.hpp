@@ -197,7 +197,11 @@ constexpr double SK_SLOTS_PER_KEY_WIDE = 3.0;
    Same-box sweep (profiles/r03/kmer_region_load_ab.txt): C3 2.5 -> 2.0 -> 1.75 -> 1.5 slots per k-mer = 47.9 -> 45.7 -> 44.6 -> 43.5 GB and
    37.8 -> 37.6 -> 37.25 -> 36.6 G lookups/s; C4 (k = 63, 64-byte slots, 9.9 % of the k-mers under heavy keys) 66.7 -> 58.0 -> 53.6 ->
    49.3 GB with every rate inside the box's +-3 % run-to-run spread (the first pass is bound by instructions there, not by lines). */
-constexpr double SK_SLOTS_PER_KMER_NARROW = 1.75, SK_SLOTS_PER_KMER_WIDE = 1.75;  // k <= 31 (2.0 until the entries there became three to a line: profiles/r04/kmer_region_places_sweep.txt), k <= 63
+/* k <= 63, round 4's last sweep (31-base table key, 3.0 slots per item in the keys' region; profiles/r04/kmer_region_places_c4_last_defaults.txt, a box that
+   repeats within 0.2 %): 1.75 -> 2.5 places per k-mer = 33.78 / 33.72 / 33.77 -> 34.42 / 34.37 / 34.43 G lookups/s (+1.9 %) for 15.2 -> 16.6 B/k-mer; the
+   streaming query does not see it (37.15 -> 37.2). With a third fewer k-mers there the region is cheap to loosen, and every lookup that gets to it has already
+   paid for two lines. */
+constexpr double SK_SLOTS_PER_KMER_NARROW = 1.75, SK_SLOTS_PER_KMER_WIDE = 2.5;  // k <= 31 (2.0 until the entries there became three to a line: profiles/r04/kmer_region_places_sweep.txt), k <= 63
 /* k <= 31 (round 4): a bucket of the k-mers' region is one 64-byte line of THREE entries instead of two copies of 32-byte slots --
    a k-mer entered under its own key needs the k-mer, where it lies and in which string, not its super-k-mer's 64 bases:
      dword 0          bits 0-2 entry e in use | bits 3-7 the bucket's go-on flags | bits 21-31 the first-choice filter (as slot 0)
