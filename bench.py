@@ -302,12 +302,13 @@ def random_line_probe():
         return {"error": f"tools/tlb_probe: {e!r}"}
 
 
-def run_other_workload(args, extra):
+def run_other_workload(args, extra, env_extra=None):
     """`python bench.py --workload ...` as a child process (its own index, replica and batch; this process has released its GPU
     memory): the child's JSON line, or the reason there is none."""
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cache-dir", args.cache_dir,
            "--seed", str(args.seed), "--no-extra-mixes", "--no-other-paths", "--no-file-query", "--no-other-workloads", "--no-line-probe"] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
     t0 = time.time()
     p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)  # (its log goes where this process's log goes)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -315,6 +316,8 @@ def run_other_workload(args, extra):
         return {"error": f"exit code {p.returncode}", "command": " ".join(cmd[1:])}
     line = json.loads(lines[-1])
     line["wall_s_of_the_child"] = round(time.time() - t0, 1)
+    if env_extra:
+        line["environment"] = dict(env_extra)  # a replica configured otherwise than the default (the switches)
     return line
 
 
@@ -781,16 +784,20 @@ def main():
             d.close()
             torch.cuda.empty_cache()
             other_workloads = {}
-            for name, extra in (("c2", ["--workload", "c2"]), ("c4", ["--workload", "c4"]),
-                                ("c4_streaming", ["--workload", "c4", "--streaming", "--reads", str(args.other_streaming_reads)]),
-                                # the streaming query at k = 31 in the regime the reference publishes (high-hit: 95 % of the reads spell
-                                # k-mers of the dictionary), on the headline's own dictionary
-                                ("c3_streaming_high_hit", ["--workload", "c3", "--streaming", "--positive", "0.95", "--reads", str(args.other_streaming_reads)])):
+            high_hit = ["--workload", "c3", "--streaming", "--positive", "0.95", "--reads", str(args.other_streaming_reads)]
+            for name, extra, env_extra in (("c2", ["--workload", "c2"], None), ("c4", ["--workload", "c4"], None),
+                                           ("c4_streaming", ["--workload", "c4", "--streaming", "--reads", str(args.other_streaming_reads)], None),
+                                           # the streaming query at k = 31 in the regime the reference publishes (high-hit: 95 % of the reads spell
+                                           # k-mers of the dictionary), on the headline's own dictionary
+                                           ("c3_streaming_high_hit", high_hit, None),
+                                           # the same with the replica a deployment that streams would configure: a 25-base table key (fewer seeds
+                                           # under heavy keys) for 5.7 B/k-mer more HBM -- DESIGN.md section 6; not the default
+                                           ("c3_streaming_high_hit_table_key_25", high_hit, {"SSHASH_AMD_SK_M": "25"})):
                 if reduced:
                     b_, q_, r_ = reduced.split(",")
                     extra = extra + ["--bases", b_, "--cpu-sample", "100000"] + (["--reads", r_, "--stream-oracle-reads", "5000"] if "--streaming" in extra else ["--queries", q_])
                 log(f"other workload {name} ...")
-                other_workloads[name] = run_other_workload(args, extra)
+                other_workloads[name] = run_other_workload(args, extra, env_extra)
                 log(f"other workload {name}: {other_workloads[name].get('value')} {other_workloads[name].get('unit')}")
         result["other_workloads"] = other_workloads
         if world == 1 and sharded is None and not args.no_line_probe and isinstance(result.get("roofline"), dict) and "random_unit_bound" in result["roofline"]:

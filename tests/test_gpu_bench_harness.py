@@ -141,7 +141,8 @@ def test_default_run_appends_the_other_baseline_configurations(tmp_path):
     assert len(out) == 1
     r = json.loads(out[0])
     others = r["other_workloads"]
-    assert set(others) == {"c2", "c4", "c4_streaming", "c3_streaming_high_hit"}
+    assert set(others) == {"c2", "c4", "c4_streaming", "c3_streaming_high_hit", "c3_streaming_high_hit_table_key_25"}
+    assert others["c3_streaming_high_hit_table_key_25"]["environment"] == {"SSHASH_AMD_SK_M": "25"} and "environment" not in others["c3_streaming_high_hit"]
     for name, line in others.items():
         assert "error" not in line, line
         for key in CONTRACT:
