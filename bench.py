@@ -281,7 +281,7 @@ def traffic_record(d, n_local: int, args):
                                             "counters": rec.get("counters"), "note": rec.get("note"), "source": rec.get("source")}
 
 
-def random_line_probe():
+def random_line_probe(device=None):
     """What THIS box's memory system sustains when a kernel does nothing but one random 64-byte read per lane group: tools/tlb_probe
     (built by `make -C sshash_amd/csrc`), 2^27 independent reads of a 32 GiB array, every line fetched by four adjacent lanes with one
     load instruction -- the access pattern of the table's bucket fetch. The boxes of the pool differ by 10 % on the headline; this
@@ -291,7 +291,11 @@ def random_line_probe():
     if not os.path.exists(tool):
         return {"error": "tools/tlb_probe is not built (make -C sshash_amd/csrc)"}
     try:
-        p = subprocess.run([tool, "32768", "64", "malloc", "0", "0", str(1 << 27), "5", "coop"], capture_output=True, text=True, timeout=300)
+        env = dict(os.environ)
+        if device is not None:  # (a rank of an N > 1 run: its own GPU, whatever the launcher's visibility list was)
+            visible = [v for v in env.get("HIP_VISIBLE_DEVICES", "").split(",") if v]
+            env["HIP_VISIBLE_DEVICES"] = visible[device] if device < len(visible) else str(device)
+        p = subprocess.run([tool, "32768", "64", "malloc", "0", "0", str(1 << 27), "5", "coop"], capture_output=True, text=True, timeout=300, env=env)
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
         if p.returncode != 0 or not lines:
             return {"error": f"tools/tlb_probe: exit code {p.returncode}: {p.stderr[-300:]}"}
@@ -305,16 +309,19 @@ def random_line_probe():
 def run_other_workload(args, extra, env_extra=None):
     """`python bench.py --workload ...` as a child process (its own index, replica and batch; this process has released its GPU
     memory): the child's JSON line, or the reason there is none."""
+    record = os.path.join(args.cache_dir, f"sshash_amd_bench_child_{os.getpid()}.json")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cache-dir", args.cache_dir,
-           "--seed", str(args.seed), "--no-extra-mixes", "--no-other-paths", "--no-file-query", "--no-other-workloads", "--no-line-probe"] + extra
+           "--seed", str(args.seed), "--no-extra-mixes", "--no-other-paths", "--no-file-query", "--no-other-workloads", "--no-line-probe",
+           "--full-record", record, "--quiet-record"] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra or {})
     t0 = time.time()
     p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)  # (its log goes where this process's log goes)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    if p.returncode != 0 or not lines:
+    if p.returncode != 0 or not lines or not os.path.exists(record):
         return {"error": f"exit code {p.returncode}", "command": " ".join(cmd[1:])}
-    line = json.loads(lines[-1])
+    line = json.load(open(record))  # the child's FULL record (its stdout line is the compact form of it)
+    os.remove(record)
     line["wall_s_of_the_child"] = round(time.time() - t0, 1)
     if env_extra:
         line["environment"] = dict(env_extra)  # a replica configured otherwise than the default (INTEGRATION.md: the switches)
@@ -426,6 +433,9 @@ def streaming_mode(args, d, index_path, rank, world, local_rank, dev, use_dist, 
         "config": {"workload": f"{WORKLOADS[args.workload][3]}, k={k} m={d.m()} {'canonical' if d.canonical() else 'regular'}, {d.num_kmers()} k-mers; "
                                f"streaming_query over ONE set of {args.reads} reads x {L} bases ({args.positive:.0%} spell k-mers of the dictionary with 1 % "
                                f"substitutions, the rest random; N at 1e-3), read-sharded over {world} GPU(s), index replicated",
+                   "workload_short": f"{args.workload.upper()} stand-in, k={k} m={d.m()} {'canonical' if d.canonical() else 'regular'}, {d.num_kmers()} k-mers; streaming_query "
+                                     f"over ONE set of {args.reads} reads x {L} bases ({args.positive:.0%} from the dictionary with 1 % substitutions, rest random, N at "
+                                     f"1e-3), read-sharded over {world} GPU(s), index replicated",
                    "reads": args.reads, "read_length": L, "reads_per_gpu": n, "k": k, "m": d.m(), "canonical": d.canonical(), "num_kmers": d.num_kmers(),
                    "device_index_bytes": d.device_bytes(local_rank), "report": rep,
                    "positive_fraction_of_kmers": round(rep["num_positive_kmers"] / rep["num_kmers"], 4),
@@ -485,6 +495,9 @@ def main():
                     help="default run (C3, one GPU): do not append the C2 and C4 lines (`other_workloads`: child runs of this script)")
     ap.add_argument("--other-streaming-reads", type=int, default=20_000_000, help="reads of the C4 streaming line inside `other_workloads`")
     ap.add_argument("--no-line-probe", action="store_true", help="skip the random-line probe of this box (tools/tlb_probe; side measurement after everything else)")
+    ap.add_argument("--full-record", default=os.path.join(ROOT, "bench_full.json"),
+                    help="where rank 0 writes the FULL record (children, histograms, per-step times, the rules in prose); stdout carries the compact line")
+    ap.add_argument("--quiet-record", action="store_true", help="do not echo the full record on stderr")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
     bases, recipe, queries, what = WORKLOADS[args.workload]
@@ -572,16 +585,17 @@ def main():
             d.to_device(local_rank)  # (the complete dictionary: used to draw the queries)
     else:
         d.to_device(local_rank)
+    upload_window = (t0, time.time())  # wall clock of this node: the ranks' uploads must overlap, not queue (per_rank)
     stats = d.device_stats(local_rank)
     if rank == 0:
-        log(f"replica in HBM: {d.device_bytes(local_rank) / 1e6:.0f} MB (upload {time.time() - t0:.1f}s); {stats}")
+        log(f"replica in HBM: {d.device_bytes(local_rank) / 1e6:.0f} MB (upload {upload_window[1] - t0:.1f}s); {stats}")
 
     if args.streaming:
         result = streaming_mode(args, d, index_path, rank, world, local_rank, dev, use_dist, dist, coll_dev, barrier, stats)
         barrier()
         if use_dist:
             dist.destroy_process_group()
-        emit(json_fd, rank, result)
+        emit(json_fd, rank, result, args)
         return
 
     # this rank's share of the batch
@@ -621,17 +635,25 @@ def main():
     elapsed = time.perf_counter() - t_begin
     kernel_ms = [starts[i].elapsed_time(stops[i]) for i in range(args.steps)]
     avg_kernel_ms = float(np.mean(kernel_ms))
-    per_rank = [{"rank": 0, "queries": n, "ms_per_step": round(own_elapsed / args.steps * 1e3, 3), "kernel_ms_per_step": round(avg_kernel_ms, 3)}]
+    per_rank = [{"rank": 0, "queries": n, "ms_per_step": round(own_elapsed / args.steps * 1e3, 3), "kernel_ms_per_step": round(avg_kernel_ms, 3),
+                 "upload_s": round(upload_window[1] - upload_window[0], 2)}]
     kernel_ms_steps = [round(float(t), 3) for t in kernel_ms]  # rank 0's steps one by one: sustained load drifts (clocks), see DESIGN.md section 6
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([float(n), own_elapsed / args.steps * 1e3, avg_kernel_ms], dtype=torch.float64, device=coll_dev)
+        # every rank's own GPU under the random-line probe (the boxes -- and the GPUs of one node -- differ by several per cent): after
+        # the timed region, all ranks at once, each on its own device
+        probe = {} if (args.no_line_probe or world == 1) else random_line_probe(device=local_rank)
+        mine = torch.tensor([float(n), own_elapsed / args.steps * 1e3, avg_kernel_ms, upload_window[0], upload_window[1],
+                             float(probe.get("probe_units_per_s", 0.0))], dtype=torch.float64, device=coll_dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
+        first = min(float(v[3].item()) for v in every)
         per_rank = [{"rank": r, "queries": int(v[0].item()), "ms_per_step": round(float(v[1].item()), 3),
-                     "kernel_ms_per_step": round(float(v[2].item()), 3)} for r, v in enumerate(every)]
+                     "kernel_ms_per_step": round(float(v[2].item()), 3), "upload_s": round(float((v[4] - v[3]).item()), 2),
+                     "upload_window_s": [round(float(v[3].item()) - first, 2), round(float(v[4].item()) - first, 2)],
+                     "random_line_probe_units_per_s": float(v[5].item()) or None} for r, v in enumerate(every)]
 
     # ---- parity spot check + algorithmic bytes (oracle = checker only) ---------------------------
     result = None
@@ -761,6 +783,11 @@ def main():
                                    f"every GPU's HBM; ONE batch of {args.queries} packed queries per step "
                                    f"({args.positive:.0%} positive, half of them reverse-complemented; negatives: {args.negatives}) "
                                    f"split over {world} GPU(s)",
+                       "workload_short": f"{args.workload.upper()} stand-in (recipe {args.recipe}: bucket statistics fitted to the reference's build log), k={d.k()} m={d.m()} "
+                                         f"{'canonical' if d.canonical() else 'regular'}, {d.num_kmers()} k-mers, index replicated per GPU; ONE batch of "
+                                         f"{args.queries} packed queries per step ({args.positive:.0%} positive, half reverse-complemented; negatives {args.negatives}) "
+                                         f"split over {world} GPU(s)",
+                       "ids_equal_oracle_on_queries": sample,
                        "queries_per_step": args.queries, "queries_per_gpu": n, "num_kmers": d.num_kmers(), "k": d.k(), "m": d.m(),
                        "canonical": d.canonical(), "index_replicated_per_gpu": sharded is None, "sharded": args.sharded,
                        "positive_fraction_found": round(found, 4), "device_index_bytes": d.device_bytes(local_rank),
@@ -770,6 +797,7 @@ def main():
             "per_rank": per_rank,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_note": None if cpu is not None or args.no_cpu_baseline else "the CPU path is timed by the N = 1 run only (rank 0, this box's host cores): see that run's line",
             "other_mixes": extra,
             "other_paths": other_paths,
             "streaming_from_file": from_file,
@@ -789,10 +817,7 @@ def main():
                                            ("c4_streaming", ["--workload", "c4", "--streaming", "--reads", str(args.other_streaming_reads)], None),
                                            # the streaming query at k = 31 in the regime the reference publishes (high-hit: 95 % of the reads spell
                                            # k-mers of the dictionary), on the headline's own dictionary
-                                           ("c3_streaming_high_hit", high_hit, None),
-                                           # the same with the replica a deployment that streams would configure: a 25-base table key (fewer seeds
-                                           # under heavy keys) for 5.7 B/k-mer more HBM -- DESIGN.md section 6; not the default
-                                           ("c3_streaming_high_hit_table_key_25", high_hit, {"SSHASH_AMD_SK_M": "25"})):
+                                           ("c3_streaming_high_hit", high_hit, None)):
                 if reduced:
                     b_, q_, r_ = reduced.split(",")
                     extra = extra + ["--bases", b_, "--cpu-sample", "100000"] + (["--reads", r_, "--stream-oracle-reads", "5000"] if "--streaming" in extra else ["--queries", q_])
@@ -813,11 +838,85 @@ def main():
     barrier()
     if use_dist:
         dist.destroy_process_group()
-    emit(json_fd, rank, result)
+    emit(json_fd, rank, result, args)
 
 
-def emit(json_fd, rank, result):
-    """stdout back in place; rank 0 prints the ONE JSON line"""
+STDOUT_LINE_LIMIT = 8192  # bytes; the driver parses the ONE stdout line, and a line that outgrows its buffer is a lost measurement
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_roofline(roof):
+    """The roofline object of the stdout line: the contract's six keys plus the few numbers they were computed from. The prose
+    (rules, kernel descriptions, provenance) and the per-step times stay in the full record."""
+    if not isinstance(roof, dict):
+        return roof
+    out = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms", "launches_per_step", "algorithmic_bytes_per_lookup",
+                       "algorithmic_bytes_per_kmer", "frac_hbm_traffic", "hbm_traffic_bytes_per_lookup", "hbm_traffic_bytes_per_kmer"))
+    out["kernel"] = str(roof.get("kernel", "")).split(" (")[0][:96]
+    bound = roof.get("random_unit_bound")
+    if isinstance(bound, dict):
+        box = bound.get("this_box") or {}
+        out["random_line_bound"] = {"units_per_s_this_box": box.get("probe_units_per_s"), "frac_this_box": box.get("frac"),
+                                    "units_per_s_r02_constant": bound.get("probe_units_per_s"), "frac_r02_constant": bound.get("frac")}
+    return out
+
+
+def compact_cpu(cpu):
+    if not isinstance(cpu, dict):
+        return cpu
+    out = _pick(cpu, ("value", "unit", "cores", "kind", "single_thread_value", "measured_in"))
+    out["sample"] = str(cpu.get("sample", ""))[:160]
+    return out
+
+
+def compact_line(full, record_path):
+    """What goes to stdout: the task contract's keys, `roofline`, `cpu_baseline`, the per-rank times, and one short entry per side
+    measurement -- a few hundred bytes each. Everything else (index statistics, table histogram, device_stats, per-step kernel
+    times, the complete child lines, the rules in prose) is in the full record at `record_path`."""
+    if full is None:
+        return None
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = full.get("config", {})
+    line["config"] = _pick(cfg, ("queries_per_step", "queries_per_gpu", "reads", "read_length", "reads_per_gpu", "num_kmers", "k", "m", "canonical",
+                                 "index_replicated_per_gpu", "sharded", "positive_fraction_found", "positive_fraction_of_kmers", "extensions_per_search",
+                                 "counters_equal_oracle_on_reads", "ids_equal_oracle_on_queries", "device_index_bytes", "device_bytes_per_kmer", "recipe",
+                                 "report"))
+    line["config"] = {"workload": str(cfg.get("workload_short") or cfg.get("workload", ""))[:400], **line["config"]}
+    line["per_rank"] = [_pick(r, ("rank", "queries", "reads", "ms_per_step", "kernel_ms_per_step", "random_line_probe_units_per_s")) for r in full.get("per_rank") or []]
+    line["roofline"] = compact_roofline(full.get("roofline"))
+    line["cpu_baseline"] = compact_cpu(full.get("cpu_baseline"))
+    if full.get("cpu_baseline_note"):
+        line["cpu_baseline_note"] = full["cpu_baseline_note"]
+    if full.get("other_mixes"):
+        line["other_mixes"] = {k: v.get("lookups_per_s") for k, v in full["other_mixes"].items()}
+    if full.get("other_paths"):
+        line["other_paths"] = {k: _pick(v, ("lookups_per_s", "roofline_frac", "ids_equal_table_path", "hbm_traffic_bytes_per_lookup")) for k, v in full["other_paths"].items()}
+    f = full.get("streaming_from_file")
+    if f:
+        line["streaming_from_file"] = {fl: {"ns_per_kmer": f[fl]["ns_per_kmer"]} for fl in ("fastq", "fastq.gz", "bgzf.fastq.gz") if fl in f}
+        line["streaming_from_file"]["counters_equal_oracle_on_sample"] = f.get("counters_equal_oracle_on_sample")
+    if full.get("other_workloads"):
+        line["other_workloads"] = {}
+        for name, w in full["other_workloads"].items():
+            if not isinstance(w, dict) or "error" in w:
+                line["other_workloads"][name] = w
+                continue
+            roof, cpu, wcfg = w.get("roofline") or {}, w.get("cpu_baseline") or {}, w.get("config") or {}
+            line["other_workloads"][name] = {
+                "value": w.get("value"), "unit": w.get("unit"), "ms_per_step": w.get("ms_per_step"), "steps": w.get("steps"),
+                "roofline_frac": roof.get("frac"), "frac_hbm_traffic": roof.get("frac_hbm_traffic"), "traffic": roof.get("traffic"),
+                "cpu_baseline_value": cpu.get("value"), "cpu_cores": cpu.get("cores"),
+                # every child compares its own results with the oracle before it prints (a mismatch is exit code 1 = "error" here)
+                "parity": "ids equal oracle" if "ids_equal_oracle_on_queries" in wcfg else ("counters equal oracle" if "counters_equal_oracle_on_reads" in wcfg else None)}
+    line["full_record"] = record_path
+    return line
+
+
+def emit(json_fd, rank, result, args):
+    """stdout back in place; rank 0 writes the full record to --full-record (and to stderr) and prints the ONE compact JSON line."""
     sys.stdout.flush()
     try:
         import ctypes
@@ -826,8 +925,33 @@ def emit(json_fd, rank, result):
     except Exception:
         pass
     os.dup2(json_fd, 1)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    if rank != 0:
+        return
+    path = args.full_record
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(result, fh)
+            fh.write("\n")
+    except OSError as e:  # a read-only checkout must not cost the line
+        log(f"full record not written to {path}: {e!r}")
+        path = None
+    line = compact_line(result, path and os.path.relpath(path, ROOT) if path and os.path.abspath(path).startswith(ROOT) else path)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= STDOUT_LINE_LIMIT:  # never silently: shed the side measurements, keep the contract
+        log(f"stdout line of {len(text)} bytes exceeds {STDOUT_LINE_LIMIT}: side measurements dropped from it (they are in the full record)")
+        for key in ("other_workloads", "streaming_from_file", "other_paths", "other_mixes", "per_rank"):
+            line.pop(key, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < STDOUT_LINE_LIMIT:
+                break
+    if not args.quiet_record:
+        print("[bench] full record: " + json.dumps(result), file=sys.stderr, flush=True)
+    if result is not None:
+        roof = result.get("roofline") or {}
+        log(f"headline {args.workload}{' streaming' if args.streaming else ''}: {result['value']:.4g} {result['unit']}, {result['ms_per_step']} ms/step, "
+            f"frac {roof.get('frac')}, n_gpus {result['n_gpus']}; full record: {path}")
+    print(text, flush=True)
 
 
 if __name__ == "__main__":

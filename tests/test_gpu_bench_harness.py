@@ -1,5 +1,6 @@
 """GPU: bench.py as the driver runs it -- `python bench.py --gpus N --steps K --warmup W` -- on a reduced workload:
-one JSON line on stdout with the contract's fields, the roofline and cpu_baseline objects at N = 1, and the N = 2 harness
+ONE compact JSON line on stdout (< 8 KB: the driver's parser lost round 4's 34 KB line) with the contract's fields, the roofline and
+cpu_baseline objects at N = 1; the full record (children, histograms, per-step times) in the file --full-record names; and the N = 2 harness
 (self-launched ranks, index built once, the batch split, MAX-reduced time, per-rank times) with both ranks on the one GPU of
 the test box."""
 from __future__ import annotations
@@ -20,21 +21,52 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "data", "config", "roofline", "cpu_baseline")
 
 
-def run_bench(extra, env_extra, tmp_path):
+LINE_LIMIT = 8192
+
+
+def run(args, env_extra, tmp_path, timeout=1200):
+    """bench.py with `args`: (the stdout line, the full record). The line is the ONE line of stdout, below the limit, carries the
+    contract, and every number it repeats equals the full record's; stderr's tail names the headline."""
     env = dict(os.environ, SSHASH_BENCH_CACHE=str(tmp_path), **env_extra)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, env=env, capture_output=True, text=True, timeout=1200)
+    record = os.path.join(str(tmp_path), "bench_full.json")
+    if os.path.exists(record):
+        os.remove(record)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--full-record", record], env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}: {p.stdout[:500]}"
-    return json.loads(lines[0])
+    assert len(lines[0]) < LINE_LIMIT, f"the stdout line has {len(lines[0])} bytes"
+    line, full = json.loads(lines[0]), json.load(open(record))
+    for key in CONTRACT:
+        assert key in line, key
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[key] == full[key], key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in line["roofline"] and line["roofline"][key] == full["roofline"][key], key
+    assert (line["cpu_baseline"] is None) == (full["cpu_baseline"] is None)
+    if line["cpu_baseline"] is not None:
+        for key in ("value", "unit", "cores", "kind", "sample"):
+            assert key in line["cpu_baseline"], key
+        assert line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    assert "workload" in line["config"] and "model" not in line["config"]
+    for heavy in ("index_statistics", "table_histogram", "device_stats"):
+        assert heavy not in line["config"], heavy
+    assert "kernel_ms_steps" not in line["roofline"]
+    tail = p.stderr[-600:]
+    assert "[bench] headline" in tail and f"{full['ms_per_step']} ms/step" in tail, tail  # whatever tail a log keeps carries the number
+    return line, full
+
+
+def run_bench(extra, env_extra, tmp_path):
+    return run(SMALL + extra, env_extra, tmp_path)
 
 
 def test_one_gpu_line_carries_the_contract(tmp_path):
-    r = run_bench([], {}, tmp_path)
-    for key in CONTRACT:
-        assert key in r, key
+    line, r = run_bench([], {}, tmp_path)
+    assert set(line["other_mixes"]) == set(r["other_mixes"]) and set(line["other_paths"]) == {"directory", "mphf"}
+    assert line["streaming_from_file"]["fastq"]["ns_per_kmer"] == r["streaming_from_file"]["fastq"]["ns_per_kmer"]
     assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "strong" and r["higher_is_better"] is True
     assert r["vs_baseline"] is None and r["data"] == "synthetic" and r["dtype"] == "u64"
     assert abs(r["value"] - r["config"]["queries_per_step"] / r["ms_per_step"] * 1e3) / r["value"] < 0.02
@@ -63,9 +95,16 @@ def test_one_gpu_line_carries_the_contract(tmp_path):
 
 
 def test_two_ranks_split_one_batch(tmp_path):
-    r = run_bench(["--gpus", "2", "--no-cpu-baseline"], {"SSHASH_BENCH_TEST_ALL_RANKS_ON_DEVICE": "0"}, tmp_path)
+    line, r = run_bench(["--gpus", "2"], {"SSHASH_BENCH_TEST_ALL_RANKS_ON_DEVICE": "0"}, tmp_path)
     assert r["n_gpus"] == 2 and r["scaling"] == "strong"
-    assert [p["rank"] for p in r["per_rank"]] == [0, 1]
+    assert [p["rank"] for p in r["per_rank"]] == [0, 1] == [p["rank"] for p in line["per_rank"]]
+    # round 5: the CPU path is the N = 1 run's and the line says so; no side measurement at N > 1; every rank reports its own upload
+    # (the windows overlap: the ranks do not queue behind one another) and the random-line probe of its own device
+    assert r["cpu_baseline"] is None and "N = 1" in r["cpu_baseline_note"] == line["cpu_baseline_note"]
+    assert r["other_mixes"] is None and r["other_paths"] is None and r["streaming_from_file"] is None and r["other_workloads"] is None
+    (a0, a1), (b0, b1) = (p["upload_window_s"] for p in r["per_rank"])
+    assert max(a0, b0) < min(a1, b1), r["per_rank"]
+    assert all(5e9 < p["random_line_probe_units_per_s"] < 8e10 for p in line["per_rank"]), line["per_rank"]  # (here the two probes share one GPU)
     assert sum(p["queries"] for p in r["per_rank"]) == r["config"]["queries_per_step"] == 4000000
     assert r["ms_per_step"] >= max(p["ms_per_step"] for p in r["per_rank"]) * 0.98  # the MAX over the ranks
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".sshash")]) == 1  # built once, by rank 0
@@ -76,7 +115,7 @@ def test_two_ranks_split_one_batch(tmp_path):
 def test_two_ranks_route_one_batch_over_a_partitioned_dictionary(how, tmp_path):
     """`bench.py --sharded ... --gpus 2`: the N > 1 ROUTED path (route -> all-to-all -> lookup -> return -> combine), both ranks on
     the one GPU of the test box and the exchange over gloo; ids are checked against the oracle inside bench.py."""
-    r = run_bench(["--gpus", "2", "--no-cpu-baseline", "--sharded", how], {"SSHASH_BENCH_TEST_ALL_RANKS_ON_DEVICE": "0"}, tmp_path)
+    _, r = run_bench(["--gpus", "2", "--no-cpu-baseline", "--sharded", how, "--no-line-probe"], {"SSHASH_BENCH_TEST_ALL_RANKS_ON_DEVICE": "0"}, tmp_path)
     assert r["n_gpus"] == 2 and r["config"]["sharded"] == how and r["config"]["index_replicated_per_gpu"] is False
     assert sum(p["queries"] for p in r["per_rank"]) == 4000000 and abs(r["config"]["positive_fraction_found"] - 0.5) < 0.01
 
@@ -84,13 +123,8 @@ def test_two_ranks_route_one_batch_over_a_partitioned_dictionary(how, tmp_path):
 def test_config_c4_line(tmp_path):
     """`bench.py --workload c4` (human k = 63, m = 25 stand-in) at reduced size: the two-word path behind the same line -- statistics
     against the published k = 63 build, the table-less paths, and the FASTQ query with its counters equal to the oracle's."""
-    env = dict(os.environ, SSHASH_BENCH_CACHE=str(tmp_path))
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
     args = ["--workload", "c4", "--bases", "30000000", "--queries", "2000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--file-reads", "100000"]
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=1200)
-    assert p.returncode == 0, p.stderr[-3000:]
-    r = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    _, r = run(args, {}, tmp_path)
     assert r["config"]["k"] == 63 and r["config"]["m"] == 25 and r["dtype"] == "u64" and r["config"]["recipe"] == "human_k63"
     assert r["config"]["index_statistics"]["source"].startswith("benchmarks/results-10-11-25/k63/regular-build.log")
     assert abs(r["config"]["positive_fraction_found"] - 0.5) < 0.01
@@ -104,19 +138,10 @@ def test_config_c4_line(tmp_path):
 def test_streaming_mode_one_rank_and_two(tmp_path):
     """`bench.py --workload c4 --streaming [--gpus 2]` (BASELINE.json configs[3]) at reduced size: reads drawn on every rank's device,
     read-sharded, the six counters summed with one all_reduce; the line carries the contract, per-rank reports and the oracle check."""
-    env = dict(os.environ, SSHASH_BENCH_CACHE=str(tmp_path))
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
     base = ["--workload", "c4", "--bases", "30000000", "--streaming", "--reads", "400001", "--steps", "2", "--warmup", "1", "--stream-oracle-reads", "5000"]
-    lines = {}
     for n, extra, env_extra in ((1, [], {}), (2, ["--gpus", "2"], {"SSHASH_BENCH_TEST_ALL_RANKS_ON_DEVICE": "0"})):
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + base + extra, env=dict(env, **env_extra), capture_output=True, text=True, timeout=1200)
-        assert p.returncode == 0, p.stderr[-3000:]
-        out = [l for l in p.stdout.splitlines() if l.strip()]
-        assert len(out) == 1
-        lines[n] = r = json.loads(out[0])
-        for key in CONTRACT:
-            assert key in r, key
+        line, r = run(base + extra, env_extra, tmp_path)
+        assert line["config"]["report"] == r["config"]["report"] and line["roofline"]["traffic"] == r["roofline"]["traffic"]
         assert r["unit"] == "k-mers/s" and r["n_gpus"] == n and r["scaling"] == "strong" and r["config"]["k"] == 63
         rep = r["config"]["report"]
         assert rep["num_kmers"] == 400001 * (150 - 63 + 1) == sum(p_["report"][0] for p_ in r["per_rank"])
@@ -131,18 +156,14 @@ def test_streaming_mode_one_rank_and_two(tmp_path):
 def test_default_run_appends_the_other_baseline_configurations(tmp_path):
     """The driver's command measures C3 and, behind it, BASELINE.json's other single-GPU configurations as child runs of the same script
     (`other_workloads`: C2, C4, C4's streaming query, the k = 31 streaming query on high-hit reads), each with its own oracle check, roofline and cpu_baseline -- here at reduced size."""
-    env = dict(os.environ, SSHASH_BENCH_CACHE=str(tmp_path), SSHASH_BENCH_TEST_OTHER_WORKLOADS="24000000,2000000,200000")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
     args = ["--bases", "24000000", "--queries", "2000000", "--steps", "2", "--warmup", "1", "--cpu-sample", "100000", "--no-extra-mixes", "--no-other-paths", "--no-file-query"]
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=2400)
-    assert p.returncode == 0, p.stderr[-3000:]
-    out = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(out) == 1
-    r = json.loads(out[0])
+    stdout_line, r = run(args, {"SSHASH_BENCH_TEST_OTHER_WORKLOADS": "24000000,2000000,200000"}, tmp_path, timeout=2400)
     others = r["other_workloads"]
-    assert set(others) == {"c2", "c4", "c4_streaming", "c3_streaming_high_hit", "c3_streaming_high_hit_table_key_25"}
-    assert others["c3_streaming_high_hit_table_key_25"]["environment"] == {"SSHASH_AMD_SK_M": "25"} and "environment" not in others["c3_streaming_high_hit"]
+    assert set(others) == {"c2", "c4", "c4_streaming", "c3_streaming_high_hit"} == set(stdout_line["other_workloads"])
+    for name, short in stdout_line["other_workloads"].items():  # per child: value, unit, time, roofline fraction, CPU baseline, parity -- and nothing else
+        assert set(short) == {"value", "unit", "ms_per_step", "steps", "roofline_frac", "frac_hbm_traffic", "traffic", "cpu_baseline_value", "cpu_cores", "parity"}
+        assert short["value"] == others[name]["value"] and short["roofline_frac"] == others[name]["roofline"]["frac"]
+        assert short["cpu_baseline_value"] == others[name]["cpu_baseline"]["value"] and short["parity"] in ("ids equal oracle", "counters equal oracle")
     for name, line in others.items():
         assert "error" not in line, line
         for key in CONTRACT:
