@@ -94,6 +94,9 @@ typedef struct sshash_streaming_report {
 } sshash_streaming_report;
 
 const char* sshash_last_error(void);
+/* how the library was built, "key=value;..." (no reference counterpart): isa_guard=guarded|plain -- whether the device code went
+ * through tools/isa_guard.py, which keeps a gfx950 register hazard out of the kernels (a plain build also warns at the first upload) */
+const char* sshash_build_info(void);
 void sshash_build_config_default(sshash_build_config* cfg);
 
 /* ---- construction / persistence: dictionary::build (src/builder/build.cpp:10-28),

@@ -135,6 +135,7 @@ def _load() -> C.CDLL:
     P = C.c_void_p
     sigs = {
         "sshash_last_error": (C.c_char_p, []),
+        "sshash_build_info": (C.c_char_p, []),
         "sshash_build_config_default": (None, [C.POINTER(_BuildConfig)]),
         "sshash_build_from_fasta": (C.c_int, [C.c_char_p, C.POINTER(_BuildConfig), C.POINTER(P)]),
         "sshash_build_from_packed": (C.c_int, [P, P, C.c_uint64, C.POINTER(_BuildConfig), C.POINTER(P)]),
@@ -187,7 +188,7 @@ def _load() -> C.CDLL:
 
 
 C_ABI_SYMBOLS = (
-    "sshash_last_error sshash_build_config_default sshash_build_from_fasta sshash_build_from_packed sshash_save "
+    "sshash_last_error sshash_build_info sshash_build_config_default sshash_build_from_fasta sshash_build_from_packed sshash_save "
     "sshash_load sshash_free sshash_get_info sshash_bucket_stats sshash_device_count sshash_to_device sshash_to_device_table_shard sshash_device_bytes sshash_device_stats sshash_device_table_histogram "
     "sshash_lookup_packed_device sshash_lookup_ascii_device sshash_lookup_packed sshash_lookup_ascii "
     "sshash_neighbours_packed_device sshash_neighbours_packed sshash_string_neighbours sshash_string_size sshash_string_offsets "
@@ -202,6 +203,11 @@ C_ABI_SYMBOLS = (
 def _check(status: int) -> None:
     if status != 0:
         raise SSHashError(status, _load().sshash_last_error().decode("utf-8", "replace"))
+
+
+def build_info() -> dict:
+    """sshash_build_info(): {"isa_guard": "guarded" | "plain", "arch": "gfx950"}"""
+    return dict(kv.split("=", 1) for kv in _load().sshash_build_info().decode().split(";") if "=" in kv)
 
 
 def device_count() -> int:

@@ -94,6 +94,11 @@ extern "C" {
 
 const char* sshash_last_error(void) { return g_last_error.c_str(); }
 
+const char* sshash_build_info(void) {
+    static const std::string info = std::string("isa_guard=") + sshash_amd::isa_guard_state() + ";arch=gfx950";
+    return info.c_str();
+}
+
 void sshash_build_config_default(sshash_build_config* cfg) {
     if (!cfg) return;
     std::memset(cfg, 0, sizeof(*cfg));

@@ -139,5 +139,6 @@ private:
 };
 
 int visible_device_count();  // 0 when no GPU / no driver
+char const* isa_guard_state();  // "guarded": device code built through tools/isa_guard.py; "plain": by hipcc alone (engine.hip)
 
 }  // namespace sshash_amd

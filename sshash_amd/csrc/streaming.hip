@@ -346,23 +346,323 @@ void launch_streaming(dict_view const& d, skew_part_dev const* skew, char const*
     HIP_CHECK(hipGetLastError());
 }
 
+
+/* ==== the run-based streaming kernel (round 5) =====================================================================
+   The per-base walk above spends its instructions where nothing is decided: 61 % of the k-mers of a high-hit read extend the
+   run of the k-mer before them, and it rolls the k-mer, its reverse complement and two election candidates for every one of them,
+   64 reads in step (397 vector instructions per base and wave). A run is a longest common prefix: once a seed has put the read at
+   offset `off` of the strings in orientation `o`, the next k-mers are extensions for as long as the read's NEXT BASE equals the
+   strings' next base in that direction and no string starts there -- streaming_query.hpp:86-100 compares whole k-mers
+   (`expected == kmer or expected == kmer_rc`), but given the k-mer before matched the strings' k-mer before, the two k-mers share
+   k - 1 bases and differ or agree in the one new base; the other alternative of the reference's test can then only hold when the
+   new bases agree as well:
+       forward   F' = F[1:] + s, x' = x[1:] + r, F = x.   F' = rc(x') means y + s = comp(r) + rc(y) for y = x[1:]:  y[0] = comp(r),
+                 y[i] = comp(y[k-2-(i-1)]) ..., s = comp(y[0]) = r.
+       backward  F' = s + F[:-1], F = rc(x), rc(x') = comp(r) + F[:-1].   F' = x' means s + z = rc(z) + r for z = F[:-1]:
+                 r = z[k-2], s = comp(z[k-2]) = comp(r).
+   So the length of a run is min(longest common prefix of the read's tail and the strings -- 32 bases a step: XOR of two packed
+   words and a count of trailing zeros --, bases left in the string, valid bases left in the read), and nothing per base is left.
+
+   What remains are the SEEDS (the negative k-mers, and one search per run): 0.29 per base on the high-hit set, 0.41 on config
+   C4's. The kernel is a loop over EVENTS, not over bases: in every turn every lane of a wave handles the next event of its own
+   read -- a seed at its own position, or the extension that follows a hit -- so the lanes of a wave are no longer in step along
+   their reads, and a lane that is done with its read takes the next one of its wave's share at once (the wave hands them out in
+   order: a ballot and a prefix count, no atomics). The reads are packed to two bits a base (and a validity bit a base) by a pass
+   of their own first: a seed cuts its k-mer out of two or three words, and the invalid k-mers around an `N` are counted and
+   skipped with one subtraction (streaming_query.hpp:59-65: a k-mer is invalid iff one of its k characters is). */
+
+/* pass 1: lane t packs bases [8t, 8t + 8): 16 bits of codes ((c >> 1) & 3, include/kmer.hpp:118; base i of a 32-base word in bits
+   2i, 2i + 1) and 8 validity bits (A C G T a c g t, include/kmer.hpp:209-219) */
+__global__ void __launch_bounds__(256)
+stream_pack_kernel(const char* __restrict__ bases, const uint64_t total_bases, uint16_t* __restrict__ packed, uint8_t* __restrict__ okay) {
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t at = 8 * t;
+    if (at >= total_bases) return;
+    uint64_t v = 0;
+    if (at + 8 <= total_bases && ((reinterpret_cast<uintptr_t>(bases) + at) & 7) == 0) {
+        v = *reinterpret_cast<const uint64_t*>(bases + at);
+    } else {
+        for (uint32_t b = 0; b < 8 && at + b < total_bases; ++b) v |= uint64_t(uint8_t(bases[at + b])) << (8 * b);
+    }
+    uint64_t two = (v >> 1) & 0x0303030303030303ULL;
+    two = (two | (two >> 6)) & 0x000F000F000F000FULL;
+    two = (two | (two >> 12)) & 0x000000FF000000FFULL;
+    two = two | (two >> 24);
+    const uint64_t u = v & 0xDFDFDFDFDFDFDFDFULL;  // fold the case
+    auto nonzero = [](uint64_t z) { return ((z & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | z; };  // bit 7 of every byte that is not zero
+    uint64_t ok = ~(nonzero(u ^ 0x4141414141414141ULL) & nonzero(u ^ 0x4343434343434343ULL) & nonzero(u ^ 0x4747474747474747ULL) &
+                    nonzero(u ^ 0x5454545454545454ULL)) & 0x8080808080808080ULL;
+    ok >>= 7;
+    ok |= ok >> 7;
+    ok |= ok >> 14;
+    ok |= ok >> 28;
+    packed[t] = uint16_t(two);
+    okay[t] = uint8_t(ok);
+}
+
+/* first invalid base in [from, end), or `end` */
+__device__ __forceinline__ uint64_t first_invalid_base(const uint64_t* __restrict__ okay, uint64_t from, uint64_t end) {
+    uint64_t p = from;
+    while (p < end) {
+        const uint64_t bad = ~okay[p >> 6] >> (p & 63u);
+        if (bad) {
+            p += uint64_t(__builtin_ctzll(bad));
+            break;
+        }
+        p = (p | 63u) + 1;
+    }
+    return p < end ? p : end;
+}
+
+/* the 32 bases of the packed reads starting at base p */
+__device__ __forceinline__ uint64_t read_bases32(const uint64_t* __restrict__ packed, uint64_t p) {
+    const uint64_t i = p >> 5;
+    return funnel_shr(packed[i], packed[i + 1], 2 * (uint32_t(p) & 31u));
+}
+
+/* the 32 bases of the strings starting at base p; mark bit j (0 .. 32): a string starts at base p + j */
+template <int W>
+__device__ __forceinline__ void string_bases32(dict_view const& d, uint64_t p, uint64_t& bases, uint64_t& marks) {
+    const uint32_t rel = uint32_t(p) & 31u;
+    if constexpr (W == 1) {
+        const uint4* A = reinterpret_cast<const uint4*>(d.granules) + 2 * (p >> 5);
+        const uint4 q0 = A[0], q1 = A[1];
+        bases = funnel_shr(uint64_t(q0.x) | (uint64_t(q0.y) << 32), uint64_t(q0.z) | (uint64_t(q0.w) << 32), 2 * rel);
+        marks = (uint64_t(q1.x) | (uint64_t(q1.y) << 32)) >> rel;
+    } else {
+        const uint4* G = reinterpret_cast<const uint4*>(d.granules) + (p >> 5);
+        const uint4 g0 = G[0], g1 = G[1];
+        bases = funnel_shr(uint64_t(g0.z) | (uint64_t(g0.w) << 32), uint64_t(g1.z) | (uint64_t(g1.w) << 32), 2 * rel);
+        marks = (uint64_t(g0.y) | (uint64_t(g1.y) << 32)) >> rel;
+    }
+}
+
+/* Length of the run behind a hit: the read's k-mer that ends at base `b` - 1 lies at offset `off` of the strings (orientation
+   `ori`); at most `room` k-mers follow it inside the read's valid bases. Returns how many of them are extensions. */
+template <int W>
+__device__ __forceinline__ uint64_t extend_run(dict_view const& d, const uint64_t* __restrict__ packed, uint64_t off, int ori, uint64_t b,
+                                               uint64_t room) {
+    uint64_t run = 0;
+    if (ori > 0) {
+        /* the t-th extension gains the strings' base off + k - 1 + t; it leaves its string iff a string starts there */
+        const uint64_t q = off + d.k;
+        while (run < room) {
+            uint64_t s, marks;
+            string_bases32<W>(d, q + run, s, marks);
+            const uint64_t diff = s ^ read_bases32(packed, b + run);
+            const uint32_t same = diff ? uint32_t(__builtin_ctzll(diff)) >> 1 : 32u;
+            const uint32_t inside = uint32_t(marks) ? uint32_t(__builtin_ctz(uint32_t(marks))) : 32u;
+            uint64_t step = same < inside ? same : inside;
+            if (step > room - run) step = room - run;
+            run += step;
+            if (step < 32) break;
+        }
+    } else {
+        /* the t-th extension gains the strings' base off - t, complemented, and leaves its string iff a string starts at
+           off - t + 1 (streaming_query.hpp:92: remaining_string_bases = kmer_id_in_string going backward) */
+        while (run < room) {
+            const uint64_t top = off - run;  // the base gained next is top - 1; the mark that stops it is top's
+            if (top == 0) break;
+            const uint32_t have = top >= 32 ? 32u : uint32_t(top);
+            uint64_t s, marks;
+            string_bases32<W>(d, top - have, s, marks);
+            /* bases [top - have, top), the last of them moved to place 31, reversed and complemented: place i = comp(S[top - 1 - i]) */
+            const uint64_t rc = revcomp_word(s << (2 * (32 - have)));
+            const uint64_t diff = rc ^ read_bases32(packed, b + run);
+            const uint32_t same = diff ? uint32_t(__builtin_ctzll(diff)) >> 1 : 32u;
+            /* the mark of base top - i stops extension i of this word: marks bit (have - i), moved to bit 31 - i */
+            const uint32_t gate = uint32_t((marks >> 1) << (32 - have));
+            const uint32_t inside = gate ? uint32_t(__builtin_clz(gate)) : 32u;
+            uint64_t step = same < inside ? same : inside;
+            if (step > have) step = have;
+            if (step > room - run) step = room - run;
+            run += step;
+            if (step < 32) break;
+        }
+    }
+    return run;
+}
+
+template <int W, bool CANON, bool SK>
+__global__ void __launch_bounds__(256)
+streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const uint64_t* __restrict__ packed,
+                     const uint64_t* __restrict__ okay, const uint64_t* __restrict__ offsets, const uint64_t n_reads,
+                     const uint64_t reads_per_wave, uint64_t* __restrict__ report) {
+    uint64_t c_kmers = 0, c_invalid = 0, c_negative = 0, c_searches = 0, c_extensions = 0;
+    const uint32_t k = d.k;
+    const uint32_t lane = threadIdx.x & 63u;
+    /* this wave's share of the reads, handed out in order to whichever lane is done with its read */
+    const uint64_t wave = uint64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint64_t next = wave * reads_per_wave, last = next + reads_per_wave;
+    if (next > n_reads) next = n_reads;
+    if (last > n_reads) last = n_reads;
+    uint64_t cur = 0, rd_end = 0, inv = 0;  // the k-mer to settle starts at base cur of the read that ends at rd_end; inv: first invalid base >= cur
+    bool pending = false;                   // the k-mer before cur was found at `off`, orientation `ori`: the run behind it is to be measured
+    uint64_t off = 0;
+    int ori = 1;
+    bool neg_unknown_mini = false;          // (no table) streaming_query.hpp:150-157
+    uint64_t prev_f = 0, prev_r = 0;
+    sk_line_cache line_cache;
+    for (;;) {
+        /* -- the reads: whoever has none left takes the next of the wave's share -- */
+        const bool want = cur + k > rd_end;
+        const uint64_t wants = __ballot(want);
+        if (wants != 0 && next < last) {
+            const uint64_t rank = uint64_t(__popcll(wants & ((uint64_t(1) << lane) - 1)));
+            if (want && rank < last - next) {
+                const uint64_t r = next + rank;
+                cur = offsets[r];
+                rd_end = offsets[r + 1];
+                if (rd_end - cur >= k) c_kmers += rd_end - cur - k + 1;
+                inv = first_invalid_base(okay, cur, rd_end);
+                neg_unknown_mini = false;
+            }
+            const uint64_t taken = uint64_t(__popcll(wants));
+            next = taken < last - next ? next + taken : last;
+        }
+        bool live = cur + k <= rd_end;
+        if (next >= last && __ballot(live) == 0) break;
+        /* -- the k-mers over an invalid base: all invalid (streaming_query.hpp:59-65), counted and skipped -- */
+        while (live && cur + k > inv) {
+            const uint64_t last_over_it = inv < rd_end - k ? inv : rd_end - k;
+            c_invalid += last_over_it - cur + 1;
+            cur = inv + 1;
+            inv = first_invalid_base(okay, cur < rd_end ? cur : rd_end, rd_end);
+            neg_unknown_mini = false;
+            live = cur + k <= rd_end;
+        }
+        if (!live) continue;  // (as a lane: the others go on)
+        if (pending) {
+            /* -- the run behind the hit of the turn before -- */
+            pending = false;
+            const uint64_t valid_end = inv < rd_end ? inv : rd_end;
+            const uint64_t run = extend_run<W>(d, packed, off, ori, cur + k - 1, valid_end - (cur + k - 1));
+            c_extensions += run;
+            cur += run;
+            continue;
+        }
+        /* -- seed() at cur (streaming_query.hpp:144-197) -- */
+        kmer_w<W> x;
+        {
+            const uint64_t i = cur >> 5;
+            const uint32_t sh = 2 * (uint32_t(cur) & 31u);
+            const uint64_t w0 = packed[i], w1 = packed[i + 1];
+            x.w[0] = funnel_shr(w0, w1, sh);
+            if constexpr (W == 2) x.w[1] = funnel_shr(w1, packed[i + 2], sh);
+            x = kmer_take_chars<W>(x, k);
+        }
+        const kmer_w<W> x_rc = kmer_revcomp<W>(x, k);
+        bool settled = false, found = false;
+        if constexpr (SK) {
+            const sk_key_t kk = sk_key<W>(x, x_rc, k, d.sk.m);
+            if (sk_usable(d, kk)) {
+                bool key_seen;
+                const fast_t r = sk_probe<W>(d, x, x_rc, kk, key_seen, line_cache);
+                if (r.outcome != FAST_DEFER) {
+                    settled = true;
+                    found = r.outcome == FAST_HIT;
+                    off = r.kmer_offset;
+                    ori = r.orientation;
+                }
+            }
+        }
+        if (!settled) {
+            /* no table, or a tie / an unplaced key / another shard's key: the complete seed() */
+            const minimizer_t mf = compute_minimizer<W>(x, k, d.m, d.hash_magic);
+            const minimizer_t mr = compute_minimizer<W>(x_rc, k, d.m, d.hash_magic);
+            if (!SK && neg_unknown_mini && mf.value == prev_f && mr.value == prev_r) {  // :150-157
+                found = false;
+            } else {
+                prev_f = mf.value;
+                prev_r = mr.value;
+                const hit_t h = seed_lookup<W, CANON>(d, skew, x, x_rc, mf, mr);
+                found = h.found;
+                off = h.kmer_offset;
+                ori = h.orientation;
+                neg_unknown_mini = !SK && !h.found && !h.minimizer_found;
+            }
+        }
+        if (found) {
+            ++c_searches;
+            neg_unknown_mini = false;
+            const uint64_t valid_end = inv < rd_end ? inv : rd_end;
+            pending = cur + 1 + k <= valid_end;  // (otherwise nothing can extend it)
+        } else {
+            ++c_negative;
+        }
+        ++cur;
+    }
+    block_report(c_kmers, c_invalid, c_negative, c_searches, c_extensions, report);
+}
+
+template <int W, bool CANON>
+void launch_streaming_runs(device_replica const* rep, dict_view const& d, char const* bases, uint64_t const* offsets, uint64_t n_reads,
+                           uint64_t total_bases, uint64_t* report, hipStream_t s) {
+    /* two bits and a validity bit a base, in words of 32 and 64 bases; three words of slack behind the last base (a seed and a
+       run read up to two words past their first) */
+    const uint64_t packed_bytes = ((total_bases + 31) / 32 + 3) * 8, okay_bytes = ((total_bases + 63) / 64 + 2) * 8;
+    struct temporaries {
+        hipStream_t s;
+        void* p[2];
+        ~temporaries() {
+            for (void* q : p)
+                if (q) (void)hipFreeAsync(q, s);
+        }
+    } tmp{s, {nullptr, nullptr}};
+    tmp.p[0] = rep->stream_alloc(packed_bytes, s);
+    tmp.p[1] = rep->stream_alloc(okay_bytes, s);
+    uint64_t* packed = static_cast<uint64_t*>(tmp.p[0]);
+    uint64_t* okay = static_cast<uint64_t*>(tmp.p[1]);
+    if (total_bases) {
+        const uint64_t lanes = (total_bases + 7) / 8;
+        hipLaunchKernelGGL(stream_pack_kernel, dim3(uint32_t((lanes + 255) / 256)), dim3(256), 0, s, bases, total_bases,
+                           reinterpret_cast<uint16_t*>(packed), reinterpret_cast<uint8_t*>(okay));
+    }
+    /* waves: a share of at least 8 reads a lane (a lane that finishes its read takes the wave's next: the longer the share, the
+       better the lanes of a wave even out), at most as many waves as the chip holds at once */
+    static const uint64_t max_waves = [] {
+        char const* e = std::getenv("SSHASH_AMD_STREAM_WAVES");
+        return e ? std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) : uint64_t(256) * 16;
+    }();
+    uint64_t waves = std::min<uint64_t>(max_waves, std::max<uint64_t>(1, n_reads / (64 * 8)));
+    waves = (waves + 3) / 4 * 4;
+    const uint64_t reads_per_wave = (n_reads + waves - 1) / waves;
+    const dim3 grid(uint32_t(waves / 4)), block(256);
+    if (d.sk.enabled) hipLaunchKernelGGL((streaming_run_kernel<W, CANON, true>), grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, report);
+    else hipLaunchKernelGGL((streaming_run_kernel<W, CANON, false>), grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, report);
+    HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace
 
 void engine::streaming_query_device(int device, char const* d_bases, uint64_t const* d_read_offsets, uint64_t n_reads,
-                                    uint64_t /*total_bases*/, uint64_t* d_report, void* stream) const {
+                                    uint64_t total_bases, uint64_t* d_report, void* stream) const {
     device_replica const* rep = replica(device);
     if (n_reads == 0) return;
-    int prev = 0;
-    HIP_CHECK(hipGetDevice(&prev));
-    if (prev != device) HIP_CHECK(hipSetDevice(device));
+    device_guard guard(device);
     dict_view const& d = rep->view;
     hipStream_t s = hipStream_t(stream);
     const bool wide = d.k > 31;
-    if (!wide && !d.canonical) launch_streaming<1, false>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
-    else if (!wide && d.canonical) launch_streaming<1, true>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
-    else if (wide && !d.canonical) launch_streaming<2, false>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
-    else launch_streaming<2, true>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
-    if (prev != device) HIP_CHECK(hipSetDevice(prev));
+    /* SSHASH_AMD_STREAM_WALK=bases: the per-base kernel of rounds 1-4 (one read a lane, the lanes in step along their reads), kept for A/B runs */
+    char const* walk = std::getenv("SSHASH_AMD_STREAM_WALK");
+    if (walk && walk[0] == 'b') {
+        if (!wide && !d.canonical) launch_streaming<1, false>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
+        else if (!wide && d.canonical) launch_streaming<1, true>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
+        else if (wide && !d.canonical) launch_streaming<2, false>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
+        else launch_streaming<2, true>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
+        return;
+    }
+    if (total_bases == 0) {
+        /* the packing pass covers bases [0, read_offsets[n_reads]): a caller that does not say how many that is (the C ABI's device
+           entry point) costs the launch one 8-byte read-back on its stream */
+        HIP_CHECK(hipMemcpyAsync(&total_bases, d_read_offsets + n_reads, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (total_bases == 0) return;
+    }
+    if (!wide && !d.canonical) launch_streaming_runs<1, false>(rep, d, d_bases, d_read_offsets, n_reads, total_bases, d_report, s);
+    else if (!wide && d.canonical) launch_streaming_runs<1, true>(rep, d, d_bases, d_read_offsets, n_reads, total_bases, d_report, s);
+    else if (wide && !d.canonical) launch_streaming_runs<2, false>(rep, d, d_bases, d_read_offsets, n_reads, total_bases, d_report, s);
+    else launch_streaming_runs<2, true>(rep, d, d_bases, d_read_offsets, n_reads, total_bases, d_report, s);
 }
 
 /* ---- per-k-mer results: the streaming query as a position-parallel pipeline -----------------------------------

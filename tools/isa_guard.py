@@ -25,7 +25,14 @@ repairs it without touching what the kernel computes:
           .amdhsa_accum_offset, .vgpr_count) -- the register named is no longer the last one; one wave per SIMD less may fit.
 Writes the assembly back out and a JSON report; csrc/Makefile assembles what comes out.
 
-    python3 tools/isa_guard.py in.s out.s [--report report.json] [--check] [--pad-only]     (--check: exit 1 if anything had to be changed)
+The guard FAILS CLOSED: it raises -- and the build stops -- when it meets something it was not written for, instead of
+letting a kernel through unexamined: a kernel descriptor whose register count is not a plain integer (hipcc writes `max(...)`
+expressions for kernels that call non-inlined functions), a kernel that calls (s_swappc / s_call, or an s_setpc that is not the
+assembler's own long branch: the callee's registers are not the kernel's names), a number of kernels examined that differs from the number of `.amdhsa_kernel` directives in the file, or a
+line inside a kernel's body that is neither an instruction, a label, a directive nor a comment. The report records the compiler
+that wrote the assembly (`--toolchain`).
+
+    python3 tools/isa_guard.py in.s out.s [--report report.json] [--check] [--pad-only] [--toolchain "text"]     (--check: exit 1 if anything had to be changed)
 """
 import json
 import re
@@ -34,6 +41,13 @@ import sys
 GRANULE = 8
 # 64-bit typed VALU mnemonics: ..._b64, _u64, _i64, _f64 anywhere in the name (v_lshlrev_b64, v_mad_u64_u32, v_lshl_add_u64, v_cvt_f64_u32 ...)
 WIDE = re.compile(r"^v_\w*(b64|u64|i64|f64)")
+
+
+class GuardError(Exception):
+    """something in the assembly the guard cannot vouch for: the build must stop"""
+
+
+INSTRUCTION = re.compile(r"^[a-z][a-z0-9_]*(\s|$)")  # a mnemonic: v_..., s_..., ds_..., global_..., buffer_..., flat_..., scratch_...
 
 
 def kernels_of(lines):
@@ -50,18 +64,63 @@ def kernels_of(lines):
             k = {"name": m.group(1), "desc": i}
             j = i
             while ".end_amdhsa_kernel" not in lines[j]:
-                mm = re.match(r"\s*\.amdhsa_next_free_vgpr\s+(\d+)", lines[j])
+                mm = re.match(r"\s*\.amdhsa_next_free_vgpr\s+(.*?)\s*(;.*)?$", lines[j])
                 if mm:
+                    if not re.fullmatch(r"\d+", mm.group(1)):
+                        raise GuardError("kernel %s: .amdhsa_next_free_vgpr is not a plain integer (%r): a kernel with non-inlined calls? "
+                                         "The guard cannot tell its last register" % (k["name"], mm.group(1)))
                     k["vgpr_line"], k["next_free_vgpr"] = j, int(mm.group(1))
                 mm = re.match(r"\s*\.amdhsa_accum_offset\s+(\d+)", lines[j])
                 if mm:
                     k["accum_line"], k["accum_offset"] = j, int(mm.group(1))
                 j += 1
+            if k["name"] not in labels:
+                raise GuardError("kernel %s: no label of that name in the file" % k["name"])
+            if "next_free_vgpr" not in k:
+                raise GuardError("kernel %s: its descriptor has no .amdhsa_next_free_vgpr" % k["name"])
             k["body"] = (labels[k["name"]], i)
             out.append(k)
             i = j
         i += 1
+    directives = sum(1 for l in lines if re.match(r"\s*\.amdhsa_kernel\s", l))
+    if len(out) != directives:
+        raise GuardError("%d .amdhsa_kernel directives but %d kernels parsed" % (directives, len(out)))
     return out
+
+
+def body_end(lines, k):
+    """the line after a kernel's last instruction: its .Lfunc_end label (the descriptor follows in another section)"""
+    for i in range(k["body"][0], k["body"][1]):
+        if re.match(r"\.Lfunc_end\d*\w*:", lines[i]) or re.match(r"\s*\.section\s", lines[i]):
+            return i
+    return k["body"][1]
+
+
+def classify_body(lines, k):
+    """every line of the kernel's body must be something the guard understands; a kernel that calls is refused"""
+    for i in range(k["body"][0], body_end(lines, k)):
+        l = lines[i]
+        code = l.split(";")[0].strip()
+        if not code or code.startswith(".") or code.endswith(":"):
+            continue  # empty / comment, directive, label
+        if code.split("//")[0].strip() == "":
+            continue
+        if not INSTRUCTION.match(code):
+            raise GuardError("kernel %s, line %d: not an instruction, label, directive or comment: %r" % (k["name"], i + 1, l))
+        mnemonic = code.split(None, 1)[0]
+        if re.search(r"(?<![\w.])a(\d+|\[\d+:\d+\])(?![\w(])", code.split(None, 1)[1] if " " in code or "\t" in code else ""):
+            raise GuardError("kernel %s, line %d: accumulation registers in use (%s): with them the allocation is split at .amdhsa_accum_offset "
+                             "and 'the last VGPR' is not what this guard computes" % (k["name"], i + 1, code))
+        if mnemonic.startswith("s_setpc"):
+            # a long branch inside the kernel (s_getpc_b64 sN, label arithmetic, s_setpc_b64 sN: what the assembler's branch relaxation
+            # writes when a target is out of a 16-bit offset's reach) is not a call; anything else that sets the PC is refused
+            pair = code.split(None, 1)[1].strip()
+            recent = [lines[j].split(";")[0].strip() for j in range(max(k["body"][0], i - 6), i)]
+            if any(r.startswith("s_getpc_b64") and r.split(None, 1)[1].strip() == pair for r in recent):
+                continue
+        if mnemonic.startswith(("s_swappc", "s_setpc", "s_call")):
+            raise GuardError("kernel %s, line %d: %s -- the kernel calls a function that was not inlined; its registers follow the "
+                             "callee's convention, not the names in this body" % (k["name"], i + 1, mnemonic))
 
 
 def hazards(lines, k):
@@ -147,18 +206,24 @@ def try_rename(lines, k, alloc):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    argv = sys.argv[1:]
+    args, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+        elif a in ("--report", "--toolchain"):
+            skip = True
+        elif not a.startswith("--"):
+            args.append(a)
     src, dst = args[0], args[1]
     report_path = sys.argv[sys.argv.index("--report") + 1] if "--report" in sys.argv else None
-    if report_path in args:
-        args.remove(report_path)
     lines = open(src).read().split("\n")
-    report = {"source": src, "kernels": 0, "use_their_last_register": 0, "renamed": [], "padded": []}
+    toolchain = sys.argv[sys.argv.index("--toolchain") + 1] if "--toolchain" in sys.argv else None
+    report = {"source": src, "toolchain": toolchain, "kernels": 0, "use_their_last_register": 0, "renamed": [], "padded": []}
     bumped = {}
     for k in kernels_of(lines):
         report["kernels"] += 1
-        if "next_free_vgpr" not in k:
-            continue
+        classify_body(lines, k)
         alloc, found = hazards(lines, k)
         if k["next_free_vgpr"] == alloc:
             report["use_their_last_register"] += 1
@@ -197,4 +262,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except GuardError as e:
+        print("[isa_guard] REFUSED: %s" % e, file=sys.stderr)
+        sys.exit(2)
