@@ -264,6 +264,16 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_buckets) {
     return h;
 }
 
+/* the first choice and the fingerprint alone (both come out of `a`): what a probe that ends in its key's first bucket needs -- 19 in 20 */
+SSH_HD void sk_hash_first(uint64_t key, uint32_t num_buckets, uint32_t& bucket, uint32_t& fingerprint) {
+    uint64_t a = key * 0xFF51AFD7ED558CCDULL;
+    a ^= a >> 32;
+    a *= 0xC4CEB9FE1A85EC53ULL;
+    a ^= a >> 29;
+    bucket = mulhi32(uint32_t(a >> 32), num_buckets);
+    fingerprint = uint32_t(a) & 0xFFFFFFu;
+}
+
 /* bucket sequence of a heavy key's k-mer: hashed into the k-mers' region */
 SSH_HD sk_hash_t sk_hash_kmer_region(uint64_t kmer_key, uint32_t first_bucket, uint32_t kmer_buckets) {
     sk_hash_t h = sk_hash(kmer_key, kmer_buckets);
@@ -293,6 +303,7 @@ SSH_HD uint64_t sk_kmer_key(kmer_w<W> const& x, kmer_w<W> const& x_rc) {
 struct sk_key_t {
     uint64_t key;  // the m-mer, as read on the winning strand
     uint32_t pos;  // where it starts on that strand
+    uint32_t hash; // the winning occurrence's 26-bit election hash (sk_key_persists)
     bool rc;       // the winning strand is the reverse complement of x
     bool tie;
 };
@@ -428,8 +439,57 @@ SSH_HD sk_key_t sk_key(kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, ui
     out.rc = (best_r >> SK_POS_BITS) < (best_f >> SK_POS_BITS);
     out.tie = (best_r >> SK_POS_BITS) == (best_f >> SK_POS_BITS);
     out.pos = (out.rc ? best_r : best_f) & ((1u << SK_POS_BITS) - 1u);
+    out.hash = (out.rc ? best_r : best_f) >> SK_POS_BITS;
     out.key = kmer_shr_chars<W>(out.rc ? x_rc : x, out.pos).w[0] & low_mask(2 * m);
     return out;
+}
+
+/* For how many of the k-mers that FOLLOW a k-mer along a read does its key last? The k-mer one base further on keeps every
+   candidate of the election but two and gains two: the m-mer that ends at its last base, and -- on the other strand -- that
+   m-mer's reverse complement. The elected occurrence stays elected for as long as (1) it is still inside the k-mer and (2) no
+   candidate that has come in hashes below it; a newcomer that hashes EQUAL ends the count as well (it may be the leftmost of its
+   strand, or tie the strands). So: the number t <= SK_PERSIST_MAX such that sk_key of the k-mers 1 .. t bases further on elects
+   the same occurrence (same key, at a position that moves with the k-mer) -- never more than that, possibly fewer.
+     ahead_f  the 32 bases of the read that start k - m + 1 bases behind the k-mer's first: the newcomers' first bases, forward
+     ahead_r  the 32 bases that start k + 1 - min(m, 12) behind it: the last min(m, 12) bases of the following k-mers -- whose
+              reverse complements are the first bases of the newcomers on the other strand
+   What the streaming query does with it (streaming.hip): a k-mer whose key is proven absent from the table -- or present with
+   one slot that differs from the read at a base the following k-mers still hold -- settles the k-mers behind it that share its
+   key without looking at them. tests/cpp/check_table_key.cpp holds it against sk_key base by base. */
+constexpr uint32_t SK_PERSIST_MAX = 20;  // 32 bases ahead hold 21 windows of 12
+template <int W>
+SSH_HD uint32_t sk_key_persists(sk_key_t const& kk, uint32_t k, uint32_t m, uint64_t ahead_f, uint64_t ahead_r) {
+    const uint32_t inside = kk.rc ? k - m - kk.pos : kk.pos;  // (1): that many k-mers further on still hold the occurrence
+    uint32_t most = inside < SK_PERSIST_MAX ? inside : SK_PERSIST_MAX;
+    const uint32_t threshold = (kk.hash << SK_POS_BITS) | ((1u << SK_POS_BITS) - 1u);  // umul24(...) <= threshold  <=>  its 26-bit hash <= kk.hash
+    const uint32_t mul = sk_select_mul(), salt = sk_select_salt<W>();
+    const uint32_t L = m < 12 ? m : 12;
+    const uint64_t behind = revcomp_word(ahead_r);  // base 31 - i = the complement of base i of ahead_r
+    const uint32_t f_lo = uint32_t(ahead_f), f_hi = uint32_t(ahead_f >> 32), r_lo = uint32_t(behind), r_hi = uint32_t(behind >> 32);
+    uint32_t first = SK_PERSIST_MAX + 1;  // the first k-mer (1-based) with a newcomer at or below the threshold
+    auto newcomer = [&](uint32_t word, uint32_t t) {
+        word ^= salt;
+        if (m < 12) word <<= 24 - 2 * m;  // uniform (sk_elect: MASKED)
+        first = sk_select_hash(word, 0u, mul) <= threshold ? t : first;
+    };
+    if (m >= 12) {  // uniform: every shift below is a constant
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t t = SK_PERSIST_MAX; t >= 1; --t) {
+            /* forward: the 12 bases from base t - 1 of ahead_f; other strand: the reverse complement of the 12 bases from base t - 1 of
+               ahead_r = the 12 bases from base 32 - 12 - (t - 1) of `behind` */
+            newcomer(t - 1 < 16 ? funnel32(f_lo, f_hi, 2 * (t - 1)) : f_hi >> (2 * (t - 1 - 16)), t);
+            const uint32_t at = 21 - t;
+            newcomer(at < 16 ? funnel32(r_lo, r_hi, 2 * at) : r_hi >> (2 * (at - 16)), t);
+        }
+    } else {
+        for (uint32_t t = SK_PERSIST_MAX; t >= 1; --t) {
+            newcomer(uint32_t(ahead_f >> (2 * (t - 1))) & uint32_t(low_mask(2 * L)), t);
+            newcomer(uint32_t(behind >> (2 * (32 - L - (t - 1)))) & uint32_t(low_mask(2 * L)), t);
+        }
+    }
+    return first - 1 < most ? first - 1 : most;
 }
 
 /* The same election for a k-mer that SLIDES along a read one base at a time (the streaming query): sk_key looks at all
@@ -525,6 +585,7 @@ SSH_HD sk_key_t sk_roll_key(sk_roll_state const& st, kmer_w<W> const& x, kmer_w<
     out.rc = best_r < best_f;
     out.tie = best_r == best_f;
     out.pos = out.rc ? pos_r : pos_f;
+    out.hash = out.rc ? best_r : best_f;
     out.key = kmer_shr_chars<W>(out.rc ? x_rc : x, out.pos).w[0] & low_mask(2 * m);
     return out;
 }
@@ -586,6 +647,7 @@ SSH_HD bool sk_roll1_key(sk_roll1_state const& st, kmer_w<W> const& x, kmer_w<W>
     const bool before = place > b;  // a place of the block before (they are b + 1 .. n - 1)
     out.rc = (least & SK_ROLL1_RC) != 0;
     out.tie = false;
+    out.hash = least >> 8;  // (24 bits of it: not comparable with sk_key's -- sk_key_persists is for keys elected by sk_key)
     out.pos = out.rc ? (before ? b + n - place : b - place) : (before ? place - b - 1 : n - 1 - b + place);
     out.key = kmer_shr_chars<W>(out.rc ? x_rc : x, out.pos).w[0] & low_mask(2 * m);
     return true;

@@ -690,9 +690,15 @@ struct sk_bucket_flags {
    staged the line, or out of global memory. Straight-line code (selects, no branch). FIRST: the slot is slot 0 of
    its bucket and carries the bucket's flags. Out: r (a hit), `marker` (the slot says that the key is heavy: its
    k-mers are entered under keys of their own), `key_seen`. */
-template <int W, bool FIRST, class Piece>
-__device__ __forceinline__ void sk_examine_slot(dict_view const& d, sk_query_t<W> const Q, uint32_t c, Piece piece, fast_t& r,
-                                                bool& key_seen, bool& marker, sk_bucket_flags& flags) {
+/* TRACK (the streaming query, streaming.hip): `lasts` is lowered to what THIS slot allows -- for how many of the k-mers that follow
+   the query along its read and elect the same key occurrence (sk_key_persists) the slot is sure to miss as it misses now. A slot that
+   does not carry the key's fingerprint has no say. One that does holds the strings around an occurrence of the key: the read lies
+   against it at a fixed offset for as long as the key occurrence is the same, so a base at which the two differ keeps them apart
+   while the k-mer still holds that base -- the LAST differing base of the k-mer when the read runs along the strings here, the first
+   when it runs against them. No difference (the k-mer ends outside the super-k-mer's extent) or a marker: no promise. */
+template <int W, bool FIRST, bool TRACK, class Piece>
+__device__ __forceinline__ void sk_examine_slot_tracking(dict_view const& d, sk_query_t<W> const Q, uint32_t c, Piece piece, fast_t& r,
+                                                         bool& key_seen, bool& marker, sk_bucket_flags& flags, uint32_t& lasts) {
     const uint32_t km = d.k - d.sk.m;
     const uint32_t j = Q.j;
     /* values, not references into Q: a select between two members of a by-reference struct is compiled into an
@@ -746,12 +752,39 @@ __device__ __forceinline__ void sk_examine_slot(dict_view const& d, sk_query_t<W
     }
     cand = kmer_take_chars<W>(cand, d.k);
     const uint32_t left = (meta >> SK_LEFT_SHIFT) & 63u, right = (meta >> SK_RIGHT_SHIFT) & 63u;
-    const bool hit = valid && !is_marker && kmer_eq<W>(cand, kmer_pick<W>(o, y_rc, y)) && a + left >= km && a <= right;
+    const kmer_w<W> target = kmer_pick<W>(o, y_rc, y);
+    const bool hit = valid && !is_marker && kmer_eq<W>(cand, target) && a + left >= km && a <= right;
     /* a k-mer occurs once in the strings: at most one slot hits */
     r.kmer_offset = hit ? at + a - km : r.kmer_offset;
     r.string_id = hit ? q0.y : r.string_id;
     r.orientation = hit ? ((o != Q.s) ? int8_t(-1) : int8_t(1)) : r.orientation;
     r.outcome = hit ? int(FAST_HIT) : r.outcome;
+    if constexpr (TRACK) {
+        uint32_t first, last;  // the first and the last base at which the k-mer and the slot differ (only read when they do)
+        bool differ;
+        if constexpr (W == 1) {
+            const uint64_t x0 = cand.w[0] ^ target.w[0];
+            differ = x0 != 0;
+            first = uint32_t(__builtin_ctzll(x0 | (uint64_t(1) << 63))) >> 1;
+            last = (63u - uint32_t(__builtin_clzll(x0 | 1u))) >> 1;
+        } else {
+            const uint64_t x0 = cand.w[0] ^ target.w[0], x1 = cand.w[1] ^ target.w[1];
+            differ = (x0 | x1) != 0;
+            first = x0 ? uint32_t(__builtin_ctzll(x0)) >> 1 : 32u + (uint32_t(__builtin_ctzll(x1 | (uint64_t(1) << 63))) >> 1);
+            last = x1 ? 32u + ((63u - uint32_t(__builtin_clzll(x1))) >> 1) : (63u - uint32_t(__builtin_clzll(x0 | 1u))) >> 1;
+        }
+        const bool along = o == Q.s;  // target is the read's own k-mer: base i of it is base i of the read's k-mer; else base k - 1 - i
+        uint32_t mine = along ? last : d.k - 1 - first;
+        mine = (differ && !is_marker) ? mine : 0u;
+        lasts = (same_fingerprint && mine < lasts) ? mine : lasts;
+    }
+}
+
+template <int W, bool FIRST, class Piece>
+__device__ __forceinline__ void sk_examine_slot(dict_view const& d, sk_query_t<W> const Q, uint32_t c, Piece piece, fast_t& r,
+                                                bool& key_seen, bool& marker, sk_bucket_flags& flags) {
+    uint32_t unused = 0;
+    sk_examine_slot_tracking<W, FIRST, false>(d, Q, c, piece, r, key_seen, marker, flags, unused);
 }
 
 /* k <= 63: one ENTRY of the k-mers' region (device_layout.hpp: 32 bytes -- meta, string id, position | fingerprint, the

@@ -483,6 +483,66 @@ __device__ __forceinline__ uint64_t extend_run(dict_view const& d, const uint64_
     return run;
 }
 
+/* sk_probe (lookup_device.hpp) for a seed of the run-based kernel: the same walk, with two differences. The first bucket's choice and
+   the key's fingerprint are hashed alone (sk_hash_first) -- the other four choices cost three more 64-bit multiplies and one probe in
+   twenty looks at them. And the slots say for how many of the following k-mers with the same key occurrence a miss stands (`lasts`:
+   sk_examine_slot_tracking); a probe that has to go on past its first bucket, or meets its key's marker, promises nothing. */
+template <int W>
+__device__ __forceinline__ fast_t stream_probe(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
+                                               sk_line_cache& cache, uint32_t& lasts) {
+    uint32_t b, fingerprint;
+    sk_hash_first(kk.key, d.sk.num_buckets, b, fingerprint);
+    sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, fingerprint);
+    fast_t r = fast_unsettled(false);
+    lasts = 0xFFFFu;
+    const uint4* B0 = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(b);
+    if (b != cache.bucket) {
+        cache.bucket = b;
+        for (int i = 0; i < 4; ++i) cache.piece[i] = B0[i];
+    }
+    const uint4 c0 = cache.piece[0], c1 = cache.piece[1], c2 = cache.piece[2], c3 = cache.piece[3];
+    auto cached = [c0, c1, c2, c3](uint32_t i) { return i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3; };
+    sk_bucket_flags flags;
+    bool marker = false, seen = false;
+    sk_examine_slot_tracking<W, true, true>(d, Q, 0, cached, r, seen, marker, flags, lasts);
+    if (r.outcome == FAST_MISS && flags.second_used) {
+        if constexpr (W == 1) sk_examine_slot_tracking<W, false, true>(d, Q, 0, [cached](uint32_t i) { return cached(2 + i); }, r, seen, marker, flags, lasts);
+        else sk_examine_slot_tracking<W, false, true>(d, Q, 0, [B0](uint32_t i) { return B0[2 * W + i]; }, r, seen, marker, flags, lasts);
+    }
+    const uint32_t first_go_on = flags.go_on;
+    if (r.outcome != FAST_MISS || (!marker && first_go_on == 0)) return r;  // found, or a miss that is final here
+    lasts = 0;
+    sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), 0);
+    bool more = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, first_go_on, marker);
+#pragma unroll 1
+    while (more) {
+        const uint32_t bucket = sk_choice(w.h, w.c);
+        const bool compact = bucket >= d.sk.num_buckets;  // the k-mers' region (lookup_device.hpp: sk_probe)
+        const uint4* B = reinterpret_cast<const uint4*>(static_cast<char const*>(d.sk.slots) + sk_bucket_offset<W>(d, bucket, compact));
+        marker = false;
+        if constexpr (W == 2) {
+            if (compact) {
+                sk_examine_kmer_entry<true>(Q, w.c, [B](uint32_t i) { return B[i]; }, r, flags);
+                sk_examine_kmer_entry<false>(Q, w.c, [B](uint32_t i) { return B[2 + i]; }, r, flags);
+            }
+        } else {
+            if (compact) {
+                const uint4 l0 = B[0], l1 = B[1], l2 = B[2], l3 = B[3];
+                const uint32_t words[16] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
+                sk_examine_kmer_line(Q, w.c, [&words](uint32_t i) { return words[i]; }, r, flags);
+            }
+        }
+        if (!compact) {
+            sk_examine_slot<W, true>(d, Q, w.c, [B](uint32_t i) { return B[i]; }, r, seen, marker, flags);
+            if (r.outcome == FAST_MISS && flags.second_used)
+                sk_examine_slot<W, false>(d, Q, w.c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags);
+        }
+        const uint32_t go_on = flags.go_on;
+        more = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
+    }
+    return r;
+}
+
 template <int W, bool CANON, bool SK>
 __global__ void __launch_bounds__(256)
 streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const uint64_t* __restrict__ packed,
@@ -556,13 +616,25 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
         if constexpr (SK) {
             const sk_key_t kk = sk_key<W>(x, x_rc, k, d.sk.m);
             if (sk_usable(d, kk)) {
-                bool key_seen;
-                const fast_t r = sk_probe<W>(d, x, x_rc, kk, key_seen, line_cache);
+                uint32_t lasts;
+                const fast_t r = stream_probe<W>(d, x, x_rc, kk, line_cache, lasts);
                 if (r.outcome != FAST_DEFER) {
                     settled = true;
                     found = r.outcome == FAST_HIT;
                     off = r.kmer_offset;
                     ori = r.orientation;
+                    if (!found) {
+                        /* a miss that stands for the k-mers behind this one: those that elect the same key occurrence (sk_key_persists)
+                           and still hold the base that keeps the read and the key's slot apart (`lasts`; no slot with the key: all of
+                           them) are negative as well -- counted, not looked at */
+                        const uint32_t sm = d.sk.m, hashed = sm < 12 ? sm : 12;
+                        uint64_t keep = sk_key_persists<W>(kk, k, sm, read_bases32(packed, cur + k - sm + 1), read_bases32(packed, cur + k + 1 - hashed));
+                        const uint64_t valid_end = inv < rd_end ? inv : rd_end;
+                        keep = keep < lasts ? keep : lasts;
+                        keep = keep < valid_end - (cur + k) ? keep : valid_end - (cur + k);
+                        c_negative += keep;
+                        cur += keep;
+                    }
                 }
             }
         }

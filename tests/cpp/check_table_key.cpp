@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <vector>
 
 #include "../../sshash_amd/csrc/device_layout.hpp"
 
@@ -122,6 +123,51 @@ static int check_rolling(uint32_t k, uint32_t m, uint64_t reads, std::mt19937_64
     return 0;
 }
 
+/* sk_key_persists along reads: for every k-mer whose key is not a tie, the t k-mers that follow must elect the very same occurrence
+   (same key, same strand, the position moved by t); how far it looks is printed next to how far the key really lasts */
+template <int W>
+static int check_persists(uint32_t k, uint32_t m, uint64_t reads, std::mt19937_64& rng, uint64_t& kmers, uint64_t& claimed, uint64_t& lasted) {
+    const uint32_t L = m < 12 ? m : 12;
+    for (uint64_t t = 0; t < reads; ++t) {
+        const uint32_t len = k + 40 + uint32_t(rng() % 160);
+        const uint32_t alphabet = t % 5 == 0 ? 2 : 4;
+        std::vector<uint8_t> read(len + 80);
+        for (uint32_t j = 0; j < read.size(); ++j) read[j] = uint8_t(t % 11 == 0 && (j / 40) % 2 ? 0 : rng() % alphabet);
+        auto bases32 = [&](uint32_t from) {  // (what read_bases32 of streaming.hip hands over: whatever lies there, also behind the read's end)
+            uint64_t w = 0;
+            for (uint32_t i = 0; i < 32; ++i) w |= uint64_t(from + i < read.size() ? read[from + i] : 0) << (2 * i);
+            return w;
+        };
+        auto kmer_at = [&](uint32_t from) {
+            kmer_w<W> x = kmer_zero<W>();
+            for (uint32_t i = 0; i < k; ++i) x = kmer_roll<W>(x, read[from + i], k);
+            return x;
+        };
+        for (uint32_t cur = 0; cur + k <= len; ++cur) {
+            const kmer_w<W> x = kmer_at(cur);
+            const sk_key_t a = sk_key<W>(x, kmer_revcomp<W>(x, k), k, m);
+            if (a.tie) continue;
+            ++kmers;
+            const uint32_t n = sk_key_persists<W>(a, k, m, bases32(cur + k - m + 1), bases32(cur + k + 1 - L));
+            if (n > k - m) return printf("sk_key_persists claims more k-mers than a key can last (k=%u m=%u)\n", k, m), 1;
+            claimed += n;
+            for (uint32_t s = 1; s <= k - m && cur + s + k <= len; ++s) {
+                const kmer_w<W> z = kmer_at(cur + s);
+                const sk_key_t b = sk_key<W>(z, kmer_revcomp<W>(z, k), k, m);
+                const bool same = !b.tie && b.rc == a.rc && b.key == a.key && b.pos == (a.rc ? a.pos + s : a.pos - s) && b.hash == a.hash;
+                if (!same) {
+                    if (s <= n) return printf("sk_key_persists overstates (k=%u m=%u read %llu k-mer %u: claims %u, the key changes after %u)\n", k, m,
+                                              (unsigned long long)t, cur, n, s - 1), 1;
+                    break;
+                }
+                ++lasted;
+                if (a.rc ? a.pos + s == k - m : a.pos == s) break;  // the occurrence leaves the k-mer next
+            }
+        }
+    }
+    return 0;
+}
+
 int main() {
     std::mt19937_64 rng(12345);
     uint64_t ties = 0, checked = 0;
@@ -143,6 +189,12 @@ int main() {
         if (c[0] <= 31 ? check_rolling1<1>(c[0], c[1], 3000, rng, seen, ambiguous) : check_rolling1<2>(c[0], c[1], 3000, rng, seen, ambiguous)) return 1;
         fprintf(stderr, "one-word rolling election k=%u m=%u: %llu k-mers, %llu left to sk_key\n", c[0], c[1], (unsigned long long)seen,
                 (unsigned long long)ambiguous);
+    }
+    for (auto const& c : cases) {
+        uint64_t seen = 0, claimed = 0, lasted = 0;
+        if (c[0] <= 31 ? check_persists<1>(c[0], c[1], 300, rng, seen, claimed, lasted) : check_persists<2>(c[0], c[1], 300, rng, seen, claimed, lasted)) return 1;
+        fprintf(stderr, "sk_key_persists k=%u m=%u: %llu k-mers, %.2f following k-mers claimed per k-mer of %.2f the key lasts (read ends included)\n", c[0], c[1],
+                (unsigned long long)seen, double(claimed) / double(seen ? seen : 1), double(lasted) / double(seen ? seen : 1));
     }
     /* bucket hashing: every choice inside the table */
     for (uint64_t key = 1; key < 100000; key += 7) {

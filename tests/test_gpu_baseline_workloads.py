@@ -174,33 +174,46 @@ def test_streaming_query_at_the_read_count_of_config_c4(synthetic_case):
     assert (summed == whole).all()
 
 
-def test_full_size_human_scale_dictionary_properties():
-    """BASELINE.json configs[2] at FULL size: the dictionary bench.py indexes by default (built here, or taken from the
-    bench's cache), 10^8 strided ids: lookup(access(id)) == id on both strands, is_member, two launches identical, and
-    10^8 random negatives all absent."""
+def full_size_dictionary(workload):
+    """the dictionary bench.py indexes for `workload` (built here, or taken from the bench's cache) and the index file it came from"""
+    import bench
+    from sshash_amd.repeats import load_recipe
+
+    bases, recipe, _, _ = bench.WORKLOADS[workload]
+    r = load_recipe(recipe)
+    args = argparse.Namespace(bases=bases, k=int(r["k"]), m=int(r["m"]), recipe=recipe, repeat_scale=1.0, canonical=False, seed=0x5555AAAA,
+                              cache_dir=os.environ.get("SSHASH_BENCH_CACHE", "/tmp"), verbose=False)
+    d, path = bench.get_index(args, 0, 1, lambda: None)
+    d.to_device(0)
+    return d, path, args
+
+
+@pytest.mark.parametrize("workload,least_kmers", [("c3", 2_400_000_000), ("c2", 850_000_000), ("c4", 2_600_000_000)])
+def test_full_size_dictionary_properties(workload, least_kmers):
+    """BASELINE.json configs[2], [1] and [3] at FULL size -- the very dictionaries bench.py measures (C3: human scale k = 31, C2: S. enterica
+    pangenome scale, C4: human scale k = 63, two-word k-mers): 10^8 strided ids (5 x 10^7 at k = 63): lookup(access(id)) == id on both
+    strands (test/check.hpp:29-49), is_member, two launches identical, 10^8 random negatives all absent (:78-96) -- and the CPU oracle
+    over 10^6 queries of the bench's own 50/50 mix, read from the index file on disk."""
     import torch
 
-    import bench
-    from sshash_amd.synthetic import revcomp_device
+    from oracle import oracle as O
+    from sshash_amd.synthetic import draw_queries_device, revcomp_device
 
-    bases, recipe, _, _ = bench.WORKLOADS["c3"]
-    args = argparse.Namespace(bases=bases, k=31, m=21, recipe=recipe, repeat_scale=1.0, canonical=False, seed=0x5555AAAA,
-                              cache_dir=os.environ.get("SSHASH_BENCH_CACHE", "/tmp"), verbose=False)
-    d, _ = bench.get_index(args, 0, 1, lambda: None)
-    d.to_device(0)
-    assert d.num_kmers() > 2_400_000_000
+    d, path, args = full_size_dictionary(workload)
+    k, W = args.k, 1 if args.k <= 31 else 2
+    assert d.num_kmers() > least_kmers and d.k() == k
     stats = d.device_stats(0)
-    assert stats["sk_slots"] > 0, "the human-scale dictionary must be served by the super-k-mer table"
+    assert stats["sk_slots"] > 0, "the full-size dictionaries must be served by the super-k-mer table"
     dev = torch.device("cuda", 0)
-    n = 100_000_000
+    n = 100_000_000 if W == 1 else 50_000_000
     stride = d.num_kmers() // n
     ids = torch.arange(n, dtype=torch.int64, device=dev) * stride + 7
-    q = torch.empty((n, 1), dtype=torch.int64, device=dev)
+    q = torch.empty((n, W), dtype=torch.int64, device=dev)
     d.access_packed_device(0, ids.data_ptr(), n, q.data_ptr())
     out = torch.empty(n, dtype=torch.int64, device=dev)
     again = torch.empty(n, dtype=torch.int64, device=dev)
     member = torch.empty(n, dtype=torch.uint8, device=dev)
-    for qq in (q, revcomp_device(q, 31).contiguous()):
+    for qq in (q, revcomp_device(q, k).contiguous()):
         d.lookup_device(0, qq.data_ptr(), n, out.data_ptr())
         d.lookup_device(0, qq.data_ptr(), n, again.data_ptr())
         d.is_member_device(0, qq.data_ptr(), n, member.data_ptr())
@@ -208,23 +221,77 @@ def test_full_size_human_scale_dictionary_properties():
         assert int((out != ids).sum().item()) == 0
         assert torch.equal(out, again)
         assert int((member != 1).sum().item()) == 0
+    del again, member
     g = torch.Generator(device=dev)
     g.manual_seed(11)
-    neg = ((torch.randint(0, 1 << 31, (n,), generator=g, device=dev, dtype=torch.int64) << 31)
-           | torch.randint(0, 1 << 31, (n,), generator=g, device=dev, dtype=torch.int64))
+
+    def random_words(count, bits):  # uniform `bits`-bit values as int64 (bits <= 62)
+        hi = torch.randint(0, 1 << (bits - 31), (count,), generator=g, device=dev, dtype=torch.int64)
+        return (hi << 31) | torch.randint(0, 1 << 31, (count,), generator=g, device=dev, dtype=torch.int64)
+
+    if W == 1:
+        neg = random_words(n, 62).unsqueeze(1)
+    else:  # k = 63: 126 bits in two words (64 + 62)
+        low = random_words(n, 62) ^ (random_words(n, 33) << 31)  # all 64 bits of word 0 vary
+        neg = torch.stack([low, random_words(n, 2 * k - 64)], dim=1).contiguous()
     d.lookup_device(0, neg.data_ptr(), n, out.data_ptr())
     torch.cuda.synchronize()
-    # a uniformly random 31-mer IS in the dictionary with probability 2 * 2.5e9 / 4^31 ~ 1e-9: 0.1 expected among 10^8;
+    # a uniformly random 31-mer IS in the dictionary with probability 2 * 2.5e9 / 4^31 ~ 1e-9: 0.1 expected among 10^8 (none at k = 63);
     # whatever is reported found must really be there
     found = torch.nonzero(out != -1)[:, 0]
     assert found.numel() <= 3
     if found.numel():
-        back = torch.empty((found.numel(), 1), dtype=torch.int64, device=dev)
+        back = torch.empty((found.numel(), W), dtype=torch.int64, device=dev)
         hit_ids = out[found].contiguous()
         d.access_packed_device(0, hit_ids.data_ptr(), found.numel(), back.data_ptr())
         torch.cuda.synchronize()
-        asked = neg[found].unsqueeze(1)
-        assert bool(((back == asked) | (revcomp_device(back, 31) == asked)).all().item())
+        asked = neg[found]
+        assert bool(((back == asked).all(dim=1) | (revcomp_device(back, k) == asked).all(dim=1)).all().item())
+    del neg, q, ids
+    # the oracle (CPU restatement, reading the index file the dictionary was loaded from) over the bench's own mix
+    m = 1_000_000
+    dq = draw_queries_device(d, 0, m, 0.5, seed=args.seed + 99)
+    d.lookup_device(0, dq.data_ptr(), m, out.data_ptr())
+    torch.cuda.synchronize()
+    got = out[:m].cpu().numpy().view(np.uint64)
+    want = O.OracleIndex(path).lookup_ids(dq.cpu().numpy().view(np.uint64), num_threads=max(1, len(os.sched_getaffinity(0))))
+    assert (got == want).all()
+    assert 0.49 < float((got != INVALID).mean()) < 0.51
+    d.close()
+
+
+def test_streaming_query_against_the_full_size_k63_dictionary():
+    """BASELINE.json configs[3] on the dictionary it names: the streaming query's six counters on 60 000 reads of the bench's own set (half
+    from the 2.96 G-base k = 63 dictionary with 1 % substitutions, half random, N at 1e-3) equal the CPU oracle's restated state machine
+    (include/streaming_query.hpp:48-197) -- through the run-based kernel, the per-base kernel of rounds 1-4 and the position-parallel pipeline."""
+    import torch
+
+    from oracle import oracle as O
+    from sshash_amd.synthetic import make_reads_device
+
+    d, path, args = full_size_dictionary("c4")
+    dev = torch.device("cuda", 0)
+    n, L = 60_000, 150
+    reads = make_reads_device(d, 0, n, L, positive_fraction=0.5, seed=args.seed + 7)
+    offsets = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    want = O.OracleIndex(path).streaming_query([bytes(r) for r in reads.cpu().numpy()])
+    names = ("num_kmers", "num_positive_kmers", "num_negative_kmers", "num_invalid_kmers", "num_searches", "num_extensions")
+    assert want["num_kmers"] == n * (L - 63 + 1) and want["num_extensions"] > 10 * want["num_searches"] > 0 and want["num_invalid_kmers"] > 0
+    for how in ("runs", "bases", "positions"):
+        report = torch.zeros(6, dtype=torch.int64, device=dev)
+        os.environ.pop("SSHASH_AMD_STREAM_WALK", None)
+        if how == "bases":
+            os.environ["SSHASH_AMD_STREAM_WALK"] = "bases"
+        try:
+            if how == "positions":
+                d.streaming_lookup_device(0, reads.data_ptr(), offsets.data_ptr(), n, n * L, 0, d_report=report.data_ptr())
+            else:
+                d.streaming_query_device(0, reads.data_ptr(), offsets.data_ptr(), n, report.data_ptr())
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("SSHASH_AMD_STREAM_WALK", None)
+        got = dict(zip(names, (int(v) for v in report.cpu().tolist())))
+        assert got == {f: int(v) for f, v in want.items()}, how
     d.close()
 
 
