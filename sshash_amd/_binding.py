@@ -374,7 +374,7 @@ class Dictionary:
                 "directory_keys": int(out[3]), "sk_slots": int(out[4]), "sk_keys": int(out[5]), "sk_inline_keys": int(out[6]),
                 "sk_deferred_keys": int(out[7]), "sk_slots_used": int(out[8]), "sk_heavy_keys": int(out[9]),
                 "sk_heavy_kmers": int(out[10]), "sk_absent_reason": reasons.get(int(out[11]), str(int(out[11]))),
-                "sk_bytes": int(out[12]), "sk_load_factor": round(int(out[8]) / int(out[4]), 4) if int(out[4]) else 0.0}
+                "sk_bytes": int(out[12]), "sk_key_length": int(out[13]), "sk_load_factor": round(int(out[8]) / int(out[4]), 4) if int(out[4]) else 0.0}
 
     def device_table_histogram(self, device: int = 0) -> dict:
         """Keys of the super-k-mer table by number of occurrences (sshash_device_table_histogram)."""

@@ -477,6 +477,7 @@ SSH_HD uint32_t sk_key_persists(sk_key_t const& kk, uint32_t k, uint32_t m, uint
 #pragma unroll
 #endif
         for (uint32_t t = SK_PERSIST_MAX; t >= 1; --t) {
+            if (t > k - m) continue;  // uniform: no key lasts longer than k - m k-mers (k = 31, m = 21: ten steps of the twenty)
             /* forward: the 12 bases from base t - 1 of ahead_f; other strand: the reverse complement of the 12 bases from base t - 1 of
                ahead_r = the 12 bases from base 32 - 12 - (t - 1) of `behind` */
             newcomer(t - 1 < 16 ? funnel32(f_lo, f_hi, 2 * (t - 1)) : f_hi >> (2 * (t - 1 - 16)), t);

@@ -192,7 +192,8 @@ void engine::device_stats(int device, uint64_t out[16]) const {
     out[10] = r->sk_heavy_kmers;
     out[11] = r->view.sk.enabled ? 0 : r->sk_absent_reason;
     out[12] = r->sk_bytes;
-    out[13] = out[14] = out[15] = 0;
+    out[13] = r->view.sk.m;  // length of the table's keys (sk_table_m; the ranks of a sharded lookup compare it: sharded.cpp)
+    out[14] = out[15] = 0;
 }
 
 void engine::device_table_histogram(int device, uint64_t out[32]) const {
@@ -570,8 +571,15 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
         }
         if (!active) return;
     } else {
-        if constexpr (W == 1 && !CANON) r = fast_lookup_pairs(d, x, active, check_rc);  // (32-byte units fetched by pairs of lanes)
-        else r = active ? fast_lookup_one<W, CANON>(d, x, check_rc) : fast_unsettled(false);
+        /* (32-byte units fetched by pairs of lanes: pair_load32 posts a unit as a 32-bit number, enough for 2^37 bases of strings --
+           uniform; past that every lane reads its own units: ADVICE r4) */
+        bool by_pairs = false;
+        if constexpr (W == 1 && !CANON) by_pairs = (d.num_bases >> 37) == 0;
+        if (by_pairs) {
+            if constexpr (W == 1 && !CANON) r = fast_lookup_pairs(d, x, active, check_rc);
+        } else {
+            r = active ? fast_lookup_one<W, CANON>(d, x, check_rc) : fast_unsettled(false);
+        }
         /* a MIDLOAD bucket whose first position did not settle the query: the rest of it is scanned by whole waves
            (scan_lookup_kernel), not by this lane while its 63 neighbours wait */
         const bool scan = active && r.outcome == FAST_SCAN;

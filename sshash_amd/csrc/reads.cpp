@@ -400,8 +400,12 @@ fastq_pieces::parsed fastq_pieces::parse(uint64_t i, uint32_t k, char* bases, ui
         while (p < n && from + p < next_cut) {
             const uint64_t b0 = line_end(p) + 1;   // behind the header
             if (starved) break;
-            if (b0 >= n) {                         // a header and nothing behind it: the sequential reader ends here as well
-                p = n;
+            if (b0 >= n) {
+                if (!whole) {                      // the header's line end is the buffer's last byte: more of the file is needed, not less
+                    starved = true;
+                    break;
+                }
+                p = n;                             // a header and nothing behind it: the sequential reader ends here as well
                 break;
             }
             const uint64_t e1 = line_end(b0);      // the bases: [b0, e1)

@@ -71,9 +71,11 @@ public:
        = 0). `raw` is the calling thread's scratch for the file bytes (kept between calls). */
     parsed parse(uint64_t i, uint32_t k, char* bases, uint64_t bases_capacity, uint64_t* offsets, uint64_t offsets_capacity,
                  std::vector<char>& raw) const;
-    /* enough for any piece: bases <= the bytes looked at, a read of >= k bases takes >= 2 k + 6 bytes of file */
+    /* enough for any piece: bases <= the bytes looked at; a read of >= k bases takes >= k + 6 bytes of file ('@', four line ends, a
+       '+', its bases -- nothing is validated, so the quality line may be empty: ADVICE r4, a file of such records used to overflow the
+       offsets sized for 2 k + 6 and fall back to the sequential reader after partial work) */
     uint64_t bases_capacity() const { return piece_ + slack_; }
-    uint64_t offsets_capacity(uint32_t k) const { return (piece_ + slack_) / (2 * uint64_t(k) + 6) + 2; }
+    uint64_t offsets_capacity(uint32_t k) const { return (piece_ + slack_) / (uint64_t(k) + 6) + 2; }
 
 private:
     int fd_ = -1;

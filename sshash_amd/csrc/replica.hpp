@@ -1,6 +1,8 @@
 // replica.hpp -- one dictionary replica resident in the HBM of one device (internal header).
 #pragma once
 
+#include <atomic>
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -52,6 +54,8 @@ struct device_replica {
     uint64_t directory_entries = 0;     // keys resident in the directory
     uint64_t sk_keys = 0, sk_heavy_keys = 0, sk_heavy_kmers = 0, sk_unplaced = 0, sk_slots_used = 0, sk_bytes = 0;  // super-k-mer table
     uint32_t sk_absent_reason = 1;  // SK_ABSENT_* (0 = the table is there)
+    /* sharded lookups (sharded.cpp): the number of ranks this replica has compared its table key length with (0: not yet) */
+    mutable std::atomic<uint32_t> peers_share_table_key{0};
     /* keys of the table by number of occurrences (bins SK_HIST_BINS: 1, 2, 3, 4, 5-8, 9-16, 17-64, 65-1024, > 1024):
        [0..9) keys per bin, [9..18) occurrences (= super-k-mers) per bin; [18] super-k-mers, [19] slots asked for */
     uint64_t sk_histogram[20] = {0};

@@ -50,6 +50,21 @@ void engine::sharded_lookup_device(int device, uint32_t num_ranks, bool by_table
     const uint32_t W = rep->view.k <= 31 ? 1 : 2, R = num_ranks;
     stream_buffers buf{s, rep, {}};
 
+    /* 0. (first call of this replica with this many ranks) every rank elects table keys of the same length: the length steers which
+       rank owns a key (route_bucket_kernel BY_KEY, sk_owner) and is read from the environment when a replica is built
+       (SSHASH_AMD_SK_M: sktable.hip), so ranks started under different environments would route keys to ranks that do not hold
+       them -- complete-path fallbacks at best, misses on table shards -- with nothing to show for it. One more
+       exchange of R words, once. */
+    if (by_table_key && rep->peers_share_table_key.load() != R) {
+        std::vector<uint64_t> mine(R, uint64_t(rep->view.sk.m)), theirs(R, 0);
+        call(x.counts(x.ctx, mine.data(), theirs.data()), "table key length");
+        for (uint32_t r = 0; r < R; ++r)
+            if (theirs[r] != mine[r])
+                throw error(error_kind::argument, "sharded lookup: rank " + std::to_string(r) + " elects table keys of " + std::to_string(theirs[r]) +
+                                                      " bases, this rank of " + std::to_string(mine[r]) + " (SSHASH_AMD_SK_M must be the same on every rank)");
+        rep->peers_share_table_key.store(R);
+    }
+
     /* 1. route: messages per owner, then the messages themselves in per-owner regions (engine.hip: route_bucket_kernel) */
     uint64_t* d_cursors = buf.get<uint64_t>(R);
     HIP_CHECK(hipMemsetAsync(d_cursors, 0, R * sizeof(uint64_t), s));

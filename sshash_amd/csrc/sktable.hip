@@ -554,6 +554,9 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     const uint64_t slot_bytes = wide ? 64 : 32;
     const uint64_t table_bytes = key_buckets * SK_BUCKET_SLOTS * slot_bytes + kmer_buckets * 64;
     if (num_buckets >= (uint64_t(1) << 32)) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);
+    /* k <= 63: the in-wave hops post a bucket as a 32-bit LINE number -- two lines a bucket of the keys' region, one of the k-mers'
+       (lookup_device.hpp: sk_finish_in_wave<2>): that number must fit too (a table of 256 GB would have wrapped silently) */
+    if (wide && 2 * key_buckets + kmer_buckets >= (uint64_t(1) << 32)) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);
     {
         size_t free_bytes = 0, total_bytes = 0;
         HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));

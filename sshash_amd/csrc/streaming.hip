@@ -483,31 +483,31 @@ __device__ __forceinline__ uint64_t extend_run(dict_view const& d, const uint64_
     return run;
 }
 
-/* sk_probe (lookup_device.hpp) for a seed of the run-based kernel: the same walk, with two differences. The first bucket's choice and
-   the key's fingerprint are hashed alone (sk_hash_first) -- the other four choices cost three more 64-bit multiplies and one probe in
-   twenty looks at them. And the slots say for how many of the following k-mers with the same key occurrence a miss stands (`lasts`:
-   sk_examine_slot_tracking); a probe that has to go on past its first bucket, or meets its key's marker, promises nothing. */
+/* sk_probe (lookup_device.hpp) for a seed of the run-based kernel: the same walk, with three differences. The first bucket's choice and
+   the key's fingerprint are hashed alone (sk_hash_first, by the caller) -- the other four choices cost three more 64-bit multiplies and
+   one probe in twenty looks at them. The first bucket's line has been fetched by the wave together (sk_stage_lines: the four lanes of a
+   quad read one line with one instruction -- ONE address translation a line; a lane reading its own line in four 16-byte pieces asks for
+   four, and at 70 G translation misses a second chip-wide that, not DRAM, bounded the first version of this kernel: 2.28 x 10^9 misses
+   for 5 x 10^8 probes, profiles/r05/streaming_run_kernel_v2_random_pmc_summary.json) and is read out of LDS (`mine`). And the slots
+   say for how many of the following k-mers with the same key occurrence a miss stands (`lasts`: sk_examine_slot_tracking); a probe that
+   has to go on past its first bucket, or meets its key's marker, promises nothing. */
 template <int W>
 __device__ __forceinline__ fast_t stream_probe(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
-                                               sk_line_cache& cache, uint32_t& lasts) {
-    uint32_t b, fingerprint;
-    sk_hash_first(kk.key, d.sk.num_buckets, b, fingerprint);
+                                               uint32_t b, uint32_t fingerprint, const uint4* mine, uint32_t& lasts) {
     sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, fingerprint);
     fast_t r = fast_unsettled(false);
     lasts = 0xFFFFu;
-    const uint4* B0 = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(b);
-    if (b != cache.bucket) {
-        cache.bucket = b;
-        for (int i = 0; i < 4; ++i) cache.piece[i] = B0[i];
-    }
-    const uint4 c0 = cache.piece[0], c1 = cache.piece[1], c2 = cache.piece[2], c3 = cache.piece[3];
-    auto cached = [c0, c1, c2, c3](uint32_t i) { return i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3; };
+    auto staged = [mine](uint32_t i) { return mine[i]; };
     sk_bucket_flags flags;
     bool marker = false, seen = false;
-    sk_examine_slot_tracking<W, true, true>(d, Q, 0, cached, r, seen, marker, flags, lasts);
+    sk_examine_slot_tracking<W, true, true>(d, Q, 0, staged, r, seen, marker, flags, lasts);
     if (r.outcome == FAST_MISS && flags.second_used) {
-        if constexpr (W == 1) sk_examine_slot_tracking<W, false, true>(d, Q, 0, [cached](uint32_t i) { return cached(2 + i); }, r, seen, marker, flags, lasts);
-        else sk_examine_slot_tracking<W, false, true>(d, Q, 0, [B0](uint32_t i) { return B0[2 * W + i]; }, r, seen, marker, flags, lasts);
+        if constexpr (W == 1) {
+            sk_examine_slot_tracking<W, false, true>(d, Q, 0, [mine](uint32_t i) { return mine[2 + i]; }, r, seen, marker, flags, lasts);
+        } else {  // slot 1 lives in the bucket's second line, and only the lanes whose key's fingerprint is there get here
+            const uint4* B1 = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(b) + 2 * W;
+            sk_examine_slot_tracking<W, false, true>(d, Q, 0, [B1](uint32_t i) { return B1[i]; }, r, seen, marker, flags, lasts);
+        }
     }
     const uint32_t first_go_on = flags.go_on;
     if (r.outcome != FAST_MISS || (!marker && first_go_on == 0)) return r;  // found, or a miss that is final here
@@ -543,11 +543,13 @@ __device__ __forceinline__ fast_t stream_probe(dict_view const& d, kmer_w<W> con
     return r;
 }
 
-template <int W, bool CANON, bool SK>
-__global__ void __launch_bounds__(256)
+template <int W, bool CANON, bool SK, int OCC>
+__global__ void __launch_bounds__(256, OCC)
 streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const uint64_t* __restrict__ packed,
                      const uint64_t* __restrict__ okay, const uint64_t* __restrict__ offsets, const uint64_t n_reads,
                      const uint64_t reads_per_wave, uint64_t* __restrict__ report) {
+    __shared__ uint4 stage[SK ? 4 * 256 : 1];  // a wave's 64 bucket lines on their way from the quads that fetch them to the lanes that own them
+    uint4* const wave_stage = stage + (SK ? (threadIdx.x >> 6) * 256 : 0);
     uint64_t c_kmers = 0, c_invalid = 0, c_negative = 0, c_searches = 0, c_extensions = 0;
     const uint32_t k = d.k;
     const uint32_t lane = threadIdx.x & 63u;
@@ -562,7 +564,6 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
     int ori = 1;
     bool neg_unknown_mini = false;          // (no table) streaming_query.hpp:150-157
     uint64_t prev_f = 0, prev_r = 0;
-    sk_line_cache line_cache;
     for (;;) {
         /* -- the reads: whoever has none left takes the next of the wave's share -- */
         const bool want = cur + k > rd_end;
@@ -591,33 +592,45 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             neg_unknown_mini = false;
             live = cur + k <= rd_end;
         }
-        if (!live) continue;  // (as a lane: the others go on)
-        if (pending) {
-            /* -- the run behind the hit of the turn before -- */
-            pending = false;
-            const uint64_t valid_end = inv < rd_end ? inv : rd_end;
+        const uint64_t valid_end = inv < rd_end ? inv : rd_end;
+        /* -- this turn's event of the lane: the run behind the hit of the turn before, or a seed -- */
+        if (live && pending) {
             const uint64_t run = extend_run<W>(d, packed, off, ori, cur + k - 1, valid_end - (cur + k - 1));
             c_extensions += run;
             cur += run;
-            continue;
+            live = false;  // (its next k-mer waits for the next turn: it may lie over an invalid base, or in the next read)
         }
-        /* -- seed() at cur (streaming_query.hpp:144-197) -- */
-        kmer_w<W> x;
-        {
+        pending = false;
+        /* -- seed() at cur (streaming_query.hpp:144-197): the k-mer, its key, its key's first bucket -- */
+        kmer_w<W> x = kmer_zero<W>(), x_rc = kmer_zero<W>();
+        sk_key_t kk{};
+        uint64_t ahead_f = 0, ahead_r = 0;
+        uint32_t bucket = 0, fingerprint = 0;
+        bool table = false;
+        if (live) {
             const uint64_t i = cur >> 5;
             const uint32_t sh = 2 * (uint32_t(cur) & 31u);
             const uint64_t w0 = packed[i], w1 = packed[i + 1];
             x.w[0] = funnel_shr(w0, w1, sh);
             if constexpr (W == 2) x.w[1] = funnel_shr(w1, packed[i + 2], sh);
             x = kmer_take_chars<W>(x, k);
+            x_rc = kmer_revcomp<W>(x, k);
+            if constexpr (SK) {
+                /* what sk_key_persists looks at, asked for together with the k-mer's own words: one wait for all of the read this turn needs */
+                const uint32_t sm = d.sk.m, hashed = sm < 12 ? sm : 12;
+                ahead_f = read_bases32(packed, cur + k - sm + 1);
+                ahead_r = read_bases32(packed, cur + k + 1 - hashed);
+                kk = sk_key<W>(x, x_rc, k, sm);
+                table = sk_usable(d, kk);
+                sk_hash_first(kk.key, d.sk.num_buckets, bucket, fingerprint);
+            }
         }
-        const kmer_w<W> x_rc = kmer_revcomp<W>(x, k);
         bool settled = false, found = false;
         if constexpr (SK) {
-            const sk_key_t kk = sk_key<W>(x, x_rc, k, d.sk.m);
-            if (sk_usable(d, kk)) {
+            sk_stage_lines<W>(d, bucket, 0u, table, wave_stage);  // (all 64 lanes, whatever their event)
+            if (table) {
                 uint32_t lasts;
-                const fast_t r = stream_probe<W>(d, x, x_rc, kk, line_cache, lasts);
+                const fast_t r = stream_probe<W>(d, x, x_rc, kk, bucket, fingerprint, wave_stage + (lane & 3u) * 64 + (lane >> 2) * 4, lasts);
                 if (r.outcome != FAST_DEFER) {
                     settled = true;
                     found = r.outcome == FAST_HIT;
@@ -627,9 +640,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                         /* a miss that stands for the k-mers behind this one: those that elect the same key occurrence (sk_key_persists)
                            and still hold the base that keeps the read and the key's slot apart (`lasts`; no slot with the key: all of
                            them) are negative as well -- counted, not looked at */
-                        const uint32_t sm = d.sk.m, hashed = sm < 12 ? sm : 12;
-                        uint64_t keep = sk_key_persists<W>(kk, k, sm, read_bases32(packed, cur + k - sm + 1), read_bases32(packed, cur + k + 1 - hashed));
-                        const uint64_t valid_end = inv < rd_end ? inv : rd_end;
+                        uint64_t keep = sk_key_persists<W>(kk, k, d.sk.m, ahead_f, ahead_r);
                         keep = keep < lasts ? keep : lasts;
                         keep = keep < valid_end - (cur + k) ? keep : valid_end - (cur + k);
                         c_negative += keep;
@@ -638,7 +649,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 }
             }
         }
-        if (!settled) {
+        if (live && !settled) {
             /* no table, or a tie / an unplaced key / another shard's key: the complete seed() */
             const minimizer_t mf = compute_minimizer<W>(x, k, d.m, d.hash_magic);
             const minimizer_t mr = compute_minimizer<W>(x_rc, k, d.m, d.hash_magic);
@@ -654,15 +665,16 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 neg_unknown_mini = !SK && !h.found && !h.minimizer_found;
             }
         }
-        if (found) {
-            ++c_searches;
-            neg_unknown_mini = false;
-            const uint64_t valid_end = inv < rd_end ? inv : rd_end;
-            pending = cur + 1 + k <= valid_end;  // (otherwise nothing can extend it)
-        } else {
-            ++c_negative;
+        if (live) {
+            if (found) {
+                ++c_searches;
+                neg_unknown_mini = false;
+                pending = cur + 1 + k <= valid_end;  // (otherwise nothing can extend it)
+            } else {
+                ++c_negative;
+            }
+            ++cur;
         }
-        ++cur;
     }
     block_report(c_kmers, c_invalid, c_negative, c_searches, c_extensions, report);
 }
@@ -700,8 +712,15 @@ void launch_streaming_runs(device_replica const* rep, dict_view const& d, char c
     waves = (waves + 3) / 4 * 4;
     const uint64_t reads_per_wave = (n_reads + waves - 1) / waves;
     const dim3 grid(uint32_t(waves / 4)), block(256);
-    if (d.sk.enabled) hipLaunchKernelGGL((streaming_run_kernel<W, CANON, true>), grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, report);
-    else hipLaunchKernelGGL((streaming_run_kernel<W, CANON, false>), grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, report);
+    static const int occ = [] {  // (A/B: waves per SIMD the kernel is compiled for)
+        char const* e = std::getenv("SSHASH_AMD_STREAM_OCC");
+        return e ? std::atoi(e) : 4;
+    }();
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, report); };
+    if (!d.sk.enabled) launch(streaming_run_kernel<W, CANON, false, 4>);
+    else if (occ == 5) launch(streaming_run_kernel<W, CANON, true, 5>);
+    else if (occ == 6) launch(streaming_run_kernel<W, CANON, true, 6>);
+    else launch(streaming_run_kernel<W, CANON, true, 4>);
     HIP_CHECK(hipGetLastError());
 }
 
