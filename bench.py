@@ -97,7 +97,7 @@ def get_index(args, rank: int, world: int, barrier):
     """Build the synthetic dictionary once (rank 0), cache it on local disk, load it on every rank."""
     import sshash_amd
 
-    key = f"v4-{args.bases}-{args.k}-{args.m}-{int(args.canonical)}-{args.seed}-{args.recipe}-{args.repeat_scale}-{recipe_digest(args.recipe)}"
+    key = f"v5-{args.bases}-{args.k}-{args.m}-{int(args.canonical)}-{args.seed}-{args.recipe}-{args.repeat_scale}-{recipe_digest(args.recipe)}"
     path = os.path.join(args.cache_dir, "sshash_amd_bench_" + hashlib.sha1(key.encode()).hexdigest()[:16] + ".sshash")
     if rank == 0 and not os.path.exists(path):
         t0 = time.time()
@@ -197,8 +197,12 @@ def measure_other_paths(args, index_path, device, d, dq, W, bytes_per_lookup):
         if not bool((out == ids_of_table_path).all().item()):
             raise SystemExit(f"PARITY FAILURE: the {name} path and the table path disagree")
         gbs = bytes_per_lookup * m / (ms * 1e-3) / 1e9
+        traffic, provenance = traffic_record(d, m, args, path=name)
         res[name] = {"lookups_per_s": round(m / ms * 1e3, 1), "ms": round(ms, 3), "queries": m, "ids_equal_table_path": True,
-                     "device_index_bytes": st["bytes"], "roofline_frac": round(gbs / HBM_PEAK_GBS, 5), "algorithmic_GBps": round(gbs, 1)}
+                     "device_index_bytes": st["bytes"], "roofline_frac": round(gbs / HBM_PEAK_GBS, 5), "algorithmic_GBps": round(gbs, 1),
+                     "traffic": traffic, "traffic_provenance": provenance,
+                     "hbm_traffic_bytes_per_lookup": round(traffic / m, 2) if traffic else None,
+                     "frac_hbm_traffic": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None}
         d2.close()
     return res
 
@@ -261,24 +265,35 @@ def measure_streaming_from_file(d, index_path, reads_tensor, directory, tag, ora
     return res
 
 
-def traffic_record(d, n_local: int, args):
-    """HBM bytes per step from the PMC passes of THIS workload (profiles/traffic.json: one record per workload name, written by
-    tools/make_traffic_json.py from rocprofv3 --pmc runs of this very command); None when no record fits this run's shape. The
-    provenance (file, commit, counters) is printed with the number."""
+def traffic_key(args, path=None):
+    """name of this run's record in profiles/traffic.json (tools/make_traffic_json.py)"""
+    name = args.workload + ("_canonical" if args.canonical else "")
+    if path:
+        return f"{name}_{path}"
+    return f"{name}_streaming_p{int(round(args.positive * 100))}" if args.streaming else name
+
+
+def traffic_record(d, n_local: int, args, path=None):
+    """HBM bytes per step from the PMC passes of THIS workload (profiles/traffic.json: one record per traffic_key, written by
+    tools/make_traffic_json.py from rocprofv3 --pmc runs of this very command); None when no record fits this run's shape (n_local:
+    queries, or reads, of this GPU). The provenance (file, commit, counters) is printed with the number."""
     prof = os.path.join(ROOT, "profiles", "traffic.json")
+    key = traffic_key(args, path)
     try:
-        recs = json.load(open(prof))
+        rec = json.load(open(prof)).get(key)
     except Exception:
         return None, None
-    rec = recs.get(args.workload) if "queries" not in recs else (recs if args.workload == "c3" else None)  # (round-3 file: one record, C3's)
     if not rec:
         return None, None
-    same = (rec.get("queries") == n_local and rec.get("bases") == args.bases and rec.get("canonical") == args.canonical
-            and rec.get("k", 31) == args.k)
+    same = rec.get("canonical") == args.canonical and rec.get("k", 31) == args.k and rec.get("bases") in (None, args.bases, d.num_bases())
+    if args.streaming and not path:
+        same = same and rec.get("reads") == n_local and rec.get("read_length") == args.read_len
+    else:
+        same = same and rec.get("queries") == n_local
     if not same:
         return None, None
-    return rec.get("hbm_bytes_per_launch"), {"file": "profiles/traffic.json", "workload": args.workload, "commit": rec.get("commit"),
-                                            "counters": rec.get("counters"), "note": rec.get("note"), "source": rec.get("source")}
+    return rec.get("hbm_bytes_per_launch"), {"file": "profiles/traffic.json", "record": key, "commit": rec.get("commit"),
+                                            "counters": rec.get("counters"), "note": rec.get("unit_note"), "source": rec.get("source")}
 
 
 def random_line_probe(device=None):
@@ -326,6 +341,30 @@ def run_other_workload(args, extra, env_extra=None):
     if env_extra:
         line["environment"] = dict(env_extra)  # a replica configured otherwise than the default (the switches)
     return line
+
+
+def streaming_roofline(d, args, n_reads_local, W, achieved, avg_kernel_ms, kernel_ms, algorithmic, rep, n_local_kmers, bytes_per_lookup):
+    """the roofline object of a streaming line: algorithmic bytes against the HBM peak, the PMC traffic of this very workload
+    (profiles/traffic.json) and the 64-byte lines it asks of the memory system against the random-line rate"""
+    traffic, provenance = traffic_record(d, n_reads_local, args)
+    roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "traffic_provenance": provenance,
+            "kernel": "streaming_run_kernel<W=%d> + stream_pack_kernel (a lane handles the events of its read -- a seed, or the word-wise extension behind a hit --, "
+                      "reads packed to 2 bits first; avg_kernel_ms = HIP-event time around one step, on the launch stream)" % W,
+            "avg_kernel_ms": round(avg_kernel_ms, 3), "kernel_ms_steps": [round(float(t), 3) for t in kernel_ms],
+            "algorithmic_bytes_per_kmer": round(algorithmic / rep["num_kmers"], 3),
+            "algorithmic_bytes_rule": "1 B per base + (searches + negatives) x the oracle-counted bytes of a lookup (%.1f B: the reference's seed() is a "
+                                      "full lookup) + extensions x 8 W B (the string's next k-mer)" % bytes_per_lookup}
+    if traffic:
+        roof["frac_hbm_traffic"] = round(traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        roof["hbm_traffic_bytes_per_kmer"] = round(traffic / n_local_kmers, 3)
+        # what bounds a kernel of dependent random reads is random LINES, not bytes (tools/tlb_probe): the step's 64-byte requests per second
+        # against the rate a kernel doing nothing else sustains -- this box's (attached by the parent run) first, the r02 constant second
+        lines = traffic / 64.0
+        roof["random_unit_bound"] = {"probe_units_per_s": RANDOM_UNIT_PROBE, "source": "profiles/r02/tlb_probe_128_256_byte_units.jsonl",
+                                     "units": "64-byte requests of the step (PMC traffic / 64)", "units_per_s_this_gpu": round(lines / (avg_kernel_ms * 1e-3), 1),
+                                     "frac": round(lines / (avg_kernel_ms * 1e-3) / RANDOM_UNIT_PROBE, 4)}
+    return roof
 
 
 def streaming_mode(args, d, index_path, rank, world, local_rank, dev, use_dist, dist, coll_dev, barrier, stats):
@@ -440,16 +479,10 @@ def streaming_mode(args, d, index_path, rank, world, local_rank, dev, use_dist, 
                    "device_index_bytes": d.device_bytes(local_rank), "report": rep,
                    "positive_fraction_of_kmers": round(rep["num_positive_kmers"] / rep["num_kmers"], 4),
                    "extensions_per_search": round(rep["num_extensions"] / max(1, rep["num_searches"]), 2),
-                   "counters_equal_oracle_on_reads": m, "device_stats": stats},
+                   "counters_equal_oracle_on_reads": m, "num_bases": d.num_bases(), "device_stats": stats},
         "per_rank": per_rank,
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": None, "kernel": "streaming_kernel<W=%d> (one read per lane; avg_kernel_ms = HIP-event time around one step, on the launch stream)" % W,
-                     "avg_kernel_ms": round(avg_kernel_ms, 3), "kernel_ms_steps": [round(float(t), 3) for t in kernel_ms],
-                     "algorithmic_bytes_per_kmer": round(algorithmic / rep["num_kmers"], 3),
-                     "algorithmic_bytes_rule": "1 B per base + (searches + negatives) x the oracle-counted bytes of a lookup (%.1f B: the reference's seed() is a "
-                                               "full lookup) + extensions x 8 W B (the string's next k-mer)" % bytes_per_lookup,
-                     "bound_note": "a lane walks its read's dependent chain (extend or seed): latency of the chain per lane, not bytes, bounds this kernel "
-                                   "(DESIGN.md section 6)"},
+        "traffic_key": traffic_key(args),
+        "roofline": streaming_roofline(d, args, n, W, achieved, avg_kernel_ms, kernel_ms, algorithmic, rep, n_local_kmers, bytes_per_lookup),
         "cpu_baseline": {"value": round(want["num_kmers"] / t_oracle, 1), "unit": "k-mers/s", "cores": 1, "kind": "port",
                          "sample": f"the first {m} reads of the same set through the oracle's streaming state machine on one thread (the reference's query "
                                    f"tool is single-threaded): {t_oracle / max(1, want['num_kmers']) * 1e9:.1f} ns per k-mer",
@@ -689,7 +722,7 @@ def main():
                     # what bounds a structure of one random bucket per query on this chip is random UNITS, not bytes: 43.8 G
                     # random 64-byte units/s, 39.9 G 128-byte ones (tools/tlb_probe)
                     "random_unit_bound": {"probe_units_per_s": RANDOM_UNIT_PROBE, "source": "profiles/r02/tlb_probe_128_256_byte_units.jsonl",
-                                          "lookups_per_s_this_gpu": round(n / (avg_kernel_ms * 1e-3), 1),
+                                          "lookups_per_s_this_gpu": round(n / (avg_kernel_ms * 1e-3), 1), "units_per_s_this_gpu": round(n / (avg_kernel_ms * 1e-3), 1),
                                           "frac": round(n / (avg_kernel_ms * 1e-3) / RANDOM_UNIT_PROBE, 4)}}
         if traffic:
             # the kernels' own bytes: what the PMC passes of this very workload saw moving between L2 and HBM per step
@@ -787,13 +820,15 @@ def main():
                                          f"{'canonical' if d.canonical() else 'regular'}, {d.num_kmers()} k-mers, index replicated per GPU; ONE batch of "
                                          f"{args.queries} packed queries per step ({args.positive:.0%} positive, half reverse-complemented; negatives {args.negatives}) "
                                          f"split over {world} GPU(s)",
-                       "ids_equal_oracle_on_queries": sample,
+                       "ids_equal_oracle_on_queries": sample, "num_bases": d.num_bases(),
                        "queries_per_step": args.queries, "queries_per_gpu": n, "num_kmers": d.num_kmers(), "k": d.k(), "m": d.m(),
                        "canonical": d.canonical(), "index_replicated_per_gpu": sharded is None, "sharded": args.sharded,
                        "positive_fraction_found": round(found, 4), "device_index_bytes": d.device_bytes(local_rank),
                        "device_bytes_per_kmer": round(d.device_bytes(local_rank) / d.num_kmers(), 2),
                        "device_stats": stats, "recipe": args.recipe, "repeat_scale": args.repeat_scale,
                        "index_statistics": index_statistics, "table_histogram": table_histogram},
+            "traffic_key": traffic_key(args, {("0", "1"): "directory", ("0", "0"): "mphf"}.get(
+                (os.environ.get("SSHASH_AMD_SKTABLE", "1"), os.environ.get("SSHASH_AMD_DIRECTORY", "1")))),
             "per_rank": per_rank,
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -833,7 +868,7 @@ def main():
                 if bound is not None:
                     bound["this_box"] = dict(probe)
                     if "probe_units_per_s" in probe:
-                        bound["this_box"]["frac"] = round(bound["lookups_per_s_this_gpu"] / probe["probe_units_per_s"], 4)
+                        bound["this_box"]["frac"] = round(bound["units_per_s_this_gpu"] / probe["probe_units_per_s"], 4)
             log(f"random-line probe: {probe}")
     barrier()
     if use_dist:

@@ -10,6 +10,7 @@
 
 #include "../../include/sshash_amd.h"
 #include "engine.hpp"
+#include "hooks.hpp"
 #include "reads.hpp"
 
 using namespace sshash_amd;
@@ -349,7 +350,7 @@ sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char*
         }
         /* an uncompressed FASTQ is read and parsed by all the lanes at once (reads.hpp: fastq_pieces); a file that is not four
            lines per record comes back here and takes the sequential reader */
-        if (!multiline && fastq_pieces::applicable(filename) && !std::getenv("SSHASH_AMD_SEQUENTIAL_READER")) {
+        if (!multiline && fastq_pieces::applicable(filename) && !test_hook_u64("sequential_reader", 0, 0, 1)) {
             streaming_report r;
             if (d->eng->streaming_query_fastq_pieces(filename, r)) {
                 report->num_kmers = r.num_kmers;
@@ -364,7 +365,7 @@ sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char*
         /* The file goes through in batches of ~256 MiB of bases (a FASTQ of hundreds of gigabytes must not be
            materialised): a reader thread decompresses batch i+1 while the devices work on batch i. */
         uint64_t batch_bases = uint64_t(256) << 20;
-        if (char const* e = std::getenv("SSHASH_AMD_QUERY_BATCH_BASES")) batch_bases = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));  // tests
+        batch_bases = test_hook_u64("query_batch_bases", batch_bases, 1, ~uint64_t(0));  // (tests: batch seams inside a small file)
         read_batch slot[2];
         std::mutex mu;
         std::condition_variable cv;

@@ -274,6 +274,26 @@ SSH_HD void sk_hash_first(uint64_t key, uint32_t num_buckets, uint32_t& bucket, 
     fingerprint = uint32_t(a) & 0xFFFFFFu;
 }
 
+/* choice c of a key's bucket sequence out of the key and the `a` of sk_hash_first's arithmetic, computed when it is asked for: what
+   sk_hash lays out in advance (three more 64-bit multiplies), for a walk that nineteen times in twenty never leaves its first bucket */
+SSH_HD uint64_t sk_hash_a(uint64_t key) {
+    uint64_t a = key * 0xFF51AFD7ED558CCDULL;
+    a ^= a >> 32;
+    a *= 0xC4CEB9FE1A85EC53ULL;
+    a ^= a >> 29;
+    return a;
+}
+SSH_HD uint32_t sk_choice_of(uint64_t key, uint64_t a, uint32_t c, uint32_t num_buckets) {
+    if (c == 0) return mulhi32(uint32_t(a >> 32), num_buckets);
+    uint64_t b = (a ^ key) * 0x9E3779B97F4A7C15ULL;
+    b ^= b >> 31;
+    if (c == 1) return mulhi32(uint32_t(b >> 32), num_buckets);
+    if (c == 2) return mulhi32(uint32_t(b), num_buckets);
+    const uint64_t cc = (a + b) * 0xD6E8FEB86659FD93ULL;
+    if (c == 3) return mulhi32(uint32_t(cc), num_buckets);
+    return mulhi32(uint32_t((cc ^ (cc >> 31)) * 0x9E3779B1u + uint32_t(a)), num_buckets);
+}
+
 /* bucket sequence of a heavy key's k-mer: hashed into the k-mers' region */
 SSH_HD sk_hash_t sk_hash_kmer_region(uint64_t kmer_key, uint32_t first_bucket, uint32_t kmer_buckets) {
     sk_hash_t h = sk_hash(kmer_key, kmer_buckets);
@@ -491,167 +511,6 @@ SSH_HD uint32_t sk_key_persists(sk_key_t const& kk, uint32_t k, uint32_t m, uint
         }
     }
     return first - 1 < most ? first - 1 : most;
-}
-
-/* The same election for a k-mer that SLIDES along a read one base at a time (the streaming query): sk_key looks at all
-   2 (k - m + 1) candidates of every k-mer; a read's consecutive k-mers share all but two of them. The hash of a candidate does
-   not depend on where in the k-mer it lies (sk_select_hash adds the position, it does not mix it in), so the minimum over the
-   window of n = k - m + 1 occurrences is kept the classical way: the occurrences are taken in blocks of n; a window is a suffix of
-   one block and a prefix of the next; the prefix minimum runs along (one min per base and strand), the suffix minima of a block
-   are made when the block is complete (in place, over the n hashes the block left in `column`: n private words per strand and
-   lane -- LDS on the device). Per base: two candidates hashed, two minima, one word pair stored and one loaded, and 2n loads
-   and stores every n bases -- about 30 vector instructions where sk_key takes 3.5 x 22 at k = 31, m = 21 and 2.5 x 78 at k = 63,
-   m = 25. Ties as in sk_key: per strand the leftmost occurrence among equal hashes -- on the forward strand the OLDEST of the
-   read, on the reverse complement the NEWEST. tests/cpp/check_table_key.cpp holds it against sk_key base by base.
-
-   Column: word pairs (forward, reverse complement) indexed 0 .. n-1; load(i) -> uint2-like {x, y}, store(i, x, y). */
-struct sk_roll_state {
-    uint32_t b;       // block index of the newest occurrence (n - 1 before the first)
-    uint32_t pf, pr;  // prefix minima of the running block: hash << 6 | tiebreak
-    uint32_t sf, sr;  // suffix minima of the block before, from where this base's window starts (all ones: none)
-};
-
-SSH_HD void sk_roll_start(sk_roll_state& st, uint32_t k, uint32_t m) {
-    st.b = k - m;
-    st.pf = st.pr = st.sf = st.sr = 0xFFFFFFFFu;
-}
-
-/* the newest occurrence -- the last m bases of x, the first m of x_rc -- as sk_elect hands its candidates to sk_select_hash */
-template <int W>
-SSH_HD void sk_roll_newest(kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m, uint32_t& wf, uint32_t& wr) {
-    const uint32_t s = 2 * (k - m);  // uniform
-    if constexpr (W == 1) {
-        const uint32_t lo = uint32_t(x.w[0]), hi = uint32_t(x.w[0] >> 32);
-        wf = s < 32 ? funnel32(lo, hi, s) : hi >> (s - 32);
-    } else {
-        const uint32_t j = s >> 5, t = s & 31u;  // 32-bit word j of four, one more (zero) behind them
-        const uint32_t w0 = uint32_t(x.w[0]), w1 = uint32_t(x.w[0] >> 32), w2 = uint32_t(x.w[1]), w3 = uint32_t(x.w[1] >> 32);
-        const uint32_t lo = j == 0 ? w0 : j == 1 ? w1 : j == 2 ? w2 : w3;
-        const uint32_t hi = j == 0 ? w1 : j == 1 ? w2 : j == 2 ? w3 : 0u;
-        wf = funnel32(lo, hi, t);
-    }
-    wr = uint32_t(x_rc.w[0]);
-    wf ^= sk_select_salt<W>();
-    wr ^= sk_select_salt<W>();
-    if (m < 12) {  // uniform: see sk_elect, MASKED
-        wf <<= 24 - 2 * m;
-        wr <<= 24 - 2 * m;
-    }
-}
-
-/* after the read's base has entered x (at its last place) and x_rc (at its first), from the (m - 1)-th base of the read on */
-template <int W, class Column>
-SSH_HD void sk_roll_push(sk_roll_state& st, kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m, Column& column) {
-    const uint32_t n = k - m + 1, mul = sk_select_mul();
-    const uint32_t b = st.b + 1 == n ? 0u : st.b + 1;
-    st.b = b;
-    uint32_t wf, wr;
-    sk_roll_newest<W>(x, x_rc, k, m, wf, wr);
-    const uint32_t hf = sk_select_hash(wf, b, mul);        // equal hashes: the smaller b, the older occurrence
-    const uint32_t hr = sk_select_hash(wr, 63u - b, mul);  // equal hashes: the larger b, the newer occurrence
-    st.pf = b == 0 ? hf : (hf < st.pf ? hf : st.pf);
-    st.pr = b == 0 ? hr : (hr < st.pr ? hr : st.pr);
-    if (b + 1 < n) {  // the window starts at place b + 1 of the block before
-        const auto before = column.load(b + 1);
-        st.sf = before.x;
-        st.sr = before.y;
-    } else {
-        st.sf = st.sr = 0xFFFFFFFFu;
-    }
-    column.store(b, hf, hr);
-    if (b + 1 == n) {  // the block is complete: its suffix minima, in place
-        uint32_t f = 0xFFFFFFFFu, r = 0xFFFFFFFFu;
-        for (uint32_t i = n; i-- > 0;) {
-            const auto h = column.load(i);
-            f = h.x < f ? h.x : f;
-            r = h.y < r ? h.y : r;
-            column.store(i, f, r);
-        }
-    }
-}
-
-/* the key of the k-mer that ends at the base pushed last (a whole k-mer: at least k bases pushed) -- what sk_key<W>(x, x_rc, k, m) returns */
-template <int W>
-SSH_HD sk_key_t sk_roll_key(sk_roll_state const& st, kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m) {
-    const uint32_t n = k - m + 1, b = st.b;
-    const bool whole = b + 1 == n;  // the window is the running block
-    const uint32_t hSf = st.sf >> SK_POS_BITS, hPf = st.pf >> SK_POS_BITS, hSr = st.sr >> SK_POS_BITS, hPr = st.pr >> SK_POS_BITS;
-    const bool f_from_prefix = whole || hPf < hSf;    // equal: the older block's
-    const bool r_from_suffix = !whole && hSr < hPr;   // equal: the newer block's
-    const uint32_t best_f = f_from_prefix ? hPf : hSf, best_r = r_from_suffix ? hSr : hPr;
-    /* places in the block -> positions on the strand: the window starts at place b + 1 of the block before */
-    const uint32_t pos_f = f_from_prefix ? n - 1 - b + (st.pf & 63u) : (st.sf & 63u) - b - 1;
-    const uint32_t pos_r = r_from_suffix ? b + n - (63u - (st.sr & 63u)) : b - (63u - (st.pr & 63u));
-    sk_key_t out;
-    out.rc = best_r < best_f;
-    out.tie = best_r == best_f;
-    out.pos = out.rc ? pos_r : pos_f;
-    out.hash = out.rc ? best_r : best_f;
-    out.key = kmer_shr_chars<W>(out.rc ? x_rc : x, out.pos).w[0] & low_mask(2 * m);
-    return out;
-}
-
-/* The same with ONE word per place -- half the LDS, which is what decides at k <= 63 (n = 39 at m = 25: 80 KB a workgroup with
-   word pairs left two waves a SIMD and the kernel a third slower than electing from scratch). A place keeps the smaller of its two
-   strands' hashes: 24 hash bits | ambiguous | strand | place. The minimum over the window then names strand and place of the winner
-   directly -- PROVIDED it is the only candidate with its 24 hash bits: wherever two equal hash prefixes meet in a minimum the entry
-   is marked ambiguous (the marks travel with the minima), and a k-mer whose window minimum is so marked is elected from scratch
-   (sk_key): equal hashes are where sk_key's rules -- leftmost per strand, tie between the strands -- matter, and they are rare
-   (a 12-mer repeated inside the window, on either strand). */
-constexpr uint32_t SK_ROLL1_AMBIGUOUS = 0x80u, SK_ROLL1_RC = 0x40u, SK_ROLL1_NONE = 0xFFFFFFFFu;
-struct sk_roll1_state {
-    uint32_t b;  // block index of the newest occurrence
-    uint32_t p;  // minimum of the running block so far
-    uint32_t s;  // minimum of the block before, from where this base's window starts (SK_ROLL1_NONE: the window is the running block)
-};
-
-SSH_HD uint32_t sk_roll1_combine(uint32_t a, uint32_t b) {
-    const uint32_t least = a < b ? a : b;
-    return ((a ^ b) >> 8) == 0 ? least | SK_ROLL1_AMBIGUOUS : least;
-}
-
-SSH_HD void sk_roll1_start(sk_roll1_state& st, uint32_t k, uint32_t m) {
-    st.b = k - m;
-    st.p = st.s = SK_ROLL1_NONE;
-}
-
-/* Column: words indexed 0 .. n-1; load(i), store(i, word) */
-template <int W, class Column>
-SSH_HD void sk_roll1_push(sk_roll1_state& st, kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m, Column& column) {
-    const uint32_t n = k - m + 1, mul = sk_select_mul();
-    const uint32_t b = st.b + 1 == n ? 0u : st.b + 1;
-    st.b = b;
-    uint32_t wf, wr;
-    sk_roll_newest<W>(x, x_rc, k, m, wf, wr);
-    const uint32_t ef = (sk_select_hash(wf, 0u, mul) & 0xFFFFFF00u) | b;
-    const uint32_t er = (sk_select_hash(wr, 0u, mul) & 0xFFFFFF00u) | SK_ROLL1_RC | b;
-    const uint32_t here = sk_roll1_combine(ef, er);
-    st.p = b == 0 ? here : sk_roll1_combine(st.p, here);
-    st.s = b + 1 < n ? column.load(b + 1) : SK_ROLL1_NONE;
-    column.store(b, here);
-    if (b + 1 == n) {  // the block is complete: its suffix minima, in place (the last place is its own)
-        uint32_t least = here;
-        for (uint32_t i = n - 1; i-- > 0;) {
-            least = sk_roll1_combine(column.load(i), least);
-            column.store(i, least);
-        }
-    }
-}
-
-/* the key of the k-mer that ends at the base pushed last; false: ambiguous, ask sk_key */
-template <int W>
-SSH_HD bool sk_roll1_key(sk_roll1_state const& st, kmer_w<W> const& x, kmer_w<W> const& x_rc, uint32_t k, uint32_t m, sk_key_t& out) {
-    const uint32_t n = k - m + 1, b = st.b;
-    const uint32_t least = st.s == SK_ROLL1_NONE ? st.p : sk_roll1_combine(st.s, st.p);
-    if (least & SK_ROLL1_AMBIGUOUS) return false;
-    const uint32_t place = least & 63u;
-    const bool before = place > b;  // a place of the block before (they are b + 1 .. n - 1)
-    out.rc = (least & SK_ROLL1_RC) != 0;
-    out.tie = false;
-    out.hash = least >> 8;  // (24 bits of it: not comparable with sk_key's -- sk_key_persists is for keys elected by sk_key)
-    out.pos = out.rc ? (before ? b + n - place : b - place) : (before ? place - b - 1 : n - 1 - b + place);
-    out.key = kmer_shr_chars<W>(out.rc ? x_rc : x, out.pos).w[0] & low_mask(2 * m);
-    return true;
 }
 
 struct dict_view {

@@ -11,6 +11,7 @@
 #include <thread>
 
 #include "engine.hpp"
+#include "hooks.hpp"
 #include "replica.hpp"
 #include "sktable.hpp"
 
@@ -225,8 +226,7 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
     {
         static std::once_flag once;
         std::call_once(once, [] {
-            if (!std::getenv("SSHASH_AMD_QUIET"))
-                fprintf(stderr, "[sshash_amd] WARNING: this library was NOT built through tools/isa_guard.py (make -C sshash_amd/csrc): on gfx950 a "
+            fprintf(stderr, "[sshash_amd] WARNING: this library was NOT built through tools/isa_guard.py (make -C sshash_amd/csrc): on gfx950 a "
                                 "kernel that keeps a 64-bit shift amount in the last VGPR of its allocation computes wrongly some of the time "
                                 "(DESIGN.md section 6); tests/test_isa_guard.py names the kernels of a build that are exposed\n");
         });
@@ -448,8 +448,6 @@ struct pass_queues {
        reference's flag depends on which arbitrary bucket the MPHF lands on): misses are queued with DEFER_FLAG_ONLY set
        and the last pass stores that one byte for them */
     uint32_t flag_misses;
-    /* the first pass finishes every probe itself (sk_lookup_in_wave); the resume queue stays empty */
-    uint32_t finish_in_wave;
 };
 constexpr uint32_t DEFER_FLAG_ONLY = 1u << 31;  // in a deferred-queue entry (query indices stay below 2^27)
 
@@ -540,20 +538,12 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
     const uint32_t shard = blockIdx.x & (DEFER_SHARDS - 1);  // the queues are sharded by workgroup: one hot counter would
                                                              // serialise at ~90 atomics/us
     if constexpr (SK) {
-        /* k <= 31 (SSHASH_INWAVE_WIDE: k <= 63 as well -- measured in round 4, profiles/r04/inwave_k63_ab.txt: 27.1 -> 25.6 G lookups/s;
-           the loop's state takes the kernel from 60 to 86 registers, 8 to 5 waves per SIMD, and a pass that runs at the random-line rate
-           wants the waves) */
-#ifdef SSHASH_INWAVE_WIDE
-        constexpr bool IN_WAVE = true;
-#else
-        constexpr bool IN_WAVE = W == 1;
-#endif
-        bool whole = false;
-        if constexpr (IN_WAVE) {
-            whole = q.finish_in_wave != 0;  // uniform
-            if (whole) r = sk_lookup_in_wave<W>(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1), lds + (threadIdx.x >> 6) * (64 * 4));
-        }
-        if (!whole)
+        /* k <= 31: a probe that needs more than its key's first bucket is finished inside the wave (sk_finish_in_wave). k <= 63: it joins
+           the resume pass -- finishing in the wave there measured 27.1 -> 25.6 G lookups/s (profiles/r04/inwave_k63_ab.txt: the loop's state
+           takes the kernel from 60 to 86 registers, 8 to 5 waves per SIMD, and a pass that runs at the random-line rate wants the waves) */
+        if constexpr (W == 1)
+            r = sk_lookup_in_wave<W>(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1), lds + (threadIdx.x >> 6) * (64 * 4));
+        else
             r = sk_first_pass_wave<W>(d, x, active, CANON || check_rc, (!CANON && check_rc) ? int8_t(-1) : int8_t(1),
                                       lds + (threadIdx.x >> 6) * (64 * 4));
         /* whatever needs a second dependent read joins the compacted second pass, with its packed k-mer (no lane leaves
@@ -603,13 +593,7 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
            such a shift is wrong in 6-7 % of its executions -- the "0.15 % of the indexed k-mers absent, differently from launch to
            launch" of rounds 2 and 3, which an asm keep-alive of three dead registers used to hide by moving the allocation to 72.
            tools/isa_guard.py now pads such kernels when the library is built; DESIGN.md section 6, tools/debug/vgpr64_check.hip.) */
-#if defined(SSHASH_DEBUG_MEMBER_SKIP_DEFER)   // (tools/debug: no placeholder for the lanes the deferred pass rewrites)
-        if (r.outcome != FAST_DEFER) __builtin_nontemporal_store(uint8_t(r.outcome == FAST_HIT ? 1 : 0), member + i);
-#elif defined(SSHASH_DEBUG_MEMBER_CODES_FIRST)  // (tools/debug: what the first pass thought)
-        __builtin_nontemporal_store(uint8_t(r.outcome == FAST_HIT ? 1 : (r.outcome == FAST_DEFER ? 0x80 : 0)), member + i);
-#else
         __builtin_nontemporal_store(uint8_t(r.outcome == FAST_HIT ? 1 : 0), member + i);
-#endif
     } else {
         hit_t h;
         h.kmer_offset = r.kmer_offset;
@@ -815,11 +799,7 @@ deferred_lookup_kernel(const dict_view d, const skew_part_dev* __restrict__ skew
         }
         const hit_t h = lookup_one<W, CANON, true>(d, skew, x, check_rc);
         if constexpr (MODE == int(out_mode::member)) {
-#ifdef SSHASH_DEBUG_MEMBER_CODES_DEFERRED  // (tools/debug: tell the deferred pass's answers from the first pass's)
-            member[i] = h.found ? 0x41 : 0x40;
-#else
             member[i] = h.found ? 1 : 0;
-#endif
         } else {
             store_result<MODE == int(out_mode::full)>(d, out, i, h);
         }
@@ -838,63 +818,19 @@ static result_view advance(result_view v, uint64_t at) {
     return v;
 }
 
-/* queries per launch sequence (first, resume, deferred): at most 2^27 (queue entries carry 27-bit indices) */
-static uint64_t launch_piece_queries() {
-    static const uint64_t piece = [] {
-        uint64_t v = uint64_t(1) << 27;
-        if (const char* e = std::getenv("SSHASH_AMD_PIECE")) {  // measurement knob
-            const uint64_t want = std::strtoull(e, nullptr, 10);
-            if (want >= 4096 && want <= (uint64_t(1) << 27)) v = want;
-        }
-        return v;
-    }();
-    return piece;
-}
+/* queries per launch sequence (first, resume, deferred): at most 2^27 (queue entries carry 27-bit indices); the tests cut a small batch
+   into several (hooks.hpp) */
+static uint64_t launch_piece_queries() { return test_hook_u64("piece", uint64_t(1) << 27, 4096, uint64_t(1) << 27); }
 
-/* the resume queue holds half a launch piece; a query that finds it full takes the complete path instead. The divisor
-   is a test knob: with 64 nearly every resumed query overflows (tests/test_gpu_parity.py) */
-static uint32_t resume_capacity_divisor() {
-    if (const char* e = std::getenv("SSHASH_AMD_RESUME_DIVISOR")) {
-        const unsigned long v = std::strtoul(e, nullptr, 10);
-        if (v >= 1 && v <= 4096) return uint32_t(v);
-    }
-    return 2;
-}
+/* the resume queue holds half a launch piece; a query that finds it full takes the complete path instead (tests: a divisor of 64
+   makes nearly every resumed query overflow, tests/test_gpu_parity.py) */
+static uint32_t resume_capacity_divisor() { return uint32_t(test_hook_u64("resume_divisor", 2, 1, 4096)); }
 
-/* Tail passes on an auxiliary stream (launch()). SSHASH_AMD_OVERLAP: unset = when the deferred pass is the only tail pass
-   (k <= 31 with the table: sk_finish_in_wave) and the batch is cut into several launch sequences anyway; 1 = always, and a
-   batch is cut into at least OVERLAP_PIECES pieces for it; 0 = never. Measured on the calibrated stand-ins, same box,
-   alternating runs:
-     with a resume pass (profiles/r03/overlap_ab_c3.txt, overlap_ab_c2.txt): C3 35.90 / 35.95 / 35.81 G lookups/s without,
-       35.67 / 35.65 / 35.61 with; C2 (10^8 queries, four pieces) 33.5 / 34.6 / 33.5 without, 32.9 / 31.6 / 31.6 with. That tail
-       is not idle latency waiting to be hidden: it is more random line fetches (and partial-line id writes) for a memory
-       system the first pass already saturates, and the smaller pieces add launch tails;
-     deferred pass only (profiles/r03/overlap_deferred_only_ab.txt): C3 40.51 / 40.38 / 40.47 without, 40.94 / 40.88 / 40.81
-       with (+1.0 %: 68 us of dependent reads by a few thousand lanes per 3.0 ms sequence, beside the next first pass instead of
-       after this one); C2 forced into four pieces 37.7 / 37.9 -> 36.9 / 36.8, hence no forcing.
-   (Walking the rest of a probe inside the first pass itself, by the lane that needs it, SSHASH_AMD_INLINE_RESUME in
-   profiles/r03/inline_resume_ab.txt: no gain on C3, -4 % on C2; removed.) */
-enum class overlap_mode { never, when_cheap, always };
-static overlap_mode overlap_tail_passes() {
-    static const overlap_mode mode = [] {
-        const char* e = std::getenv("SSHASH_AMD_OVERLAP");
-        if (!e) return overlap_mode::when_cheap;
-        return e[0] == '1' ? overlap_mode::always : overlap_mode::never;
-    }();
-    return mode;
-}
-constexpr uint64_t OVERLAP_PIECES = 4, OVERLAP_MIN_QUERIES = uint64_t(1) << 22;
-
-/* k <= 31: probes that need more than their first bucket are finished inside the first pass (lookup_device.hpp: sk_finish_in_wave);
-   SSHASH_AMD_INWAVE=0 sends them to the resume pass instead (the round-2 form; k <= 63 always does: measured again in round 4) */
-static bool finish_in_wave() {
-    static const bool on = [] {
-        const char* e = std::getenv("SSHASH_AMD_INWAVE");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
-
+/* Tail passes on an auxiliary stream (launch()): when the deferred pass is the only tail pass (k <= 31 with the table: the rest is
+   finished in the wave) and the batch is cut into several launch sequences anyway. Measured on the calibrated stand-ins, same box,
+   alternating runs (HISTORY.md): with a resume pass overlapping LOSES (C3 35.9 -> 35.6, C2 33.5-34.6 -> 31.6-32.9: that tail is more
+   random line fetches for a memory system the first pass already saturates); deferred pass only: C3 40.4-40.5 -> 40.8-40.9 (+1.0 %);
+   cutting a batch into pieces for the sake of it: C2 37.8 -> 36.9, hence no forcing. */
 template <int W, bool CANON, int MODE, bool ASCII>
 static void launch(device_replica const* rep, void const* q, uint64_t n, bool check_rc,
                    result_view const& out, uint8_t* member, hipStream_t stream, uint8_t const* lane_valid) {
@@ -909,22 +845,16 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
         const bool wants_flag = MODE == int(out_mode::full) && out.minimizer_found;
         if (!(wants_flag && !d.sk.enabled)) {
             /* multi-pass: at most 2^27 queries per launch sequence (queue entries are 32-bit; the scratch
-               queues stay below 1.3 GiB (2.1 for 128-bit k-mers) per set). A batch is cut into at least OVERLAP_PIECES pieces
-               once it is large enough for that to pay, because the tail passes (resume, deferred: few, dependent, latency-bound
-               reads) of piece i run on an auxiliary stream while the caller's stream already runs the first pass of piece
-               i + 1 -- two sets of queues, used in turn; events order first(i) -> tail(i) -> first(i + 2). The caller's stream
-               waits for the last tail before the call returns control of it. */
+               queues stay below 1.3 GiB (2.1 for 128-bit k-mers) per set). When a batch takes several sequences and the deferred pass
+               is the only tail pass, the tail (few, dependent, latency-bound reads) of piece i runs on an auxiliary stream while the
+               caller's stream already runs the first pass of piece i + 1 -- two sets of queues, used in turn; events order
+               first(i) -> tail(i) -> first(i + 2). The caller's stream waits for the last tail before the call returns control of it. */
             const uint64_t piece_max = launch_piece_queries();
             uint64_t pieces = (n + piece_max - 1) / piece_max;
-#ifdef SSHASH_INWAVE_WIDE
-            const bool in_wave = d.sk.enabled && finish_in_wave();
-#else
-            const bool in_wave = W == 1 && d.sk.enabled && finish_in_wave();
-#endif
-            if (overlap_tail_passes() == overlap_mode::always && n >= OVERLAP_MIN_QUERIES) pieces = std::max<uint64_t>(pieces, OVERLAP_PIECES);
+            const bool in_wave = W == 1 && d.sk.enabled;
             const uint64_t piece = ((n + pieces - 1) / pieces + block - 1) / block * block;  // equal pieces, whole workgroups
             pieces = (n + piece - 1) / piece;
-            const bool overlap = pieces > 1 && (overlap_tail_passes() == overlap_mode::always || (overlap_tail_passes() == overlap_mode::when_cheap && in_wave));
+            const bool overlap = pieces > 1 && in_wave;
             const size_t qbytes = size_t(W) * 8, kbytes = d.k;
             const uint32_t nblocks_max = uint32_t((std::min(piece, n) + block - 1) / block);
             pass_queues shape{};
@@ -942,7 +872,6 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                 const uint32_t set = overlap ? uint32_t(index & 1) : 0u;
                 pass_queues pq = shape;
                 pq.flag_misses = wants_flag ? 1u : 0u;
-                pq.finish_in_wave = in_wave ? 1u : 0u;
                 char* scratch = static_cast<char*>(sc.block) + set * set_bytes;
                 if (overlap && index >= 2) HIP_CHECK(hipStreamWaitEvent(stream, sc.tail_done[set], 0));  // the set's queues are free again
                 HIP_CHECK(hipMemsetAsync(scratch, 0, 2 * DEFER_SHARDS * sizeof(uint32_t), stream));
@@ -968,9 +897,11 @@ static void launch(device_replica const* rep, void const* q, uint64_t n, bool ch
                     HIP_CHECK(hipStreamWaitEvent(sc.aux, sc.first_done[set], 0));
                     tail = sc.aux;
                 }
-                if (d.sk.enabled && !pq.finish_in_wave)
-                    hipLaunchKernelGGL((resume_lookup_kernel<W, CANON, MODE>), dim3(DEFER_SHARDS * RESUME_PARTS), dim3(block), 0, tail, d,
-                                       check_rc, ids, mem, pq);
+                if constexpr (W == 2) {  // (k <= 31 finishes every probe in the first pass's own waves)
+                    if (d.sk.enabled)
+                        hipLaunchKernelGGL((resume_lookup_kernel<W, CANON, MODE>), dim3(DEFER_SHARDS * RESUME_PARTS), dim3(block), 0, tail, d,
+                                           check_rc, ids, mem, pq);
+                }
                 if (!d.sk.enabled)
                     hipLaunchKernelGGL((scan_lookup_kernel<W, CANON, MODE>), dim3(DEFER_SHARDS * RESUME_PARTS), dim3(block), 0, tail, d,
                                        check_rc, ids, mem, pq);
@@ -1410,13 +1341,6 @@ namespace {
 constexpr uint64_t HOST_CHUNK = uint64_t(1) << 21;  // queries per lane round
 constexpr uint32_t HOST_LANES_MAX = 8;
 
-uint64_t env_u64(char const* name, uint64_t fallback, uint64_t lo, uint64_t hi) {  // measurement knobs
-    char const* e = std::getenv(name);
-    if (!e) return fallback;
-    const uint64_t v = std::strtoull(e, nullptr, 10);
-    return v >= lo && v <= hi ? v : fallback;
-}
-
 uint64_t align256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
 
 struct field_plan {  // where each output of a chunk lives inside the staging block
@@ -1495,8 +1419,8 @@ static void host_lookup(engine const& eng, std::vector<int> const& devs, void co
     if (n == 0) return;
     if (devs.empty()) throw error(error_kind::no_device, "dictionary is not resident on any device (call sshash_to_device first)");
     const uint64_t G = devs.size();
-    const uint64_t chunk = std::min<uint64_t>(env_u64("SSHASH_AMD_HOST_CHUNK", HOST_CHUNK, 1024, uint64_t(1) << 26), n);
-    const uint64_t max_lanes = env_u64("SSHASH_AMD_HOST_LANES", HOST_LANES_MAX, 1, 64);
+    const uint64_t chunk = std::min<uint64_t>(test_hook_u64("host_chunk", HOST_CHUNK, 1024, uint64_t(1) << 26), n);
+    const uint64_t max_lanes = test_hook_u64("host_lanes", HOST_LANES_MAX, 1, 64);
     const field_plan plan = plan_fields(mode, h_out, chunk, bytes_per_query);
     const uint64_t hw = std::max(1u, std::thread::hardware_concurrency());
 

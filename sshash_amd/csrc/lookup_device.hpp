@@ -913,78 +913,6 @@ __device__ __forceinline__ bool sk_walk_step(dict_view const& d, kmer_w<W> const
     return false;
 }
 
-/* One lane on its own, every piece read from global memory: the streaming query, whose lanes are at different
-   points of their reads when they need a seed. The first line of the key's first bucket stays in registers from one seed
-   to the next (`sk_line_cache`): consecutive k-mers of a read share their key more often than not -- the 30 negative seeds
-   that follow a substitution in a high-hit read, the k-mers of an absent region -- and then this probe needs no memory at
-   all unless it has to go on. */
-struct sk_line_cache {
-    uint32_t bucket = 0xFFFFFFFFu;
-    uint4 piece[4];
-};
-
-template <int W>
-__device__ __forceinline__ fast_t sk_probe(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
-                                           bool& key_seen, sk_line_cache& cache) {
-    sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), 0);
-    sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, w.h.fingerprint);
-    fast_t r = fast_unsettled(false);
-    key_seen = false;
-    bool more = true;
-    {
-        /* first bucket of the key's own sequence: through the cache */
-        const uint32_t b = sk_choice(w.h, 0);
-        const uint4* B = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(b);
-        if (b != cache.bucket) {
-            cache.bucket = b;
-            for (int i = 0; i < 4; ++i) cache.piece[i] = B[i];
-        }
-        const uint4 c0 = cache.piece[0], c1 = cache.piece[1], c2 = cache.piece[2], c3 = cache.piece[3];
-        auto cached = [c0, c1, c2, c3](uint32_t i) { return i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3; };
-        sk_bucket_flags flags;
-        bool marker = false, seen = false;
-        sk_examine_slot<W, true>(d, Q, w.c, cached, r, seen, marker, flags);
-        if (r.outcome == FAST_MISS && flags.second_used) {
-            if constexpr (W == 1) sk_examine_slot<W, false>(d, Q, w.c, [cached](uint32_t i) { return cached(2 + i); }, r, seen, marker, flags);
-            else sk_examine_slot<W, false>(d, Q, w.c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags);
-        }
-        key_seen = seen;
-        const uint32_t go_on = flags.go_on;
-        more = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
-    }
-#pragma unroll 1
-    while (more) {
-        /* k <= 63: the k-mers' region holds compact entries. (By the bucket's index, not by w.on_kmer_sequence: that stays set when a
-           probe comes back to the rest of its key's sequence.) */
-        const uint32_t bucket = sk_choice(w.h, w.c);
-        const bool compact = bucket >= d.sk.num_buckets;
-        const uint4* B = reinterpret_cast<const uint4*>(static_cast<char const*>(d.sk.slots) + sk_bucket_offset<W>(d, bucket, compact));
-        sk_bucket_flags flags;
-        bool marker = false, seen = false;
-        if constexpr (W == 2) {
-            if (compact) {
-                sk_examine_kmer_entry<true>(Q, w.c, [B](uint32_t i) { return B[i]; }, r, flags);
-                sk_examine_kmer_entry<false>(Q, w.c, [B](uint32_t i) { return B[2 + i]; }, r, flags);
-            }
-        } else {
-            if (compact) {
-                const uint4 l0 = B[0], l1 = B[1], l2 = B[2], l3 = B[3];
-                const uint32_t words[16] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
-                sk_examine_kmer_line(Q, w.c, [&words](uint32_t i) { return words[i]; }, r, flags);
-            }
-        }
-        if (!compact) {
-            sk_examine_slot<W, true>(d, Q, w.c, [B](uint32_t i) { return B[i]; }, r, seen, marker, flags);
-            if (r.outcome == FAST_MISS && flags.second_used)
-                sk_examine_slot<W, false>(d, Q, w.c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags);
-        }
-        key_seen = key_seen || (seen && !w.on_kmer_sequence);
-        const uint32_t go_on = flags.go_on;
-        more = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
-    }
-    return r;
-}
-
 /* ---- the same probe by a whole wave: quad-cooperative line fetch through LDS -----------------------------------
    Must be called by all 64 lanes of the wave together (lanes without a query pass need = false). Round p of a
    bucket fetch: the four lanes of every quad read the four 16-byte pieces of ONE 64-byte line -- the bucket of the
@@ -1225,11 +1153,10 @@ __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<
    queue entry written and read back, no second kernel, and above all no placeholder id that a later pass rewrites: an 8-byte
    store into a line that has left the caches costs the DRAM a masked write -- a random access of its own, one of the 2.5 a
    resumed query cost in the resume pass. */
-/* (k <= 63: the form further down, behind SSHASH_INWAVE_WIDE. Round 3 measured finishing in the wave there as a loss of 6 % and round
-   4, with ranked fetches everywhere, as a loss of 5.5 % -- profiles/r04/inwave_k63_ab.txt: 27.1 -> 25.6 G lookups/s. The k <= 63 first
-   pass runs at the chip's random-line rate (150.7 M line requests per 1.25 x 10^8 lookups in 3.38 ms = 44.6 G/s, vector ALUs 64 %
-   busy, profiles/r04/bench_c4_pmc_summary.json), and what it needs for that is waves in flight: the loop's state takes the kernel
-   from 60 to 86 registers, eight waves per SIMD to five. There the stragglers keep their own, compacted pass.) */
+/* (k <= 31 only. At k <= 63 finishing in the wave measured as a loss -- round 3: 6 %, round 4, with ranked fetches everywhere: 5.5 %,
+   profiles/r04/inwave_k63_ab.txt: 27.1 -> 25.6 G lookups/s. The k <= 63 first pass runs at the chip's random-line rate and what it
+   needs for that is waves in flight: the loop's state takes the kernel from 60 to 86 registers, eight waves per SIMD to five. There
+   the stragglers keep their own, compacted pass: resume_lookup_kernel.) */
 __device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<1> const& x, kmer_w<1> const& x_rc, sk_key_t const& kk, sk_walk_t& w,
                                                   sk_query_t<1>& Q, fast_t& r, bool need, uint4* wave_stage) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1263,66 +1190,6 @@ __device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<1> 
             }
             const uint32_t go_on = flags.go_on;
             need = sk_walk_step<1>(d, x, x_rc, kk, w, Q, r, go_on, marker);
-        }
-        sk_wave_sync();  // the staging area is rewritten by the next turn
-    }
-}
-
-/* The same at k <= 63, where a bucket of the keys' region is two lines (slot 0, slot 1) and a bucket of the k-mers' region one line of
-   two compact entries: a turn fetches ONE line per served lane -- a 64-byte line NUMBER is what it posts (the table stays below
-   2^32 lines = 256 GB) --: slot 0's line of a keys' bucket (and slot 1's line in a turn of its own, if slot 0 says the key's
-   fingerprint is there), or the line of a k-mers' bucket. */
-__device__ __forceinline__ void sk_finish_in_wave(dict_view const& d, kmer_w<2> const& x, kmer_w<2> const& x_rc, sk_key_t const& kk, sk_walk_t& w,
-                                                  sk_query_t<2>& Q, fast_t& r, bool need, uint4* wave_stage) {
-    const uint32_t lane = threadIdx.x & 63u;
-    char const* slots = static_cast<char const*>(d.sk.slots);
-    uint32_t* posted = reinterpret_cast<uint32_t*>(wave_stage + 64);
-    bool second = false;           // this lane's next line is slot 1's of the bucket it is at
-    uint32_t held_go_on = 0;       // what slot 0 of that bucket said, until slot 1 has been examined
-    bool held_marker = false;
-#pragma unroll 1
-    for (;;) {
-        const uint64_t mask = __ballot(need);
-        if (mask == 0) break;  // wave-uniform
-        const uint32_t rank = uint32_t(__popcll(mask & ((uint64_t(1) << lane) - 1)));
-        const bool served = need && rank < 16;
-        const uint32_t bucket = sk_choice(w.h, w.c);
-        const bool compact = bucket >= d.sk.num_buckets;
-        if (lane < 16) posted[lane] = 0u;
-        sk_wave_sync();
-        if (served) posted[rank] = compact ? 2 * d.sk.num_buckets + (bucket - d.sk.num_buckets) : 2 * bucket + (second ? 1u : 0u);
-        sk_wave_sync();
-        const uint32_t line = posted[lane >> 2];
-        wave_stage[lane] = sk_load_piece(slots + uint64_t(line) * 64 + 16 * (lane & 3u));
-        sk_wave_sync();
-        if (served) {
-            const uint4* mine = wave_stage + 4 * rank;
-            sk_bucket_flags flags;
-            flags.go_on = held_go_on;
-            flags.second_used = false;
-            bool marker = held_marker, key_seen = false;
-            bool step = true;
-            if (compact) {
-                sk_examine_kmer_entry<true>(Q, w.c, [mine](uint32_t i) { return mine[i]; }, r, flags);
-                sk_examine_kmer_entry<false>(Q, w.c, [mine](uint32_t i) { return mine[2 + i]; }, r, flags);
-            } else if (!second) {
-                sk_examine_slot<2, true>(d, Q, w.c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
-                if (r.outcome == FAST_MISS && flags.second_used) {  // slot 1 holds a key with this fingerprint: its line next
-                    second = true;
-                    held_go_on = flags.go_on;
-                    held_marker = marker;
-                    step = false;
-                }
-            } else {
-                sk_examine_slot<2, false>(d, Q, w.c, [mine](uint32_t i) { return mine[i]; }, r, key_seen, marker, flags);
-                second = false;
-            }
-            if (step) {
-                const uint32_t go_on = flags.go_on;
-                need = sk_walk_step<2>(d, x, x_rc, kk, w, Q, r, go_on, marker);
-                held_go_on = 0;
-                held_marker = false;
-            }
         }
         sk_wave_sync();  // the staging area is rewritten by the next turn
     }

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "replica.hpp"
+#include "hooks.hpp"
 #include "sktable.hpp"
 
 namespace sshash_amd {
@@ -487,10 +488,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     uint64_t K = 0;
     HIP_CHECK(hipMemcpy(&K, d_num_runs, 8, hipMemcpyDeviceToHost));
     double slots_per_key = wide ? SK_SLOTS_PER_KEY_WIDE : SK_SLOTS_PER_KEY;
-    if (const char* e = std::getenv("SSHASH_AMD_SK_SLOTS_PER_KEY")) {  // measurement knob
-        const double want = std::atof(e);
-        if (want >= 1.2 && want <= 16.0) slots_per_key = want;
-    }
+    slots_per_key = test_hook_f64("slots_per_key", slots_per_key, 1.2, 16.0);  // (tests: a packed table, where second choices and unplaced items are common)
     if (K == 0) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);
     uint32_t* run_begins = tmp.alloc<uint32_t>(K);
     {
@@ -540,10 +538,7 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     /* slots asked for: one per occurrence of a light key, one marker per heavy key -- the keys' region -- and one per k-mer of
        a heavy key, in the region behind it (sk_view::kmer_buckets) */
     double slots_per_kmer = wide ? SK_SLOTS_PER_KMER_WIDE : SK_SLOTS_PER_KMER_NARROW;
-    if (const char* e = std::getenv("SSHASH_AMD_SK_SLOTS_PER_KMER")) {  // measurement knob
-        const double want = std::atof(e);
-        if (want >= 1.2 && want <= 16.0) slots_per_kmer = want;
-    }
+    slots_per_kmer = test_hook_f64("slots_per_kmer", slots_per_kmer, 1.2, 16.0);
     const uint64_t wanted = (T - heavy_occurrences) + heavy_keys + heavy_kmers;
     const uint64_t key_buckets = uint64_t(double(wanted - heavy_kmers) * slots_per_key / SK_BUCKET_SLOTS) + 8;
     /* a bucket of the k-mers' region is one 64-byte line: two 32-byte entries at k <= 63, three 20-byte ones at k <= 31 (the k-mer

@@ -1,21 +1,17 @@
-// streaming.hip -- batched streaming query: one read per lane (gfx950 only).
+// streaming.hip -- batched streaming query (gfx950 only).
 //
 // Reference: streaming_query<Dict,canonical>::lookup / seed (include/streaming_query.hpp:56-109,
 // 144-197) driven per read by src/query.cpp:78-108. The state machine is sequential inside a
-// read and independent across reads, so reads are the parallel dimension. Per lane:
-//   * k-mer and its reverse complement are rolled one base at a time (:68-80);
-//   * while the previous k-mer matched at string offset `off`, the next k-mer is first compared
-//     with the string's own next k-mer ("extension", :86-100). With the granule layout the
-//     reference's `remaining_string_bases` counter is implicit: the window at off+-1 reports
-//     whether it runs across a string boundary, which is exactly remaining == 0;
-//   * otherwise seed(): the negative short-cut (:150-157), then the point lookups (:159-180).
-//     Minimizers are only needed inside seed(), so they are computed there, statelessly
-//     (the rolling iterators of include/minimizer_iterator.hpp return the same values: :56-57).
-//     When the replica has a super-k-mer table seed() goes through it (device_layout.hpp (5)): one slot read per
-//     seed instead of directory + window per strand. The negative short-cut becomes "same table key as
-//     the previous k-mer, and that key is provably not in the table" -- the same k-mers are negative
-//     either way, so the counters are unchanged; queries the table defers take the path above.
-// Output: the six counters of streaming_query_report (include/util.hpp:21-36).
+// read and independent across reads, so reads are the parallel dimension: a lane owns a read and
+// handles its EVENTS -- a seed (one point lookup, through the super-k-mer table when the replica has
+// one), or the run of extensions behind a hit, measured as a longest common prefix of the read and
+// the strings, 32 bases a step (streaming_run_kernel below). With the granule layout the reference's
+// `remaining_string_bases` counter is implicit: a string-start mark at the next base is exactly
+// remaining == 0. The negative short-cut (:150-157) becomes "the k-mers behind a miss that elect the
+// same table key, and cannot be in that key's slot either, are negative too" -- the same k-mers are
+// negative either way, so the counters are unchanged.
+// Output: the six counters of streaming_query_report (include/util.hpp:21-36); per-k-mer results:
+// the position-parallel pipeline further down.
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 
@@ -27,6 +23,7 @@
 #include <thread>
 
 #include "engine.hpp"
+#include "hooks.hpp"
 #include "reads.hpp"
 #include "replica.hpp"
 
@@ -92,265 +89,11 @@ __device__ __forceinline__ void block_report(uint64_t c_kmers, uint64_t c_invali
     atomicAdd(reinterpret_cast<unsigned long long*>(report + 5), (unsigned long long)t[4]);
 }
 
-/* a lane's private column of the rolling election (device_layout.hpp: sk_roll_*): n word pairs in LDS, place-major so that the 64
-   lanes of a wave touch 512 contiguous bytes */
-struct roll_column {
-    uint2* base;  // this lane's place 0
-    __device__ __forceinline__ uint2 load(uint32_t i) const { return base[i * 256u]; }
-    __device__ __forceinline__ void store(uint32_t i, uint32_t x, uint32_t y) const { base[i * 256u] = make_uint2(x, y); }
-};
-struct roll_column1 {  // one word a place (sk_roll1_*)
-    uint32_t* base;
-    __device__ __forceinline__ uint32_t load(uint32_t i) const { return base[i * 256u]; }
-    __device__ __forceinline__ void store(uint32_t i, uint32_t v) const { base[i * 256u] = v; }
-};
-/* LDS a workgroup may take for the election: k <= 31 keeps word pairs (exact by itself; n = 11 at m = 21: 22.5 KB), k <= 63 one word
-   a place (n = 39 at m = 25: 39 KB, three workgroups a CU -- as many waves as the kernel's registers allow anyway). Word pairs at
-   k = 63 (80 KB, two workgroups a CU): 31.6 -> 20.6 G k-mers/s (profiles/r04/streaming_rolling_election_k63_pairs_ab.txt). */
-constexpr uint32_t ROLL_LDS_LIMIT = 40u << 10;
-
-/* ROLL (SK only): the table key of a read's k-mers is elected incrementally -- two new candidates a base instead of all
-   2 (k - m + 1) at every seed; needs (k - m + 1) * 8 bytes of LDS per lane (the launch passes them) */
-template <int W, bool CANON, bool SK, bool ROLL>
-__global__ void __launch_bounds__(256, (ROLL && W == 2) ? 4 : 1)  // (four waves a SIMD, as without ROLL: 128 registers)
-streaming_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const char* __restrict__ bases,
-                 const uint64_t* __restrict__ offsets, const uint64_t n_reads, uint64_t* __restrict__ report) {
-    extern __shared__ uint2 roll_lds[];
-    constexpr bool PAIRS = W == 1;
-    roll_column column{roll_lds + threadIdx.x};
-    roll_column1 column1{reinterpret_cast<uint32_t*>(roll_lds) + threadIdx.x};
-    uint64_t c_kmers = 0, c_invalid = 0, c_negative = 0, c_searches = 0, c_extensions = 0;
-    const uint32_t k = d.k;
-    const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
-    for (uint64_t r = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; r < n_reads; r += stride) {
-        const uint64_t begin = offsets[r], len = offsets[r + 1] - begin;
-        if (len < k) continue;
-        c_kmers += len - k + 1;
-        kmer_w<W> x = kmer_zero<W>(), x_rc = kmer_zero<W>();
-        uint32_t valid_len = 0;
-        bool in_run = false;        // previous k-mer was found (remaining bases tracked via `off`)
-        bool neg_unknown_mini = false;  // previous k-mer: seed() said "negative, minimizer not in index"
-        uint64_t prev_f = 0, prev_r = 0;  // SK: prev_f holds the previous table key
-        uint64_t off = 0;
-        int ori = 1;
-        const char* p = bases + begin;
-        /* While a run of found k-mers is extended along a string, the string's k-mer at `off` is kept in registers (`at`)
-           and the next one is made from it with ONE base of the strings -- taken, with its string-start mark, from a block
-           of the strings cached in registers (64 bases at k <= 31, 32 at k <= 63). A window read per extension was a
-           dependent memory access per k-mer of a high-hit read; this is one per 32-64 extensions. */
-        kmer_w<W> at = kmer_zero<W>();
-        sk_line_cache line_cache;
-        sk_roll_state roll;
-        sk_roll1_state roll1;
-        if constexpr (ROLL && PAIRS) sk_roll_start(roll, k, d.sk.m);
-        if constexpr (ROLL && !PAIRS) sk_roll1_start(roll1, k, d.sk.m);
-        uint64_t c_idx = ~uint64_t(0) - 1, c_b0 = 0, c_b1 = 0, c_marks = 0;  // (neither c_idx nor c_idx + 1 is a block)
-        auto string_base = [&](uint64_t pb, uint32_t& base, bool& starts) {
-            const uint64_t idx = pb >> 5;
-            if constexpr (W == 1) {
-                if (idx != c_idx && idx != c_idx + 1) {
-                    const uint4* A = reinterpret_cast<const uint4*>(d.granules) + 2 * idx;
-                    const uint4 q0 = A[0], q1 = A[1];
-                    c_idx = idx;
-                    c_b0 = uint64_t(q0.x) | (uint64_t(q0.y) << 32);
-                    c_b1 = uint64_t(q0.z) | (uint64_t(q0.w) << 32);
-                    c_marks = uint64_t(q1.x) | (uint64_t(q1.y) << 32);
-                }
-                const uint32_t rel = uint32_t(pb - (c_idx << 5));  // 0 .. 63
-                base = uint32_t(((rel < 32 ? c_b0 : c_b1) >> (2 * (rel & 31u))) & 3u);
-                starts = ((c_marks >> rel) & 1u) != 0;
-            } else {
-                if (idx != c_idx) {
-                    const uint4 g = reinterpret_cast<const uint4*>(d.granules)[idx];
-                    c_idx = idx;
-                    c_b0 = uint64_t(g.z) | (uint64_t(g.w) << 32);
-                    c_marks = g.y;
-                }
-                const uint32_t rel = uint32_t(pb) & 31u;
-                base = uint32_t((c_b0 >> (2 * rel)) & 3u);
-                starts = ((c_marks >> rel) & 1u) != 0;
-            }
-        };
-        /* The lanes of a wave walk their reads base by base, in step, and a step costs the wave every path SOME lane takes: 478 vector and
-           336 scalar instructions per base and wave, the vector ALUs 83 % busy -- this kernel is bound by instruction issue (0.25 HBM lines per
-           k-mer: a third of the line rate; profiles/r04/streaming_kernel_stats_and_pmc_lockstep_kernel.txt). Two other schedules were
-           built and measured in round 4, both correct, both slower, because a wave lasts as long as its slowest lane:
-             * every lane runs ahead on its own while its k-mers extend a run and the lanes meet only at their seeds: 34.9 -> 16.8 G k-mers/s
-               on a high-hit set, 80.9 -> 60.4 on random reads (profiles/r04/streaming_advance_seed_phases_ab.txt) -- a phase lasts as long
-               as its LONGEST run (the maximum of 64 geometric run lengths is four times their mean), and 40 % of the lanes want a seed at
-               any base anyway: the k-mers over a substitution or a string junction are negative seeds, k in a row;
-             * a seed that needs more than its key's first bucket (one in twenty) waits, and the wave serves its waiting lanes one more bucket
-               every second / fourth / eighth step, so that the instructions of sk_probe's inner loop run at a fraction of the steps instead of
-               86 % of them: 44.0 -> 35.7 / 31.7 / 26.1 (streaming_waiting_seeds_ab.txt) -- the waiting lanes finish their reads later, and the
-               wave with them.
-           What helped this kernel in round 4 is what made the table's key cheaper (device_layout.hpp: 2.5 instructions per candidate) and
-           then ROLL: the key elected incrementally along the read (397 vector instructions per base and wave, 44.0 -> 48.9 G k-mers/s on
-           the high-hit set, 82 -> 104 on random reads; profiles/r04/streaming_rolling_election_ab.txt). With that the vector ALUs are
-           62 % busy and a wave spends 59 % of its time waiting (SQ_WAIT_ANY; no instruction-cache misses): a step now waits for its
-           slowest lane's memory access -- first the extension's (a block of the strings), then the seed's (a bucket line). A third
-           schedule, measured and not kept: the key elected and its bucket's line requested BEFORE the run is tried, so that the two
-           waits overlap -- 49.2 -> 40.7 high-hit, 104.6 -> 94.1 on random reads, 31.8 -> 26.2 on C4's set
-           (streaming_bucket_prefetch_before_extension_ab.txt): the key held across the extension costs 15 registers, the kernel
-           either drops to three waves a SIMD or spills, and either costs more than the overlap gives. */
-        /* the read's characters, eight per load (a byte load per base is a round trip per base), and (k <= 31) loaded eight bases ahead of
-           their use: the wave does not wait for them */
-        auto characters = [&](uint64_t j) {
-            uint64_t eight = 0;
-            if (j + 8 <= len) {
-                __builtin_memcpy(&eight, p + j, 8);
-            } else {
-                for (uint64_t b = j; b < len; ++b) eight |= uint64_t(uint8_t(p[b])) << (8 * (b - j));
-            }
-            return eight;
-        };
-        constexpr bool AHEAD = W == 1;  // (k <= 63: the two registers more would cost the kernel its fourth wave)
-        uint64_t eight = 0, ahead = AHEAD ? characters(0) : 0;
-        for (uint64_t j = 0; j < len; ++j) {
-            if ((j & 7u) == 0) {
-                if constexpr (AHEAD) {
-                    eight = ahead;
-                    if (j + 8 < len) ahead = characters(j + 8);
-                } else {
-                    eight = characters(j);
-                }
-            }
-            const char c = char(eight >> (8 * (j & 7u)));
-            const uint64_t code = base_code(c);
-            x = kmer_roll<W>(x, code, k);
-            x_rc = kmer_roll_rc<W>(x_rc, code, k);
-            valid_len = base_is_valid(c) ? valid_len + 1 : 0;
-            if constexpr (ROLL) {
-                if (j + 1 >= d.sk.m) {
-                    if constexpr (PAIRS) sk_roll_push<W>(roll, x, x_rc, k, d.sk.m, column);
-                    else sk_roll1_push<W>(roll1, x, x_rc, k, d.sk.m, column1);
-                }
-            }
-            if (j + 1 < k) continue;
-            if (valid_len < k) {  // :59-65 -- invalid k-mer resets the whole state
-                ++c_invalid;
-                in_run = false;
-                neg_unknown_mini = false;
-                continue;
-            }
-            if (in_run && !(ori < 0 && off == 0)) {  // :86-100
-                /* the string's next k-mer in the direction of the run: forward it gains the base at off + k, and leaves
-                   its string iff a string starts there; backward it gains the base at off - 1, and leaves its string iff
-                   a string starts at off (read_window's `crosses` for a window whose neighbour did not cross) */
-                const uint64_t next = ori > 0 ? off + 1 : off - 1;
-                uint32_t base, unused;
-                bool boundary;
-                string_base(ori > 0 ? off + k : off - 1, base, boundary);
-                if (ori < 0) string_base(off, unused, boundary);  // (the mark that matters is the one at off)
-                const kmer_w<W> t = ori > 0 ? kmer_roll<W>(at, base, k) : kmer_roll_rc<W>(at, base ^ 2u, k);
-                if (!boundary && (kmer_eq<W>(t, x) || kmer_eq<W>(t, x_rc))) {
-                    ++c_extensions;
-                    off = next;
-                    at = t;
-                    continue;
-                }
-            }
-            /* seed() */
-            if constexpr (SK) {
-                sk_key_t kk;
-                if constexpr (ROLL && PAIRS) {
-                    kk = sk_roll_key<W>(roll, x, x_rc, k, d.sk.m);
-                } else if constexpr (ROLL) {
-                    if (!sk_roll1_key<W>(roll1, x, x_rc, k, d.sk.m, kk)) kk = sk_key<W>(x, x_rc, k, d.sk.m);  // equal hash prefixes: rare
-                } else {
-                    kk = sk_key<W>(x, x_rc, k, d.sk.m);
-                }
-                if (sk_usable(d, kk)) {
-                    if (neg_unknown_mini && kk.key == prev_f) {
-                        ++c_negative;
-                        in_run = false;
-                        continue;
-                    }
-                    bool key_seen;
-                    const fast_t r = sk_probe<W>(d, x, x_rc, kk, key_seen, line_cache);
-                    if (r.outcome != FAST_DEFER) {
-                        if (r.outcome == FAST_HIT) {
-                            ++c_searches;
-                            in_run = true;
-                            off = r.kmer_offset;
-                            ori = r.orientation;
-                            at = ori > 0 ? x : x_rc;  // what the strings hold at `off`
-                            neg_unknown_mini = false;
-                        } else {
-                            ++c_negative;
-                            in_run = false;
-                            neg_unknown_mini = !key_seen;
-                            prev_f = kk.key;
-                        }
-                        continue;
-                    }
-                }
-                /* tie / unplaced key / over-long list: the complete seed() below (its own short-cut state is
-                   not carried across table seeds) */
-                neg_unknown_mini = false;
-            }
-            const minimizer_t mf = compute_minimizer<W>(x, k, d.m, d.hash_magic);
-            const minimizer_t mr = compute_minimizer<W>(x_rc, k, d.m, d.hash_magic);
-            if (neg_unknown_mini && mf.value == prev_f && mr.value == prev_r) {  // :150-157
-                ++c_negative;
-                in_run = false;
-                continue;
-            }
-            prev_f = mf.value;
-            prev_r = mr.value;
-            const hit_t h = seed_lookup<W, CANON>(d, skew, x, x_rc, mf, mr);
-            if (h.found) {
-                ++c_searches;
-                in_run = true;
-                off = h.kmer_offset;
-                ori = h.orientation;
-                at = ori > 0 ? x : x_rc;
-                neg_unknown_mini = false;
-            } else {
-                ++c_negative;
-                in_run = false;
-                neg_unknown_mini = SK ? false : !h.minimizer_found;
-            }
-        }
-    }
-    block_report(c_kmers, c_invalid, c_negative, c_searches, c_extensions, report);
-}
-
-template <int W, bool CANON>
-void launch_streaming(dict_view const& d, skew_part_dev const* skew, char const* bases, uint64_t const* offsets,
-                      uint64_t n_reads, uint64_t* report, hipStream_t s) {
-    const uint32_t block = 256;
-    uint64_t blocks = (n_reads + block - 1) / block;
-    if (blocks > (uint64_t(1) << 20)) blocks = uint64_t(1) << 20;
-    const uint32_t roll_bytes = (d.k - d.sk.m + 1) * block * uint32_t(W == 1 ? sizeof(uint2) : sizeof(uint32_t));
-    /* SSHASH_AMD_STREAM_ROLLING: 0 = every seed elects its key from scratch (sk_key), as until round 4; 1 = incrementally wherever the
-       LDS allows. Default: incrementally at k <= 31 (high-hit reads 44.0 -> 48.9 G k-mers/s, random reads 82 -> 104); at k <= 63 only
-       on request -- random reads gain as much (63 -> 78) but reads that hit lose 3-4 % (31.7 -> 30.8 on config C4's set): there a
-       step waits for the slowest lane's memory access, not for the election, and the kernel no longer fits its 128 registers
-       (20 bytes of scratch). profiles/r04/streaming_rolling_election_k63_ab.txt */
-    char const* choice = std::getenv("SSHASH_AMD_STREAM_ROLLING");  // (read at every launch: the tests switch it inside one process)
-    const bool rolling = choice && (choice[0] == '0' || choice[0] == '1') ? choice[0] == '1' : W == 1;
-    char const* lds = std::getenv("SSHASH_AMD_STREAM_ROLLING_LDS");  // bytes of LDS a workgroup may take for it (A/B runs, tests)
-    const uint32_t roll_limit = lds ? uint32_t(std::strtoul(lds, nullptr, 10)) : ROLL_LDS_LIMIT;
-    if (d.sk.enabled && rolling && roll_bytes <= roll_limit) {
-        if (roll_bytes > (64u << 10))  // beyond what a launch may ask for without saying so first
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&streaming_kernel<W, CANON, true, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(roll_bytes)));
-        hipLaunchKernelGGL((streaming_kernel<W, CANON, true, true>), dim3(uint32_t(blocks)), dim3(block), roll_bytes, s, d, skew, bases,
-                           offsets, n_reads, report);
-    } else if (d.sk.enabled)
-        hipLaunchKernelGGL((streaming_kernel<W, CANON, true, false>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
-                           offsets, n_reads, report);
-    else
-        hipLaunchKernelGGL((streaming_kernel<W, CANON, false, false>), dim3(uint32_t(blocks)), dim3(block), 0, s, d, skew, bases,
-                           offsets, n_reads, report);
-    HIP_CHECK(hipGetLastError());
-}
-
-
 /* ==== the run-based streaming kernel (round 5) =====================================================================
-   The per-base walk above spends its instructions where nothing is decided: 61 % of the k-mers of a high-hit read extend the
-   run of the k-mer before them, and it rolls the k-mer, its reverse complement and two election candidates for every one of them,
-   64 reads in step (397 vector instructions per base and wave). A run is a longest common prefix: once a seed has put the read at
+   The per-base walk of rounds 1-4 (one read a lane, the lanes in step along their reads, k-mer and table key rolled base by base: HISTORY.md)
+   spent its instructions where nothing is decided: 61 % of the k-mers of a high-hit read extend the
+   run of the k-mer before them, and it rolled the k-mer, its reverse complement and two election candidates for every one of them,
+   64 reads in step (397 vector instructions per base and wave; 48 G k-mers/s on that set, 104 on random reads, 37 on config C4's). A run is a longest common prefix: once a seed has put the read at
    offset `off` of the strings in orientation `o`, the next k-mers are extensions for as long as the read's NEXT BASE equals the
    strings' next base in that direction and no string starts there -- streaming_query.hpp:86-100 compares whole k-mers
    (`expected == kmer or expected == kmer_rc`), but given the k-mer before matched the strings' k-mer before, the two k-mers share
@@ -442,43 +185,31 @@ __device__ __forceinline__ void string_bases32(dict_view const& d, uint64_t p, u
 template <int W>
 __device__ __forceinline__ uint64_t extend_run(dict_view const& d, const uint64_t* __restrict__ packed, uint64_t off, int ori, uint64_t b,
                                                uint64_t room) {
+    /* Forward, the t-th extension gains the strings' base off + k - 1 + t and leaves its string iff a string starts there. Backward it
+       gains the base off - t, complemented, and leaves its string iff a string starts at off - t + 1 (streaming_query.hpp:92:
+       remaining_string_bases = kmer_id_in_string going backward). ONE loop for both (the lanes of a wave run in both directions, and two
+       loops are paid for twice): a step takes the 32 bases of the strings that come next in the run's direction -- backward: the `have`
+       bases below `top`, the last of them moved to place 31, reversed and complemented: place i = comp(S[top - 1 - i]) -- and the marks
+       that stop it -- backward: the mark of base top - i stops extension i: marks bit (have - i), moved to bit 31 - i. */
+    const bool forward = ori > 0;
+    const uint64_t q = off + d.k;
     uint64_t run = 0;
-    if (ori > 0) {
-        /* the t-th extension gains the strings' base off + k - 1 + t; it leaves its string iff a string starts there */
-        const uint64_t q = off + d.k;
-        while (run < room) {
-            uint64_t s, marks;
-            string_bases32<W>(d, q + run, s, marks);
-            const uint64_t diff = s ^ read_bases32(packed, b + run);
-            const uint32_t same = diff ? uint32_t(__builtin_ctzll(diff)) >> 1 : 32u;
-            const uint32_t inside = uint32_t(marks) ? uint32_t(__builtin_ctz(uint32_t(marks))) : 32u;
-            uint64_t step = same < inside ? same : inside;
-            if (step > room - run) step = room - run;
-            run += step;
-            if (step < 32) break;
-        }
-    } else {
-        /* the t-th extension gains the strings' base off - t, complemented, and leaves its string iff a string starts at
-           off - t + 1 (streaming_query.hpp:92: remaining_string_bases = kmer_id_in_string going backward) */
-        while (run < room) {
-            const uint64_t top = off - run;  // the base gained next is top - 1; the mark that stops it is top's
-            if (top == 0) break;
-            const uint32_t have = top >= 32 ? 32u : uint32_t(top);
-            uint64_t s, marks;
-            string_bases32<W>(d, top - have, s, marks);
-            /* bases [top - have, top), the last of them moved to place 31, reversed and complemented: place i = comp(S[top - 1 - i]) */
-            const uint64_t rc = revcomp_word(s << (2 * (32 - have)));
-            const uint64_t diff = rc ^ read_bases32(packed, b + run);
-            const uint32_t same = diff ? uint32_t(__builtin_ctzll(diff)) >> 1 : 32u;
-            /* the mark of base top - i stops extension i of this word: marks bit (have - i), moved to bit 31 - i */
-            const uint32_t gate = uint32_t((marks >> 1) << (32 - have));
-            const uint32_t inside = gate ? uint32_t(__builtin_clz(gate)) : 32u;
-            uint64_t step = same < inside ? same : inside;
-            if (step > have) step = have;
-            if (step > room - run) step = room - run;
-            run += step;
-            if (step < 32) break;
-        }
+    while (run < room) {
+        const uint64_t top = off - run;  // (backward) the base gained next is top - 1
+        if (!forward && top == 0) break;
+        const uint32_t have = forward || top >= 32 ? 32u : uint32_t(top);
+        uint64_t s, marks;
+        string_bases32<W>(d, forward ? q + run : top - have, s, marks);
+        const uint64_t along = forward ? s : revcomp_word(s << (2 * (32 - have)));
+        const uint64_t diff = along ^ read_bases32(packed, b + run);
+        const uint32_t same = diff ? uint32_t(__builtin_ctzll(diff)) >> 1 : 32u;
+        const uint32_t gate = forward ? uint32_t(__brev(uint32_t(marks))) : uint32_t((marks >> 1) << (32 - have));  // bit 31 - i stops extension i
+        const uint32_t inside = gate ? uint32_t(__builtin_clz(gate)) : 32u;
+        uint64_t step = same < inside ? same : inside;
+        if (step > have) step = have;
+        if (step > room - run) step = room - run;
+        run += step;
+        if (step < 32) break;
     }
     return run;
 }
@@ -512,39 +243,73 @@ __device__ __forceinline__ fast_t stream_probe(dict_view const& d, kmer_w<W> con
     const uint32_t first_go_on = flags.go_on;
     if (r.outcome != FAST_MISS || (!marker && first_go_on == 0)) return r;  // found, or a miss that is final here
     lasts = 0;
-    sk_walk_t w = sk_walk_begin(sk_hash(kk.key, d.sk.num_buckets), 0);
-    bool more = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, first_go_on, marker);
+    /* The rest of the walk (lookup_device.hpp: sk_walk_step), by this lane alone, the choices hashed as they are needed. Where it
+       stands: sequence `on` (the key's, or -- once the key's marker has been met -- the k-mer's own, in the k-mers' region), choice c
+       of it, and the choice of the key's sequence to come back to when the k-mer's sequence ends without the k-mer (the marker may
+       have been another key's with an equal fingerprint). */
+    uint64_t on = kk.key, on_a = sk_hash_a(kk.key);
+    uint32_t c = 0, back_to = SK_NO_RETURN, go_on = first_go_on;
+    bool visited = false;  // the k-mer's own sequence has been (or is being) walked
+    bool compact = false;  // the walk is on the k-mer's own sequence: the k-mers' region, compact entries (device_layout.hpp)
 #pragma unroll 1
-    while (more) {
-        const uint32_t bucket = sk_choice(w.h, w.c);
-        const bool compact = bucket >= d.sk.num_buckets;  // the k-mers' region (lookup_device.hpp: sk_probe)
+    for (;;) {
+        if (marker && !visited) {
+            back_to = go_on ? c + 1 : SK_NO_RETURN;
+            visited = true;
+            compact = true;
+            on = sk_kmer_key<W>(x, x_rc);
+            on_a = sk_hash_a(on);
+            c = 0;
+            Q.fingerprint = uint32_t(on_a) & 0xFFFFFFu;
+        } else if (go_on) {
+            if (++c >= SK_CHOICES) {  // a key (or k-mer) that found no slot: the complete path
+                r.outcome = FAST_DEFER;
+                break;
+            }
+        } else if (compact && back_to != SK_NO_RETURN) {  // not under its own key: the rest of the key's sequence
+            c = back_to;
+            back_to = SK_NO_RETURN;
+            if (c >= SK_CHOICES) {
+                r.outcome = FAST_DEFER;
+                break;
+            }
+            compact = false;
+            on = kk.key;
+            on_a = sk_hash_a(on);
+            Q.fingerprint = uint32_t(on_a) & 0xFFFFFFu;
+        } else {
+            break;  // a final miss
+        }
+        const uint32_t bucket = compact ? d.sk.num_buckets + sk_choice_of(on, on_a, c, d.sk.kmer_buckets) : sk_choice_of(on, on_a, c, d.sk.num_buckets);
         const uint4* B = reinterpret_cast<const uint4*>(static_cast<char const*>(d.sk.slots) + sk_bucket_offset<W>(d, bucket, compact));
         marker = false;
         if constexpr (W == 2) {
             if (compact) {
-                sk_examine_kmer_entry<true>(Q, w.c, [B](uint32_t i) { return B[i]; }, r, flags);
-                sk_examine_kmer_entry<false>(Q, w.c, [B](uint32_t i) { return B[2 + i]; }, r, flags);
+                sk_examine_kmer_entry<true>(Q, c, [B](uint32_t i) { return B[i]; }, r, flags);
+                sk_examine_kmer_entry<false>(Q, c, [B](uint32_t i) { return B[2 + i]; }, r, flags);
             }
         } else {
             if (compact) {
                 const uint4 l0 = B[0], l1 = B[1], l2 = B[2], l3 = B[3];
                 const uint32_t words[16] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
-                sk_examine_kmer_line(Q, w.c, [&words](uint32_t i) { return words[i]; }, r, flags);
+                sk_examine_kmer_line(Q, c, [&words](uint32_t i) { return words[i]; }, r, flags);
             }
         }
         if (!compact) {
-            sk_examine_slot<W, true>(d, Q, w.c, [B](uint32_t i) { return B[i]; }, r, seen, marker, flags);
+            sk_examine_slot<W, true>(d, Q, c, [B](uint32_t i) { return B[i]; }, r, seen, marker, flags);
             if (r.outcome == FAST_MISS && flags.second_used)
-                sk_examine_slot<W, false>(d, Q, w.c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags);
+                sk_examine_slot<W, false>(d, Q, c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags);
         }
-        const uint32_t go_on = flags.go_on;
-        more = sk_walk_step<W>(d, x, x_rc, kk, w, Q, r, go_on, marker);
+        if (r.outcome != FAST_MISS) break;
+        go_on = flags.go_on;
     }
     return r;
 }
 
-template <int W, bool CANON, bool SK, int OCC>
-__global__ void __launch_bounds__(256, OCC)
+/* (four waves a SIMD: 102 registers at k <= 31, 118 at k <= 63. Compiled for five -- 96 registers, 20 to 100 bytes of scratch -- it is as fast at
+   k <= 31 and 9 % slower at k <= 63; for six, 14 / 31 % slower: profiles/r05/streaming_run_kernel_waves_per_simd_ab.txt) */
+template <int W, bool CANON, bool SK>
+__global__ void __launch_bounds__(256, W == 1 ? 5 : 4)
 streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const uint64_t* __restrict__ packed,
                      const uint64_t* __restrict__ okay, const uint64_t* __restrict__ offsets, const uint64_t n_reads,
                      const uint64_t reads_per_wave, uint64_t* __restrict__ report) {
@@ -704,23 +469,13 @@ void launch_streaming_runs(device_replica const* rep, dict_view const& d, char c
     }
     /* waves: a share of at least 8 reads a lane (a lane that finishes its read takes the wave's next: the longer the share, the
        better the lanes of a wave even out), at most as many waves as the chip holds at once */
-    static const uint64_t max_waves = [] {
-        char const* e = std::getenv("SSHASH_AMD_STREAM_WAVES");
-        return e ? std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) : uint64_t(256) * 16;
-    }();
+    const uint64_t max_waves = uint64_t(256) * 4 * (W == 1 ? 5 : 4);  // (what the chip holds of this kernel: 96 registers at k <= 31, 114 at k <= 63)
     uint64_t waves = std::min<uint64_t>(max_waves, std::max<uint64_t>(1, n_reads / (64 * 8)));
     waves = (waves + 3) / 4 * 4;
     const uint64_t reads_per_wave = (n_reads + waves - 1) / waves;
     const dim3 grid(uint32_t(waves / 4)), block(256);
-    static const int occ = [] {  // (A/B: waves per SIMD the kernel is compiled for)
-        char const* e = std::getenv("SSHASH_AMD_STREAM_OCC");
-        return e ? std::atoi(e) : 4;
-    }();
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, report); };
-    if (!d.sk.enabled) launch(streaming_run_kernel<W, CANON, false, 4>);
-    else if (occ == 5) launch(streaming_run_kernel<W, CANON, true, 5>);
-    else if (occ == 6) launch(streaming_run_kernel<W, CANON, true, 6>);
-    else launch(streaming_run_kernel<W, CANON, true, 4>);
+    if (d.sk.enabled) hipLaunchKernelGGL((streaming_run_kernel<W, CANON, true>), grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, report);
+    else hipLaunchKernelGGL((streaming_run_kernel<W, CANON, false>), grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, report);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -734,15 +489,6 @@ void engine::streaming_query_device(int device, char const* d_bases, uint64_t co
     dict_view const& d = rep->view;
     hipStream_t s = hipStream_t(stream);
     const bool wide = d.k > 31;
-    /* SSHASH_AMD_STREAM_WALK=bases: the per-base kernel of rounds 1-4 (one read a lane, the lanes in step along their reads), kept for A/B runs */
-    char const* walk = std::getenv("SSHASH_AMD_STREAM_WALK");
-    if (walk && walk[0] == 'b') {
-        if (!wide && !d.canonical) launch_streaming<1, false>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
-        else if (!wide && d.canonical) launch_streaming<1, true>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
-        else if (wide && !d.canonical) launch_streaming<2, false>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
-        else launch_streaming<2, true>(d, rep->d_skew, d_bases, d_read_offsets, n_reads, d_report, s);
-        return;
-    }
     if (total_bases == 0) {
         /* the packing pass covers bases [0, read_offsets[n_reads]): a caller that does not say how many that is (the C ABI's device
            entry point) costs the launch one 8-byte read-back on its stream */
@@ -1232,7 +978,7 @@ bool engine::streaming_query_fastq_pieces(std::string const& filename, streaming
         if (stat(filename.c_str(), &st) == 0)
             piece_bytes = std::min<uint64_t>(piece_bytes, std::max<uint64_t>(uint64_t(4) << 20, uint64_t(st.st_size) / (want_lanes * 8)));
     }
-    if (char const* e = std::getenv("SSHASH_AMD_FASTQ_PIECE_BYTES")) piece_bytes = std::max<uint64_t>(4096, std::strtoull(e, nullptr, 10));  // tests
+    piece_bytes = test_hook_u64("fastq_piece_bytes", piece_bytes, 4096, ~uint64_t(0));  // (tests: many pieces of a small file)
     const fastq_pieces file(filename, piece_bytes);
     const uint64_t num_pieces = file.num_pieces();
     if (num_pieces == 0) return true;  // an empty file: an empty report

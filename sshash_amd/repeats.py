@@ -170,6 +170,57 @@ def _family_strings(gen, device, families: int, copies: int, length: int, diverg
     return _t.cat(out_codes), _t.cat(out_lens)
 
 
+def _duplicate_kmer_starts(codes, lens, k: int, device, chunk: int = 1 << 26, parts: int = 16) -> np.ndarray:
+    """codes: all strings back to back (uint8, CPU), lens: their lengths; k <= 31 -> the start positions (ascending) of every k-mer
+    whose canonical form occurred at a lower position already. The k-mers are made on `device` chunk by chunk and compared part by
+    part (a hash of the k-mer picks the part: a sort of 2.5 x 10^9 values in one piece is more than a sort takes)."""
+    import torch
+
+    N = int(codes.numel())
+    n = N - k + 1
+    if n <= 0:
+        return np.zeros(0, dtype=np.int64)
+    vals = torch.empty(n, dtype=torch.int64, device=device)
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        vals[a:b] = _canonical_kmers(codes[a:b + k - 1].to(device).reshape(1, -1), k).reshape(-1)
+    valid = torch.ones(n, dtype=torch.bool, device=device)  # a start within k - 1 bases of its string's end is no k-mer
+    ends = torch.cumsum(lens.to(device), 0)
+    for a in range(0, int(ends.numel()), 1 << 22):
+        idx = (ends[a:a + (1 << 22), None] - torch.arange(1, k, device=device)[None, :]).reshape(-1)
+        valid[idx[(idx >= 0) & (idx < n)]] = False
+    del ends
+    part = ((vals * _s64(0x9E3779B97F4A7C15)) >> 40) & (parts - 1)  # (bits of the product's upper half: the low bits of a k-mer are its first bases)
+    found = []
+    for j in range(parts):
+        # (torch.nonzero takes fewer than 2^31 elements at a time)
+        pos = torch.cat([torch.nonzero((part[a:a + (1 << 30)] == j) & valid[a:a + (1 << 30)])[:, 0] + a for a in range(0, n, 1 << 30)])
+        if pos.numel() < 2:
+            continue
+        order = torch.sort(vals[pos], stable=True)  # equal k-mers in order of position
+        again = order.values[1:] == order.values[:-1]
+        if bool(again.any()):
+            found.append(pos[order.indices[1:][again]].cpu().numpy())
+    return np.sort(np.concatenate(found)) if found else np.zeros(0, dtype=np.int64)
+
+
+def _cut_kmers_out(codes, lens, starts: np.ndarray, k: int):
+    """The strings without the k-mers that start at `starts` (a handful): the string holding one falls apart into what lies before
+    the k-mer's last base and what lies behind its first -- the two pieces keep every other k-mer --, a piece shorter than k is dropped."""
+    import torch
+
+    lens = lens.numpy().copy()
+    for p in sorted((int(v) for v in starts), reverse=True):  # from the back: what lies before stays where it is
+        ends = np.cumsum(lens)
+        s = int(np.searchsorted(ends, p, side="right"))
+        begin, end = (int(ends[s - 1]) if s else 0), int(ends[s])
+        left, right = codes[begin:p + k - 1], codes[p + 1:end]
+        pieces = [piece for piece in (left, right) if piece.numel() >= k]
+        codes = torch.cat([codes[:begin]] + pieces + [codes[end:]])
+        lens = np.concatenate([lens[:s], np.array([int(piece.numel()) for piece in pieces], dtype=lens.dtype), lens[s + 1:]])
+    return codes, torch.from_numpy(lens)
+
+
 def pack_codes_torch(codes):
     """uint8 base codes (0..3) on any device -> numpy uint64 words, base i in bits [2i, 2i+1] of word i // 32."""
     import torch
@@ -255,6 +306,14 @@ def make_repeat_spss(num_bases: int, k: int = 31, classes=(), seed: int = 0x5555
         parts_lens.append(lens.cpu())
     codes = torch.cat(parts_codes)
     lens = torch.cat(parts_lens)
+    if k <= 31:
+        # the de-duplication above works family by family; two k-mers of DIFFERENT families (or of the background) coincide by chance
+        # about n^2 / 4^k times -- once or twice among the 0.9 / 2.5 x 10^9 k-mers of the C2 / C3 stand-ins (round 5's full-size
+        # lookup(access(id)) == id test met the one of C2). A spectrum-preserving string set holds every k-mer once: the later
+        # occurrences are cut out of their strings. (k = 63: 4^63 leaves no such chance.)
+        extra = _duplicate_kmer_starts(codes, lens, k, dev)
+        if extra.size:
+            codes, lens = _cut_kmers_out(codes, lens, extra, k)
     endpoints = np.zeros(int(lens.numel()) + 1, dtype=np.uint64)
     endpoints[1:] = np.cumsum(lens.numpy()).astype(np.uint64)
     return pack_codes_torch(codes), endpoints

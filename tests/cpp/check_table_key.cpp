@@ -53,76 +53,6 @@ static int check(uint32_t k, uint32_t m, uint64_t trials, std::mt19937_64& rng, 
     return 0;
 }
 
-/* the rolling election of the streaming query (sk_roll_*) against sk_key, base by base along random and low-complexity reads */
-struct host_column {
-    struct pair { uint32_t x, y; };
-    pair at[64];
-    pair load(uint32_t i) const { return at[i]; }
-    void store(uint32_t i, uint32_t x, uint32_t y) { at[i] = {x, y}; }
-};
-
-struct host_column1 {
-    uint32_t at[64];
-    uint32_t load(uint32_t i) const { return at[i]; }
-    void store(uint32_t i, uint32_t v) { at[i] = v; }
-};
-
-/* the one-word form: equal to sk_key wherever it commits itself; how often it does not is printed */
-template <int W>
-static int check_rolling1(uint32_t k, uint32_t m, uint64_t reads, std::mt19937_64& rng, uint64_t& kmers, uint64_t& ambiguous) {
-    for (uint64_t t = 0; t < reads; ++t) {
-        const uint32_t len = k + uint32_t(rng() % 200);
-        const uint32_t alphabet = t % 5 == 0 ? 2 : 4;
-        kmer_w<W> x = kmer_zero<W>(), y = kmer_zero<W>();
-        sk_roll1_state st;
-        host_column1 column;
-        sk_roll1_start(st, k, m);
-        for (uint32_t j = 0; j < len; ++j) {
-            const uint64_t code = t % 11 == 0 && (j / 40) % 2 ? 0 : rng() % alphabet;
-            x = kmer_roll<W>(x, code, k);
-            y = kmer_roll_rc<W>(y, code, k);
-            if (j + 1 >= m) sk_roll1_push<W>(st, x, y, k, m, column);
-            if (j + 1 < k) continue;
-            ++kmers;
-            const sk_key_t a = sk_key<W>(x, y, k, m);
-            sk_key_t b;
-            if (!sk_roll1_key<W>(st, x, y, k, m, b)) {
-                ++ambiguous;
-                continue;
-            }
-            if (a.tie || a.rc != b.rc || a.pos != b.pos || a.key != b.key)
-                return printf("one-word rolling election differs from sk_key (k=%u m=%u read %llu base %u: tie %d rc %d/%d pos %u/%u)\n", k, m,
-                              (unsigned long long)t, j, a.tie, a.rc, b.rc, a.pos, b.pos), 1;
-        }
-    }
-    return 0;
-}
-
-template <int W>
-static int check_rolling(uint32_t k, uint32_t m, uint64_t reads, std::mt19937_64& rng, uint64_t& kmers) {
-    for (uint64_t t = 0; t < reads; ++t) {
-        const uint32_t len = k + uint32_t(rng() % 200);
-        const uint32_t alphabet = t % 5 == 0 ? 2 : 4;  // two-letter reads: equal hashes inside one window, on both strands
-        kmer_w<W> x = kmer_zero<W>(), y = kmer_zero<W>();
-        sk_roll_state st;
-        host_column column;
-        sk_roll_start(st, k, m);
-        for (uint32_t j = 0; j < len; ++j) {
-            const uint64_t code = t % 11 == 0 && (j / 40) % 2 ? 0 : rng() % alphabet;  // and stretches of one letter
-            x = kmer_roll<W>(x, code, k);
-            y = kmer_roll_rc<W>(y, code, k);
-            if (j + 1 >= m) sk_roll_push<W>(st, x, y, k, m, column);
-            if (j + 1 < k) continue;
-            const sk_key_t a = sk_key<W>(x, y, k, m), b = sk_roll_key<W>(st, x, y, k, m);
-            if (a.tie != b.tie || a.rc != b.rc || a.pos != b.pos || a.key != b.key)
-                return printf("rolling election differs from sk_key (k=%u m=%u read %llu base %u: tie %d/%d rc %d/%d pos %u/%u)\n", k, m,
-                              (unsigned long long)t, j, a.tie, b.tie, a.rc, b.rc, a.pos, b.pos), 1;
-            ++kmers;
-        }
-    }
-    return 0;
-}
-
 /* sk_key_persists along reads: for every k-mer whose key is not a tie, the t k-mers that follow must elect the very same occurrence
    (same key, same strand, the position moved by t); how far it looks is printed next to how far the key really lasts */
 template <int W>
@@ -180,16 +110,6 @@ int main() {
         checked += trials;
         fprintf(stderr, "k=%u m=%u: %llu ties in %llu k-mers\n", c[0], c[1], (unsigned long long)(ties - before), (unsigned long long)trials);
     }
-    uint64_t rolled = 0;
-    for (auto const& c : cases)
-        if (c[0] <= 31 ? check_rolling<1>(c[0], c[1], 3000, rng, rolled) : check_rolling<2>(c[0], c[1], 3000, rng, rolled)) return 1;
-    fprintf(stderr, "rolling election: %llu k-mers equal to sk_key\n", (unsigned long long)rolled);
-    for (auto const& c : cases) {
-        uint64_t seen = 0, ambiguous = 0;
-        if (c[0] <= 31 ? check_rolling1<1>(c[0], c[1], 3000, rng, seen, ambiguous) : check_rolling1<2>(c[0], c[1], 3000, rng, seen, ambiguous)) return 1;
-        fprintf(stderr, "one-word rolling election k=%u m=%u: %llu k-mers, %llu left to sk_key\n", c[0], c[1], (unsigned long long)seen,
-                (unsigned long long)ambiguous);
-    }
     for (auto const& c : cases) {
         uint64_t seen = 0, claimed = 0, lasted = 0;
         if (c[0] <= 31 ? check_persists<1>(c[0], c[1], 300, rng, seen, claimed, lasted) : check_persists<2>(c[0], c[1], 300, rng, seen, claimed, lasted)) return 1;
@@ -202,6 +122,13 @@ int main() {
         for (uint32_t c = 0; c < SK_CHOICES; ++c)
             if (h.bucket[c] >= 1000003u) return printf("bucket out of range\n"), 1;
         if (h.fingerprint >> 24) return printf("fingerprint wider than 24 bits\n"), 1;
+        /* the choices computed one by one (sk_choice_of: the streaming query's walk) are sk_hash's */
+        const uint64_t k64 = key * 0x9E3779B97F4A7C15ULL >> 22, a = sk_hash_a(k64);
+        uint32_t b0, fp;
+        sk_hash_first(k64, 1000003u, b0, fp);
+        if (b0 != h.bucket[0] || fp != h.fingerprint || (uint32_t(a) & 0xFFFFFFu) != fp) return printf("sk_hash_first differs from sk_hash\n"), 1;
+        for (uint32_t c = 0; c < SK_CHOICES; ++c)
+            if (sk_choice_of(k64, a, c, 1000003u) != h.bucket[c]) return printf("sk_choice_of differs from sk_hash (choice %u)\n", c), 1;
     }
     printf("OK %llu %llu\n", (unsigned long long)checked, (unsigned long long)ties);
     return 0;

@@ -263,7 +263,7 @@ def test_full_size_dictionary_properties(workload, least_kmers):
 def test_streaming_query_against_the_full_size_k63_dictionary():
     """BASELINE.json configs[3] on the dictionary it names: the streaming query's six counters on 60 000 reads of the bench's own set (half
     from the 2.96 G-base k = 63 dictionary with 1 % substitutions, half random, N at 1e-3) equal the CPU oracle's restated state machine
-    (include/streaming_query.hpp:48-197) -- through the run-based kernel, the per-base kernel of rounds 1-4 and the position-parallel pipeline."""
+    (include/streaming_query.hpp:48-197) -- through the run-based kernel and through the position-parallel pipeline."""
     import torch
 
     from oracle import oracle as O
@@ -277,19 +277,13 @@ def test_streaming_query_against_the_full_size_k63_dictionary():
     want = O.OracleIndex(path).streaming_query([bytes(r) for r in reads.cpu().numpy()])
     names = ("num_kmers", "num_positive_kmers", "num_negative_kmers", "num_invalid_kmers", "num_searches", "num_extensions")
     assert want["num_kmers"] == n * (L - 63 + 1) and want["num_extensions"] > 10 * want["num_searches"] > 0 and want["num_invalid_kmers"] > 0
-    for how in ("runs", "bases", "positions"):
+    for how in ("runs", "positions"):
         report = torch.zeros(6, dtype=torch.int64, device=dev)
-        os.environ.pop("SSHASH_AMD_STREAM_WALK", None)
-        if how == "bases":
-            os.environ["SSHASH_AMD_STREAM_WALK"] = "bases"
-        try:
-            if how == "positions":
-                d.streaming_lookup_device(0, reads.data_ptr(), offsets.data_ptr(), n, n * L, 0, d_report=report.data_ptr())
-            else:
-                d.streaming_query_device(0, reads.data_ptr(), offsets.data_ptr(), n, report.data_ptr())
-            torch.cuda.synchronize()
-        finally:
-            os.environ.pop("SSHASH_AMD_STREAM_WALK", None)
+        if how == "positions":
+            d.streaming_lookup_device(0, reads.data_ptr(), offsets.data_ptr(), n, n * L, 0, d_report=report.data_ptr())
+        else:
+            d.streaming_query_device(0, reads.data_ptr(), offsets.data_ptr(), n, report.data_ptr())
+        torch.cuda.synchronize()
         got = dict(zip(names, (int(v) for v in report.cpu().tolist())))
         assert got == {f: int(v) for f, v in want.items()}, how
     d.close()

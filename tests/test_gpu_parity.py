@@ -266,8 +266,8 @@ def test_batch_larger_than_one_launch_piece(case_se_regular):
 
 
 @pytest.mark.parametrize("settings", [{"SSHASH_AMD_DIRECTORY": "0", "SSHASH_AMD_SKTABLE": "0"}, {"SSHASH_AMD_SKTABLE": "0"}, {},
-                                      {"SSHASH_AMD_DIRECTORY": "1"}, {"SSHASH_AMD_SK_SLOTS_PER_KEY": "1.2", "SSHASH_AMD_SK_SLOTS_PER_KMER": "1.2"}, {"SSHASH_AMD_PIECE": "4096"},
-                                      {"SSHASH_AMD_PIECE": "4096", "SSHASH_AMD_SKTABLE": "0"}],
+                                      {"SSHASH_AMD_DIRECTORY": "1"}, {"SSHASH_AMD_TEST_HOOKS": "slots_per_key=1.2,slots_per_kmer=1.2"}, {"SSHASH_AMD_TEST_HOOKS": "piece=4096"},
+                                      {"SSHASH_AMD_TEST_HOOKS": "piece=4096", "SSHASH_AMD_SKTABLE": "0"}],
                          ids=["mphf_only", "directory_only", "sktable_lean", "sktable_over_directory", "sktable_packed_tight",
                               "many_launch_pieces", "many_launch_pieces_no_table"])
 def test_accelerators_disabled(tmp_path, settings):
@@ -303,7 +303,7 @@ def test_accelerators_disabled(tmp_path, settings):
                 want_directory = os.environ.get("SSHASH_AMD_DIRECTORY") == "1" or (not table and os.environ.get("SSHASH_AMD_DIRECTORY") != "0")
                 assert (stats["directory_sectors"] != 0) == want_directory, stats
                 assert (stats["sk_slots"] != 0) == table, stats
-                if os.environ.get("SSHASH_AMD_SK_SLOTS_PER_KMER"):
+                if "slots_per_kmer" in os.environ.get("SSHASH_AMD_TEST_HOOKS", ""):
                     assert stats["sk_heavy_kmers"] > 0 and stats["sk_load_factor"] > 0.75 and stats["sk_deferred_keys"] > 0, stats
                 q = case.queries(4000, 4000, seed=1)
                 want = case.oracle.lookup_ids(q)
@@ -321,8 +321,7 @@ def test_accelerators_disabled(tmp_path, settings):
     env = dict(os.environ)
     env.pop("SSHASH_AMD_DIRECTORY", None)
     env.pop("SSHASH_AMD_SKTABLE", None)
-    for name in ("SSHASH_AMD_PIECE", "SSHASH_AMD_SK_SLOTS_PER_KEY", "SSHASH_AMD_SK_SLOTS_PER_KMER"):  # (a caller's measurement switches)
-        env.pop(name, None)
+    env.pop("SSHASH_AMD_TEST_HOOKS", None)
     env.update(settings)
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "LAYERS OK" in p.stdout, p.stdout + p.stderr
@@ -524,7 +523,7 @@ def test_a_full_resume_queue_sends_its_queries_down_the_complete_path(case_name,
     ids and membership of every k-mer, both strands, plus a random mix against the oracle, must not change."""
     case = request.getfixturevalue(case_name)
     d = case.dict.to_device(0)
-    monkeypatch.setenv("SSHASH_AMD_RESUME_DIVISOR", "64")
+    monkeypatch.setenv("SSHASH_AMD_TEST_HOOKS", "resume_divisor=64")
     n = d.num_kmers()
     q = d.access_packed(np.arange(n, dtype=np.uint64))
     want = np.arange(n, dtype=np.uint64)

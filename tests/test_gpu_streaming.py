@@ -60,22 +60,60 @@ def test_streaming_counters_match_oracle(case_name, request):
     assert got["num_extensions"] > 0 and got["num_invalid_kmers"] > 0
 
 
-@pytest.mark.parametrize("rolling", ["0", "1"])
 @pytest.mark.parametrize("case_name", ["case_se_regular", "case_se_canonical", "case_skew_regular", "case_k63_canonical", "case_k63_regular",
                                        "case_small_k", "case_m_equals_k"])
-def test_streaming_counters_with_the_key_elected_from_scratch_and_incrementally(case_name, rolling, request, monkeypatch):
-    """SSHASH_AMD_STREAM_ROLLING: 0 = sk_key at every seed, 1 = the sliding election (device_layout.hpp: sk_roll_*; word pairs at k <= 31, one
-    word a place with the ambiguous windows handed to sk_key at k <= 63 -- off by default there), with room for the widest window of
-    the cases (k = 63, m = 17: 47 places). Low-complexity reads put equal hashes into one window."""
+def test_streaming_counters_on_low_complexity_reads(case_name, request):
+    """Reads that put equal election hashes into one window (two-letter reads, homopolymers, short tandem repeats): ties between the
+    strands (complete path), keys that never change, newcomers that hash equal to the elected occurrence (sk_key_persists must stop there)."""
     case = request.getfixturevalue(case_name)
-    monkeypatch.setenv("SSHASH_AMD_STREAM_ROLLING", rolling)
-    monkeypatch.setenv("SSHASH_AMD_STREAM_ROLLING_LDS", str(64 << 10))
     d = case.dict.to_device(0)
     rng = np.random.default_rng(5)
     reads = _synthetic_reads(case, 2000, seed=23)
     reads += ["".join(rng.choice(list("AC"), size=200)) for _ in range(50)] + ["A" * 300, "ACGT" * 60, ("A" * 40 + "C" * 40) * 3]
     got = _as_dict(d.streaming_query(reads))
     assert got == case.oracle.streaming_query(reads)
+
+
+def test_streaming_runs_and_skips_against_hand_made_reads(case_se_regular, case_se_canonical, case_k63_regular):
+    """What the run-based kernel decides without looking (streaming.hip): extension runs measured 32 bases a step, forward and
+    backward, across word boundaries, up to a string's end and past it; the k-mers behind a miss counted by the slot's say. Reads cut
+    out of the strings at chosen places, with ONE substitution at every possible distance from either end, long reads (several
+    hundred extensions in a row), reads that run off their string's end into random bases, and N's next to the substitution."""
+    comp = str.maketrans("ACGT", "TGCA")
+    for case in (case_se_regular, case_se_canonical, case_k63_regular):
+        d = case.dict.to_device(0)
+        k = case.k
+        rng = np.random.default_rng(11)
+        long_seqs = sorted((s for s in case.sequences if len(s) >= 4 * k + 400), key=len)
+        s = long_seqs[len(long_seqs) // 2]
+        reads = []
+        L = 2 * k + 40
+        for where in range(0, L):  # one substitution at base `where` of a read that starts at an odd offset of its string
+            r = list(s[37:37 + L])
+            r[where] = "ACGT"[("ACGT".index(r[where]) + 1 + where % 3) % 4]
+            reads.append("".join(r))
+            reads.append("".join(r).translate(comp)[::-1])
+        for a in (0, 1, 31, 32, 33, 63, 64, 65, 95, 96):  # runs that start at every alignment of the strings' words
+            reads.append(s[a:a + 3 * k + 70])
+            reads.append(s[a:a + 3 * k + 70].translate(comp)[::-1])
+        reads.append(s)  # the whole string: len - k extensions behind one search
+        reads.append(s.translate(comp)[::-1])
+        tail = "".join(rng.choice(list("ACGT"), size=k + 20))
+        reads.append(s[-(k + 50):] + tail)  # off the string's end: the run stops at the mark, the rest is looked up
+        reads.append((s[-(k + 50):] + tail).translate(comp)[::-1])
+        reads.append(tail + s[:k + 50])  # into the string's first k-mer from random bases
+        for gap in (1, 2, k - 1, k, k + 1):  # an N and a substitution `gap` bases apart
+            r = list(s[100:100 + 3 * k])
+            r[k + 5] = "N"
+            r[k + 5 + gap] = "ACGT"[("ACGT".index(r[k + 5 + gap]) + 2) % 4]
+            reads.append("".join(r))
+        got = _as_dict(d.streaming_query(reads))
+        want = case.oracle.streaming_query(reads)
+        assert got == want, (case.k, case.dict.canonical())
+        assert got["num_extensions"] > 20 * got["num_searches"] > 0 and got["num_negative_kmers"] > 0 and got["num_invalid_kmers"] > 0
+        # read by read as well: a wrong count must not cancel against another read's
+        for i in range(0, len(reads), 7):
+            assert _as_dict(d.streaming_query([reads[i]])) == case.oracle.streaming_query([reads[i]]), (case.k, i, reads[i])
 
 
 def test_streaming_query_from_fastq_file(case_se_regular, case_se_canonical):
@@ -136,9 +174,9 @@ def test_query_file_goes_through_in_batches(case_se_regular, case_skew_regular, 
     d = case_se_regular.dict.to_device(0)
     whole = _as_dict(d.streaming_query_from_file(FASTQ))
     for batch in ("1", "1000", "77777"):
-        monkeypatch.setenv("SSHASH_AMD_QUERY_BATCH_BASES", batch)
+        monkeypatch.setenv("SSHASH_AMD_TEST_HOOKS", "query_batch_bases=" + batch)
         assert _as_dict(d.streaming_query_from_file(FASTQ)) == whole
-    monkeypatch.delenv("SSHASH_AMD_QUERY_BATCH_BASES")
+    monkeypatch.delenv("SSHASH_AMD_TEST_HOOKS")
     case = case_skew_regular
     d = case.dict.to_device(0)
     p = tmp_path / "many.fa"
@@ -149,9 +187,9 @@ def test_query_file_goes_through_in_batches(case_se_regular, case_skew_regular, 
         whole = _as_dict(d.streaming_query_from_file(str(p), multiline=multiline))
         assert whole["num_kmers"] > 0
         for batch in ("1", "500"):
-            monkeypatch.setenv("SSHASH_AMD_QUERY_BATCH_BASES", batch)
+            monkeypatch.setenv("SSHASH_AMD_TEST_HOOKS", "query_batch_bases=" + batch)
             assert _as_dict(d.streaming_query_from_file(str(p), multiline=multiline)) == whole
-        monkeypatch.delenv("SSHASH_AMD_QUERY_BATCH_BASES")
+        monkeypatch.delenv("SSHASH_AMD_TEST_HOOKS")
     with pytest.raises(Exception):
         d.streaming_query_from_file(str(tmp_path / "missing.fq"))
 
@@ -175,21 +213,21 @@ def test_plain_fastq_is_read_in_pieces_by_all_lanes(case_se_regular, tmp_path, m
     for name, blob in files.items():
         path = tmp_path / f"{name}.fastq"
         path.write_bytes(blob)
-        monkeypatch.setenv("SSHASH_AMD_SEQUENTIAL_READER", "1")
+        monkeypatch.setenv("SSHASH_AMD_TEST_HOOKS", "sequential_reader=1")
         sequential = _as_dict(d.streaming_query_from_file(str(path)))
-        monkeypatch.delenv("SSHASH_AMD_SEQUENTIAL_READER")
+        monkeypatch.delenv("SSHASH_AMD_TEST_HOOKS")
         if name == "plain":
             assert sequential == {f: 6 * v for f, v in want.items()}
         if name in ("at_quals", "cut_short"):
             assert sequential == want
         for piece, lanes in ((None, None), ("4096", "3"), ("100003", "1"), ("1000000", "16")):
-            for var, value in (("SSHASH_AMD_FASTQ_PIECE_BYTES", piece), ("SSHASH_AMD_READER_THREADS", lanes)):
+            for var, value in (("SSHASH_AMD_TEST_HOOKS", piece and "fastq_piece_bytes=" + piece), ("SSHASH_AMD_READER_THREADS", lanes)):
                 if value is None:
                     monkeypatch.delenv(var, raising=False)
                 else:
                     monkeypatch.setenv(var, value)
             assert _as_dict(d.streaming_query_from_file(str(path))) == sequential, (name, piece, lanes)
-        monkeypatch.delenv("SSHASH_AMD_FASTQ_PIECE_BYTES", raising=False)
+        monkeypatch.delenv("SSHASH_AMD_TEST_HOOKS", raising=False)
         monkeypatch.delenv("SSHASH_AMD_READER_THREADS", raising=False)
 
 

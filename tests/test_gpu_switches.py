@@ -1,7 +1,7 @@
-"""GPU: the environment switches that select kernels at run time (engine.hip, sktable.hip), each in a process of its own
-(tests/gpu_switch_worker.py): every k-mer of a C2-like stand-in through the id-returning and the is_member instances, launch after
-launch -- 20 launches where the round-3 hazard lived (probes finished in the wave / in the resume pass) --, ASCII input, the bench's
-mixes against the oracle. (Round 3 ran these settings once, from a job script.)"""
+"""GPU: the environment switches that change what a replica holds or how a batch is launched (SSHASH_AMD_SKTABLE,
+_DIRECTORY, _SK_M, and the tests' own SSHASH_AMD_TEST_HOOKS), each in a process of its own (tests/gpu_switch_worker.py): every k-mer of
+a C2-like stand-in through the id-returning and the is_member instances, launch after launch -- 20 launches where the round-3 hazard
+lived --, ASCII input, the bench's mixes against the oracle. (Round 5 removed the A/B-only switches -- INWAVE, OVERLAP -- and their kernels.)"""
 from __future__ import annotations
 
 import json
@@ -17,12 +17,8 @@ pytestmark = pytest.mark.gpu
 
 SETTINGS = [
     ("default", {}, 20),
-    ("resume_pass", {"SSHASH_AMD_INWAVE": "0"}, 20),
-    ("no_overlap", {"SSHASH_AMD_OVERLAP": "0"}, 3),
-    ("overlap_always", {"SSHASH_AMD_OVERLAP": "1"}, 3),
-    ("overlap_always_resume_pass", {"SSHASH_AMD_OVERLAP": "1", "SSHASH_AMD_INWAVE": "0"}, 3),
-    ("packed_table", {"SSHASH_AMD_SK_SLOTS_PER_KEY": "1.4", "SSHASH_AMD_SK_SLOTS_PER_KMER": "1.3"}, 3),
-    ("small_pieces", {"SSHASH_AMD_PIECE": "1000000"}, 3),
+    ("packed_table", {"SSHASH_AMD_TEST_HOOKS": "slots_per_key=1.4,slots_per_kmer=1.3"}, 3),
+    ("small_pieces", {"SSHASH_AMD_TEST_HOOKS": "piece=1000000"}, 3),
     ("table_key_17", {"SSHASH_AMD_SK_M": "17"}, 3),   # the table's own key length (sk_view::m): shorter and longer than the
     ("table_key_25", {"SSHASH_AMD_SK_M": "25"}, 3),   # dictionary's minimizers (m = 21 here)
     ("directory", {"SSHASH_AMD_SKTABLE": "0", "SSHASH_AMD_DIRECTORY": "1"}, 3),
@@ -51,6 +47,5 @@ def test_every_kmer_launch_after_launch(name, env, launches):
 
 
 @pytest.mark.parametrize("workload", ["c3_like_canonical", "c4_like_k63"])
-@pytest.mark.parametrize("name,env", [("default", {}), ("resume_pass", {"SSHASH_AMD_INWAVE": "0"})])
-def test_other_flavours_launch_after_launch(workload, name, env):
-    assert run(workload, env, 20)["ok"]
+def test_other_flavours_launch_after_launch(workload):
+    assert run(workload, {}, 20)["ok"]

@@ -155,3 +155,48 @@ def test_repeat_family_spss_k63_is_a_set():
     assert s["num_kmers"] == total and s["num_buckets_in_skew_index"] >= 1 and s["max_bucket_size"] > 64
     cmp = statistics_vs_target(s, "human_k63")
     assert cmp["num_kmers"]["achieved"] == total and 0 < cmp["scale"] < 1e-2
+
+
+def test_the_stand_in_generator_cuts_chance_duplicates_out():
+    """A spectrum-preserving string set holds every k-mer once. The stand-in generator de-duplicates family by family; k-mers of
+    different families coincide by chance once or twice per 10^9 (round 5: the full-size C2 stand-in held one, and
+    lookup(access(id)) == id failed for that id). _duplicate_kmer_starts / _cut_kmers_out (sshash_amd/repeats.py) find and remove them:
+    here on strings with a planted copy and a planted reverse complement -- every other k-mer stays, none occurs twice."""
+    import torch
+
+    from sshash_amd import repeats as R
+
+    k = 31
+    g = torch.Generator()
+    g.manual_seed(3)
+    codes = torch.randint(0, 4, (6000,), generator=g, dtype=torch.uint8)
+    lens = torch.tensor([1000, 1500, 2500, 1000])
+    codes[3200:3231] = codes[100:131]                  # a k-mer of string 0 once more in string 2
+    codes[1400:1431] = codes[100:131].flip(0) ^ 2      # and its reverse complement in string 1
+    codes[5990:6000] = codes[40:50]                    # (ten bases: no k-mer)
+
+    def kmer_multiset(c, l):
+        out, a = {}, 0
+        for n in l.tolist():
+            s = c[a:a + n].numpy()
+            for i in range(n - k + 1):
+                x = s[i:i + k]
+                key = min(bytes(x), bytes(x[::-1] ^ 2))
+                out[key] = out.get(key, 0) + 1
+            a += n
+        return out
+
+    before = kmer_multiset(codes, lens)
+    assert max(before.values()) == 3
+    starts = R._duplicate_kmer_starts(codes, lens, k, torch.device("cpu"), chunk=1 << 10, parts=4)
+    assert 1400 in starts and 3200 in starts and 100 not in starts
+    c2, l2 = R._cut_kmers_out(codes, lens, starts, k)
+    after = kmer_multiset(c2, l2)
+    assert set(after) == set(before) and max(after.values()) == 1 and int(l2.min()) >= k
+    assert R._duplicate_kmer_starts(c2, l2, k, torch.device("cpu")).size == 0
+    # and the generator as a whole: no k-mer twice, at a size where the families alone leave none
+    words, endpoints = R.make_recipe_spss("se_k31", 3_000_000, seed=7, device="cpu")
+    total = int(endpoints[-1])
+    pos = np.arange(total, dtype=np.int64)
+    again = torch.from_numpy(((words[pos >> 5] >> ((pos & 31) * 2).astype(np.uint64)) & np.uint64(3)).astype(np.uint8))
+    assert R._duplicate_kmer_starts(again, torch.from_numpy(np.diff(endpoints).astype(np.int64)), k, torch.device("cpu")).size == 0

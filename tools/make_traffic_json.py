@@ -1,11 +1,14 @@
 #!/usr/bin/env python
-"""profiles/traffic.json from a PMC profile of the bench command (tools/jobs/r02_profile.sh -> <dir>/summary.json):
+"""profiles/traffic.json from a PMC profile of the bench command (tools/jobs/r05_profile.sh -> <dir>/summary.json + bench.jsonl):
 HBM bytes per bench step, with the counters, the formula and the commit it was measured at.
 
-    python tools/make_traffic_json.py gpurun_out/r04_prof_c3 profiles/r04/bench_c3_pmc_summary.json [bases] [workload name]
+    python tools/make_traffic_json.py <profile dir> <kept summary path> [record name]
 
-profiles/traffic.json holds one record per workload name (c3, c2, c4: bench.py --workload); bench.py attaches the record of the
-workload it runs when the shape (queries, bases, k, canonical) is the same."""
+profiles/traffic.json holds one record per record name -- bench.py's `traffic_key`: the workload (c3, c2, c4) for the lookup line,
+<workload>_streaming_p<percent positive> for the streaming lines, <workload>_directory / <workload>_mphf for the table-less paths
+(SSHASH_AMD_SKTABLE=0 [SSHASH_AMD_DIRECTORY=0]) -- and bench.py attaches a record to a line when the shape it was measured on
+(queries or reads per GPU, read length, bases, k, canonical) is the line's own. Every kernel of the step counts: the lookup passes
+(first, resume, deferred, scan), the streaming kernels (pack pass, run kernel)."""
 import json
 import subprocess
 import sys
@@ -13,39 +16,44 @@ import sys
 src, kept = sys.argv[1], sys.argv[2]
 s = json.load(open(src + "/summary.json"))
 bench = json.loads(open(src + "/bench.jsonl").read().strip().splitlines()[-1])
-if len(sys.argv) <= 3:
-    sys.argv.append(str(bench["config"].get("num_bases", 2_813_192_630)))
-workload = sys.argv[4] if len(sys.argv) > 4 else "c3"
+cfg, roof = bench["config"], bench["roofline"]
+streaming = "reads_per_gpu" in cfg
 pl, ks = s["per_launch_counter_averages"], s["kernel_stats"]
-launches = bench["roofline"]["launches_per_step"]
 
 
 def bytes_of(d):
     return d["TCC_EA0_RDREQ_sum"] * 64 + d["TCC_EA0_WRREQ_64B_sum"] * 64 + (d["TCC_EA0_WRREQ_sum"] - d["TCC_EA0_WRREQ_64B_sum"]) * 32
 
 
-per_seq = {k: bytes_of(pl[k]) for k in ("fast", "resume", "deferred") if k in pl and "TCC_EA0_RDREQ_sum" in pl[k]}  # (k <= 31: no resume pass since round 3)
-total = int(sum(per_seq.values()) * launches)
-n = bench["config"]["queries_per_gpu"]
-requests = sum(pl[k]["TCC_EA0_RDREQ_sum"] + pl[k]["TCC_EA0_WRREQ_sum"] for k in per_seq) * launches
+per_kernel = {k: bytes_of(pl[k]) for k in pl if "TCC_EA0_RDREQ_sum" in pl[k]}
+launches = 1 if streaming else roof.get("launches_per_step", 1)  # a lookup step of 10^9 queries is eight launch sequences; their kernels are averaged per launch
+total = int(sum(per_kernel.values()) * launches)
+units = cfg["reads_per_gpu"] * (cfg["read_length"] - cfg["k"] + 1) if streaming else cfg["queries_per_gpu"]
+requests = sum(pl[k]["TCC_EA0_RDREQ_sum"] + pl[k]["TCC_EA0_WRREQ_sum"] for k in per_kernel) * launches
+name = sys.argv[3] if len(sys.argv) > 3 else bench.get("traffic_key")
+if not name:
+    raise SystemExit("no record name: the bench line carries no traffic_key and none was given")
 rec = {
-    "workload": bench["config"]["workload"],
-    "queries": n, "bases": int(sys.argv[3]) if len(sys.argv) > 3 else 2_813_192_630,  # bench.py --bases (default: the C3 workload's)
-    "canonical": bench["config"]["canonical"], "k": bench["config"]["k"],
+    "workload": cfg.get("workload_short") or cfg["workload"],
+    "bases": cfg.get("num_bases"), "canonical": cfg["canonical"], "k": cfg["k"],
     "hbm_bytes_per_launch": total,
-    "hbm_requests_per_lookup": round(requests / n, 4),
-    "unit_note": "bytes per STEP (%d launch sequences) = %d x sum over the lookup kernels of one launch sequence (first pass, deferred pass; a resume pass at k > 31) of [TCC_EA0_RDREQ_sum x 64 B + "
-                 "TCC_EA0_WRREQ_64B_sum x 64 B + (TCC_EA0_WRREQ_sum - TCC_EA0_WRREQ_64B_sum) x 32 B], averages per launch; TCC_EA0_RDREQ_32B_sum = 0 "
-                 "(every read request is 64 bytes); random 64-byte requests are counted once (calibrated with tools/tlb_probe: 2^27 random lines -> "
-                 "1.342e8 RDREQ), so no x2 correction for this access pattern; the coalesced query/id streams (16 B per lookup) may be under-counted "
-                 "by up to 2x (guide: wide streaming reads tally 128-byte requests as 64)" % (launches, launches),
-    "per_launch_sequence_bytes": {k: int(v) for k, v in per_seq.items()},
-    "per_launch_counters": {k: {c: int(v) for c, v in pl[k].items() if c.startswith(("TCC", "TCP"))} for k in pl},
+    "hbm_requests_per_unit": round(requests / units, 4),
+    "unit_note": "bytes per STEP = %d x sum over the step's kernels (%s) of [TCC_EA0_RDREQ_sum x 64 B + TCC_EA0_WRREQ_64B_sum x 64 B + (TCC_EA0_WRREQ_sum - "
+                 "TCC_EA0_WRREQ_64B_sum) x 32 B], averages per launch of `rocprofv3 --pmc` passes of the bench command itself; TCC_EA0_RDREQ_32B_sum = 0 (every read "
+                 "request is 64 bytes); random 64-byte requests are counted once (calibrated with tools/tlb_probe: 2^27 random lines -> 1.342e8 RDREQ), so no x2 "
+                 "correction for this access pattern; the coalesced streams (queries, ids, the reads' characters) may be under-counted by up to 2x (guide: wide "
+                 "streaming reads tally 128-byte requests as 64)" % (launches, ", ".join(sorted(per_kernel))),
+    "per_kernel_bytes": {k: int(v) for k, v in per_kernel.items()},
+    "per_launch_counters": {k: {c: int(v) for c, v in pl[k].items() if c.startswith(("TCC", "TCP", "SQ_INSTS_VALU", "SQ_WAVES"))} for k in pl},
     "kernel_avg_ns": {k: ks[k]["avg_ns"] for k in ks},
-    "counters": "rocprofv3 --pmc, one group per pass (tools/jobs/r03_profile.sh)",
+    "counters": "rocprofv3 --pmc, one group per pass (tools/jobs/r05_profile.sh)",
     "commit": subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip(),
     "source": kept,
 }
+if streaming:
+    rec.update({"reads": cfg["reads_per_gpu"], "read_length": cfg["read_length"], "kmers": units})
+else:
+    rec.update({"queries": cfg["queries_per_gpu"], "hbm_requests_per_lookup": rec["hbm_requests_per_unit"]})
 json.dump(s, open(kept, "w"), indent=1)
 try:
     every = json.load(open("profiles/traffic.json"))
@@ -53,6 +61,6 @@ try:
         every = {"c3": every}
 except Exception:
     every = {}
-every[workload] = rec
+every[name] = rec
 json.dump(every, open("profiles/traffic.json", "w"), indent=1)
-print(total / 1e9, "GB per step =", round(total / n, 2), "B per lookup;", rec["hbm_requests_per_lookup"], "requests per lookup")
+print(name, total / 1e9, "GB per step =", round(total / units, 2), "B per", "k-mer;" if streaming else "lookup;", rec["hbm_requests_per_unit"], "requests per unit")
