@@ -130,7 +130,7 @@ def recipe_digest(name: str) -> str:
 
 def make_standin(args):
     """The synthetic SPSS of this run: the named recipe at --bases bases; --repeat-scale multiplies the amount of every repeat
-    family (the heavy-key sweep of DESIGN.md section 6; 1.0 = the fitted recipe)."""
+    family (the heavy-key sweep of HISTORY.md; 1.0 = the fitted recipe)."""
     import torch
     from sshash_amd.repeats import load_recipe, make_repeat_spss
 
@@ -670,7 +670,7 @@ def main():
     avg_kernel_ms = float(np.mean(kernel_ms))
     per_rank = [{"rank": 0, "queries": n, "ms_per_step": round(own_elapsed / args.steps * 1e3, 3), "kernel_ms_per_step": round(avg_kernel_ms, 3),
                  "upload_s": round(upload_window[1] - upload_window[0], 2)}]
-    kernel_ms_steps = [round(float(t), 3) for t in kernel_ms]  # rank 0's steps one by one: sustained load drifts (clocks), see DESIGN.md section 6
+    kernel_ms_steps = [round(float(t), 3) for t in kernel_ms]  # rank 0's steps one by one: sustained load drifts (clocks), see HISTORY.md
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -720,7 +720,7 @@ def main():
                                               "+ query in + id out, counted by the instrumented oracle on this batch",
                     "avg_kernel_ms": round(avg_kernel_ms, 3), "kernel_ms_steps": kernel_ms_steps,
                     # what bounds a structure of one random bucket per query on this chip is random UNITS, not bytes: 43.8 G
-                    # random 64-byte units/s, 39.9 G 128-byte ones (tools/tlb_probe)
+                    # random 64-byte units/s, 39.9 G 128-byte ones (tools/tlb_probe; HISTORY.md)
                     "random_unit_bound": {"probe_units_per_s": RANDOM_UNIT_PROBE, "source": "profiles/r02/tlb_probe_128_256_byte_units.jsonl",
                                           "lookups_per_s_this_gpu": round(n / (avg_kernel_ms * 1e-3), 1), "units_per_s_this_gpu": round(n / (avg_kernel_ms * 1e-3), 1),
                                           "frac": round(n / (avg_kernel_ms * 1e-3) / RANDOM_UNIT_PROBE, 4)}}
@@ -913,10 +913,10 @@ def compact_line(full, record_path):
     times, the complete child lines, the rules in prose) is in the full record at `record_path`."""
     if full is None:
         return None
-    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "traffic_key"))
     cfg = full.get("config", {})
     line["config"] = _pick(cfg, ("queries_per_step", "queries_per_gpu", "reads", "read_length", "reads_per_gpu", "num_kmers", "k", "m", "canonical",
-                                 "index_replicated_per_gpu", "sharded", "positive_fraction_found", "positive_fraction_of_kmers", "extensions_per_search",
+                                 "num_bases", "index_replicated_per_gpu", "sharded", "positive_fraction_found", "positive_fraction_of_kmers", "extensions_per_search",
                                  "counters_equal_oracle_on_reads", "ids_equal_oracle_on_queries", "device_index_bytes", "device_bytes_per_kmer", "recipe",
                                  "report"))
     line["config"] = {"workload": str(cfg.get("workload_short") or cfg.get("workload", ""))[:400], **line["config"]}

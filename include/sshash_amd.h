@@ -226,7 +226,9 @@ sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char*
 /* reads stored back to back: read r = bases[read_offsets[r] .. read_offsets[r+1]) ; host buffers */
 sshash_status sshash_streaming_query(const sshash_dict* d, const char* bases, const uint64_t* read_offsets,
                                      uint64_t num_reads, sshash_streaming_report* report);
-/* device buffers; `report` is a device pointer to 6 uint64 counters, accumulated into */
+/* device buffers; `report` is a device pointer to 6 uint64 counters, accumulated into. The kernels are enqueued on `hip_stream`; before
+ * that the call reads read_offsets[num_reads] back (8 bytes: the size of the 2-bit packed copy of the reads it makes) and so waits for
+ * what the stream holds at that moment -- the one synchronisation of this entry point. */
 sshash_status sshash_streaming_query_device(const sshash_dict* d, int device, const char* bases,
                                             const uint64_t* read_offsets, uint64_t num_reads, uint64_t* report,
                                             void* hip_stream);

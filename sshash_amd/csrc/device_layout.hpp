@@ -73,7 +73,7 @@
 //               one request and ONE address translation per lookup: with one lane issuing the 16-byte loads of its
 //               own slot every load is a separate UTCL1 miss once the table outgrows the ~2 GiB the per-CU
 //               translation cache covers, and the translation-request rate (75 G/s chip-wide), not DRAM, is what
-//               capped round 1's table at 38 G reads/s;
+//               capped round 1's table at 38 G reads/s (HISTORY.md);
 //        slot   32 bytes:
 //                 d0  bit0 valid | bit1 marker | bit2 strand | bits 3-7 go-on flags of the BUCKET, one per choice
 //                     (kept in slot 0 only) | bits 8-13 left | bits 14-19 right | bit 20 (slot 0 only) slot 1 is in use |
@@ -187,7 +187,7 @@ static_assert((SK_GO_ON << (SK_CHOICES - 1)) < (1u << SK_LEFT_SHIFT), "go-on fla
 static_assert(SK_CHOICES == 5, "sk_hash and sk_choice spell out five choices");
 constexpr uint32_t SK_INLINE_MAX = 4;         // a key with up to this many occurrences holds one inline slot per occurrence;
                                               // a heavier key holds a marker and its k-mers are keyed one by one
-constexpr double SK_SLOTS_PER_KEY = 2.5;  // slots per item: load factor 0.4 (1.6 ... 4.0 measured)
+constexpr double SK_SLOTS_PER_KEY = 2.5;  // slots per item: load factor 0.4 (HISTORY.md: 1.6 ... 4.0 measured)
 /* k <= 63: 3.0 (load factor 0.33). A bucket there is two lines, an item in slot 1 or past its first bucket costs a second one, and since the
    table's keys are 31 bases long (sk_table_m) the k-mers' region is small enough to pay for it: same-box, four alternating rounds
    (profiles/r04/slots_per_key_c4_table_key_31.txt) 2.5 -> 3.0 -> 3.5 slots = 30.0 -> 31.4 -> 32.0 G lookups/s (medians) for 13.35 -> 15.17 ->
@@ -223,7 +223,7 @@ struct sk_view {
     uint32_t kmer_buckets;
     /* length of the table's key m-mers. The table elects its own key (sk_key), so it need not be the dictionary's minimizer length:
        a shorter key makes longer super-k-mers (up to k - m + 1 k-mers an item) and so fewer items -- what the table's size is
-       proportional to. Set by build_sk_table; every table-side function reads it from here, never dict_view::m */
+       proportional to (HISTORY.md). Set by build_sk_table; every table-side function reads it from here, never dict_view::m */
     uint32_t m;
     /* table shard (multi-GPU, sharded.py): this replica's table holds only the keys with
        sk_owner(key, num_shards) == shard_id; lookups of other keys take the complete path */
@@ -259,7 +259,7 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_buckets) {
     /* out of `a` alone (its low 24 bits; bucket[0] comes out of its high 32): the first pass needs bucket[0] and the fingerprint
        only, and with the fingerprint taken from `c` (rounds 1-2) it had to compute b and c -- three 64-bit multiplies, a dozen
        VALU instructions each -- for every query, although only the twentieth that goes on ever looks at the other buckets. At
-       k <= 63 the first pass is bound by its instructions. */
+       k <= 63 the first pass is bound by its instructions (HISTORY.md). */
     h.fingerprint = uint32_t(a) & 0xFFFFFFu;
     return h;
 }
@@ -317,7 +317,7 @@ SSH_HD uint64_t sk_kmer_key(kmer_w<W> const& x, kmer_w<W> const& x_rc) {
    only -- 24 bits per candidate, one funnel shift to extract them, one 24-bit multiply-add to hash them -- and carries
    the candidate's position in the low 6 bits of the hash, so that a running minimum replaces compare-and-select: two and a
    half VALU instructions per candidate (the first version hashed the whole m-mer: eleven; round 2: four; at k = 63, m = 25
-   the 78 candidates made the first pass VALU-bound). Per strand the leftmost occurrence with the smallest
+   the 78 candidates made the first pass VALU-bound, HISTORY.md). Per strand the leftmost occurrence with the smallest
    26-bit hash wins; the strand with the smaller winning hash supplies the key -- the whole m-mer at the elected
    position --; equal hashes on the two strands = tie (no key: the caller takes the complete path). */
 struct sk_key_t {

@@ -212,7 +212,7 @@ device_replica const* engine::replica(int device) const {
 
 /* How this library's device code was built (csrc/Makefile): through tools/isa_guard.py -- SSHASH_ISA_GUARDED is defined by that
    recipe's host-side compile and by nothing else -- or by a plain hipcc, whose register allocation may expose kernels to the
-   last-VGPR hazard of gfx950. */
+   last-VGPR hazard of gfx950 (HISTORY.md). */
 char const* isa_guard_state() {
 #if defined(SSHASH_ISA_GUARDED)
     return "guarded";
@@ -228,7 +228,7 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
         std::call_once(once, [] {
             fprintf(stderr, "[sshash_amd] WARNING: this library was NOT built through tools/isa_guard.py (make -C sshash_amd/csrc): on gfx950 a "
                                 "kernel that keeps a 64-bit shift amount in the last VGPR of its allocation computes wrongly some of the time "
-                                "(DESIGN.md section 6); tests/test_isa_guard.py names the kernels of a build that are exposed\n");
+                                "(HISTORY.md); tests/test_isa_guard.py names the kernels of a build that are exposed\n");
         });
     }
 #endif
@@ -592,7 +592,7 @@ fast_lookup_kernel(const dict_view d, const void* __restrict__ queries, const ui
         /* (This instance allocates exactly 64 VGPRs and hipcc keeps a 64-bit shift's amount in v63, the last of them: on this chip
            such a shift is wrong in 6-7 % of its executions -- the "0.15 % of the indexed k-mers absent, differently from launch to
            launch" of rounds 2 and 3, which an asm keep-alive of three dead registers used to hide by moving the allocation to 72.
-           tools/isa_guard.py now pads such kernels when the library is built; DESIGN.md section 6, tools/debug/vgpr64_check.hip.) */
+           tools/isa_guard.py now pads such kernels when the library is built; HISTORY.md, tools/debug/vgpr64_check.hip.) */
         __builtin_nontemporal_store(uint8_t(r.outcome == FAST_HIT ? 1 : 0), member + i);
     } else {
         hit_t h;

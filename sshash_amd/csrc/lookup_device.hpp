@@ -511,7 +511,7 @@ __device__ __forceinline__ fast_t fast_probe_canonical(dict_view const& d, kmer_
 /* ---- the same first pass with PAIR-COOPERATIVE 32-byte fetches (round 4; regular dictionaries, k <= 31) ---------------------
    A lane that reads a 32-byte unit -- a directory bucket, an atom of the strings -- with two 16-byte loads makes every load
    instruction of the wave touch 64 different pages: two translation requests per unit, and the chip serves 75 G of those a second
-   (DESIGN.md section 6): the table-less first pass ran at 39 G units/s, that bound, not the memory's. Here the two lanes of a pair
+   (HISTORY.md): the table-less first pass ran at 39 G units/s, that bound, not the memory's. Here the two lanes of a pair
    read each other's units together: one load instruction fetches the even lane's unit (16 bytes a lane), the next the odd lane's,
    the halves change hands through DPP -- the same two load instructions per lane, but each touches 32 units instead of 64: one
    translation per unit. Called by all lanes of the wave (need = false: no unit wanted; the pair's load goes to unit 0). */
@@ -714,7 +714,7 @@ __device__ __forceinline__ void sk_examine_slot_tracking(dict_view const& d, sk_
     const uint32_t meta = q0.x;
     if constexpr (FIRST) {
         /* decided now, in its own register: hipcc 7.2 has been seen recycling a slot word that is only
-           consumed much later */
+           consumed much later (HISTORY.md) */
         uint32_t go_on = meta & (SK_GO_ON << c);
         /* first choice: only if a key with this query's filter index went on from here (device_layout.hpp) */
         if (c == 0) go_on &= 0u - ((meta >> (SK_FILTER_SHIFT + sk_filter_index(Q.fingerprint))) & 1u);
@@ -919,7 +919,7 @@ __device__ __forceinline__ bool sk_walk_step(dict_view const& d, kmer_w<W> const
    quad's lane p & 3 -- with one load instruction, and lane L deposits its piece at region p + 16 L of the wave's
    staging area: quad q's line lands contiguously at region p + 64 q, which transposes "lane = piece" into "lane =
    owner of the whole line". 4 W rounds fetch the buckets of all 64 lanes. The memory pipeline sees one request (and
-   one address translation) per line instead of one per 16-byte load (device_layout.hpp (5)). */
+   one address translation) per line instead of one per 16-byte load (device_layout.hpp (5), HISTORY.md). */
 
 template <int OWNER>
 __device__ __forceinline__ uint32_t quad_broadcast(uint32_t v) {
@@ -932,7 +932,7 @@ __device__ __forceinline__ uint32_t quad_broadcast(uint32_t v) {
 
    The pieces move through registers (global_load_dwordx4 + ds_write_b128). Moving them straight into LDS
    (global_load_lds_dwordx4) measured the same speed and miscompiled under hipcc 7.2 -- the repro and the micro-benchmarks
-   are kept in tools/debug/ (glds_check, m0_check, vcc_check), the code path is gone. */
+   are kept in tools/debug/ (glds_check, m0_check, vcc_check; HISTORY.md), the code path is gone. */
 
 /* Between two phases of a wave that talk through LDS: everything this lane has issued has completed, and the compiler moves
    no memory operation across. (The "wavefront" fences used elsewhere in this file order the accesses for the compiler and rely on
@@ -1152,7 +1152,7 @@ __device__ __forceinline__ fast_t sk_first_pass_wave(dict_view const& d, kmer_w<
    fetch; quads without a customer fetch bucket 0, an L2 hit), the pieces land in LDS and the owners examine their lines. No
    queue entry written and read back, no second kernel, and above all no placeholder id that a later pass rewrites: an 8-byte
    store into a line that has left the caches costs the DRAM a masked write -- a random access of its own, one of the 2.5 a
-   resumed query cost in the resume pass. */
+   resumed query cost in the resume pass (HISTORY.md). */
 /* (k <= 31 only. At k <= 63 finishing in the wave measured as a loss -- round 3: 6 %, round 4, with ranked fetches everywhere: 5.5 %,
    profiles/r04/inwave_k63_ab.txt: 27.1 -> 25.6 G lookups/s. The k <= 63 first pass runs at the chip's random-line rate and what it
    needs for that is waves in flight: the loop's state takes the kernel from 60 to 86 registers, eight waves per SIMD to five. There

@@ -30,7 +30,7 @@ bool ends_with(std::string const& s, char const* suffix) {
 
 /* ---- BGZF (bgzip, htslib) -------------------------------------------------------------------------------------
    A plain .gz is one deflate stream: it inflates on one thread, at zlib's 0.28 G bases/s, and that is what the file query
-   then runs at. A BGZF file -- what bgzip writes, a series of gzip members of at most 64 KiB each
+   then runs at (HISTORY.md). A BGZF file -- what bgzip writes, a series of gzip members of at most 64 KiB each
    whose header says how long the member is (extra subfield 'B','C': BSIZE) -- needs no decoding to find its members, so
    they are inflated side by side: a group of members is read, their sizes are in their last four bytes (ISIZE), every
    worker inflates a share of them into its place of the group's output, CRC-checked; the next group is decoded while the

@@ -41,7 +41,7 @@ private:
 };
 
 /* An UNCOMPRESSED FASTQ file read by several threads at once (the file query runs at the reader's pace: one thread splits
-   9 GB/s of file, the streaming kernels take 40+ GB/s of bases). The file is cut at fixed byte positions;
+   9 GB/s of file, the streaming kernels take 40+ GB/s of bases, HISTORY.md). The file is cut at fixed byte positions;
    piece i takes the records whose header line STARTS in [cut i, cut i+1): it finds the first record start at or behind its cut
    -- a line beginning with '@' whose line after next begins with '+': of the four lines of a record only the header passes
    that test (a quality line may begin with '@', but then the line after next is a line of bases) -- and from there counts

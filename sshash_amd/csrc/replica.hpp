@@ -76,7 +76,7 @@ struct device_replica {
             scratch_pool = nullptr;  // (fall back to the default pool with its default behaviour)
             (void)hipGetLastError();
             /* not silently: the default pool hands its memory back at every synchronisation -- 190-260 ms instead of 13 per batched
-               streaming call */
+               streaming call (HISTORY.md) */
             if (std::getenv("SSHASH_AMD_VERBOSE"))
                 fprintf(stderr, "[sshash_amd] device %d: no private memory pool (hipMemPoolCreate failed): stream-ordered scratch comes out of the default pool\n", device);
             return;

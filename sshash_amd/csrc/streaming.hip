@@ -58,7 +58,7 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
 }
 
 /* The counters of a workgroup (of 256) reach `report` with ONE set of atomics: the six counters share a cache line, and a set
-   per wave -- 2 x 10^5 atomics on one line for 3 x 10^8 bases -- serialises at ~90 atomics/us. Called by
+   per wave -- 2 x 10^5 atomics on one line for 3 x 10^8 bases -- serialises at ~90 atomics/us (HISTORY.md). Called by
    every lane of the workgroup. */
 __device__ __forceinline__ void block_report(uint64_t c_kmers, uint64_t c_invalid, uint64_t c_negative, uint64_t c_searches,
                                              uint64_t c_extensions, uint64_t* __restrict__ report) {
@@ -220,8 +220,9 @@ __device__ __forceinline__ uint64_t extend_run(dict_view const& d, const uint64_
    quad read one line with one instruction -- ONE address translation a line; a lane reading its own line in four 16-byte pieces asks for
    four, and at 70 G translation misses a second chip-wide that, not DRAM, bounded the first version of this kernel: 2.28 x 10^9 misses
    for 5 x 10^8 probes, profiles/r05/streaming_run_kernel_v2_random_pmc_summary.json) and is read out of LDS (`mine`). And the slots
-   say for how many of the following k-mers with the same key occurrence a miss stands (`lasts`: sk_examine_slot_tracking); a probe that
-   has to go on past its first bucket, or meets its key's marker, promises nothing. */
+   say for how many of the following k-mers with the same key occurrence a miss stands (`lasts`: sk_examine_slot_tracking) -- the first
+   bucket's and those of the later buckets of the key's sequence; a probe that meets its key's marker, or ends on the complete path,
+   promises nothing. */
 template <int W>
 __device__ __forceinline__ fast_t stream_probe(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
                                                uint32_t b, uint32_t fingerprint, const uint4* mine, uint32_t& lasts) {
@@ -242,7 +243,6 @@ __device__ __forceinline__ fast_t stream_probe(dict_view const& d, kmer_w<W> con
     }
     const uint32_t first_go_on = flags.go_on;
     if (r.outcome != FAST_MISS || (!marker && first_go_on == 0)) return r;  // found, or a miss that is final here
-    lasts = 0;
     /* The rest of the walk (lookup_device.hpp: sk_walk_step), by this lane alone, the choices hashed as they are needed. Where it
        stands: sequence `on` (the key's, or -- once the key's marker has been met -- the k-mer's own, in the k-mers' region), choice c
        of it, and the choice of the key's sequence to come back to when the k-mer's sequence ends without the k-mer (the marker may
@@ -254,6 +254,7 @@ __device__ __forceinline__ fast_t stream_probe(dict_view const& d, kmer_w<W> con
 #pragma unroll 1
     for (;;) {
         if (marker && !visited) {
+            lasts = 0;  // (from here on the walk follows the K-MER's own sequence: what it finds says nothing about the next k-mer)
             back_to = go_on ? c + 1 : SK_NO_RETURN;
             visited = true;
             compact = true;
@@ -264,6 +265,7 @@ __device__ __forceinline__ fast_t stream_probe(dict_view const& d, kmer_w<W> con
         } else if (go_on) {
             if (++c >= SK_CHOICES) {  // a key (or k-mer) that found no slot: the complete path
                 r.outcome = FAST_DEFER;
+                lasts = 0;
                 break;
             }
         } else if (compact && back_to != SK_NO_RETURN) {  // not under its own key: the rest of the key's sequence
@@ -296,9 +298,11 @@ __device__ __forceinline__ fast_t stream_probe(dict_view const& d, kmer_w<W> con
             }
         }
         if (!compact) {
-            sk_examine_slot<W, true>(d, Q, c, [B](uint32_t i) { return B[i]; }, r, seen, marker, flags);
+            /* the later buckets of the KEY's sequence are the key's alone -- which of them a walk sees, and in which order, does not
+               depend on the k-mer --, so their slots have their say on `lasts` like the first bucket's */
+            sk_examine_slot_tracking<W, true, true>(d, Q, c, [B](uint32_t i) { return B[i]; }, r, seen, marker, flags, lasts);
             if (r.outcome == FAST_MISS && flags.second_used)
-                sk_examine_slot<W, false>(d, Q, c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags);
+                sk_examine_slot_tracking<W, false, true>(d, Q, c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags, lasts);
         }
         if (r.outcome != FAST_MISS) break;
         go_on = flags.go_on;
@@ -630,7 +634,7 @@ stream_classify_kernel(const uint8_t* __restrict__ flags, const uint64_t total_b
                        const uint64_t* string_id, const int8_t* orientation /* may be out's own arrays */, uint64_t* __restrict__ report,
                        const bool has_predecessor /* the arrays continue below index 0: a later piece of one call */) {
     /* grid-stride: the six counters are accumulated in registers and reach `report` once per wave -- one hot set of
-       atomics per wave of 64 k-mers would serialise at ~90 atomics/us */
+       atomics per wave of 64 k-mers would serialise at ~90 atomics/us (HISTORY.md) */
     uint64_t c_kmer = 0, c_invalid = 0, c_negative = 0, c_search = 0, c_extension = 0;
     /* Four consecutive places per lane and turn, everything they may need requested at once (what a branch does not use
        is ignored): one load after the other, each behind its test, made a chain of round trips per place, and the pass
@@ -962,7 +966,7 @@ streaming_report engine::streaming_query_host(char const* bases, uint64_t const*
 }
 
 /* The file query of an uncompressed FASTQ (engine.hpp). One reader thread feeding batches through streaming_query_host splits
-   9 GB/s of file and the devices wait for it nine tenths of the time; here parsing is the lanes' own
+   9 GB/s of file and the devices wait for it nine tenths of the time (HISTORY.md); here parsing is the lanes' own
    work: lane = host thread + stream + pinned block + device block, as many lanes as usable CPUs, dealt round-robin to the
    resident replicas. */
 bool engine::streaming_query_fastq_pieces(std::string const& filename, streaming_report& total) const {

@@ -2,7 +2,7 @@
 """Worker of tests/test_gpu_switches.py: one process = one setting of the environment switches that select kernels (they are read
 once per process). Every k-mer of a stand-in goes through the id-returning and the is_member instances of the lookup, `launches`
 times, in file order and shuffled, forward and reverse-complemented -- a wrong answer that varies from launch to launch (the
-gfx950 hazard of DESIGN.md section 6 showed up as exactly that) cannot hide behind one lucky launch --, then ASCII input, then a
+gfx950 hazard of HISTORY.md showed up as exactly that) cannot hide behind one lucky launch --, then ASCII input, then a
 mixed batch against the CPU oracle. Prints one JSON line; any mismatch is an assertion error.
 
     python tests/gpu_switch_worker.py <recipe> <bases> <k> <m> <canonical 0|1> <launches>"""

@@ -536,7 +536,7 @@ def test_a_full_resume_queue_sends_its_queries_down_the_complete_path(case_name,
 
 
 def test_entry_points_that_launch_once_refuse_what_one_launch_cannot_carry(case_se_regular):
-    """A launch of 2^32 threads or more is silently not carried out: access / weight / neighbours /
+    """A launch of 2^32 threads or more is silently not carried out (HISTORY.md): access / weight / neighbours /
     route say so instead of returning untouched output. (Nothing is dereferenced before the check.)"""
     import torch
 

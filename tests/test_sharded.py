@@ -116,6 +116,45 @@ def test_two_rank_sharded_lookup_on_gpu(canonical, by, tmp_path):
     assert "SHARDED OK 60000" in outs[0]
 
 
+MISMATCH_WORKER = textwrap.dedent(
+    """
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, sys.argv[1])
+    import torch, torch.distributed as dist
+    import sshash_amd
+    from sshash_amd.sharded import ShardedDictionary
+
+    dist.init_process_group(backend="gloo")
+    rank = dist.get_rank()
+    torch.cuda.set_device(0)
+    sd = ShardedDictionary.build(sys.argv[2], device=0, by="table", k=31, m=13, canonical=False, num_threads=4)
+    print("KEY LENGTH", sd.shard.device_stats(0)["sk_key_length"], flush=True)
+    try:
+        sd.lookup(np.arange(1000, dtype=np.uint64))
+        print("NO ERROR", flush=True)
+    except sshash_amd.SSHashError as e:
+        print("REFUSED:", e, flush=True)
+    dist.barrier(); dist.destroy_process_group()
+    """
+)
+
+
+@pytest.mark.gpu
+def test_ranks_that_elect_table_keys_of_different_lengths_refuse_to_route(tmp_path):
+    """SSHASH_AMD_SK_M is read when a replica is built and steers which rank owns a key: ranks started under different environments would
+    route keys to ranks that do not hold them, silently. The ranks compare the length at their first collective call."""
+    script = tmp_path / "worker.py"
+    script.write_text(MISMATCH_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, SE_FASTA], env=dict(env, RANK=str(r), LOCAL_RANK=str(r), SSHASH_AMD_SK_M=("15", "17")[r]),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-3000:]
+        assert f"KEY LENGTH {('15', '17')[r]}" in o and "REFUSED:" in o and "SSHASH_AMD_SK_M must be the same on every rank" in o and "NO ERROR" not in o, o[-2000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case_name", ["case_skew_regular", "case_k63_canonical"])
 def test_a_table_shard_answers_every_query_on_its_own(case_name, request):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: C2 against the table's parameters (key length, slots per item), same box
+# round 5: C2 against the table's key length, same box, two alternating rounds (profiles/r05/c2_table_key_length_sweep.txt)
 cd "$(dirname "$0")/../.."
 out=gpurun_out/r05_c2_sweep; mkdir -p $out
 S="--workload c2 --steps 20 --warmup 5 --no-cpu-baseline --no-extra-mixes --no-other-paths --no-file-query --no-other-workloads --no-line-probe --quiet-record"
@@ -15,7 +15,4 @@ for round in 1 2; do
 run m21_$round "A=1"
 run m22_$round "SSHASH_AMD_SK_M=22"
 run m23_$round "SSHASH_AMD_SK_M=23"
-run m21_slots2_$round "SSHASH_AMD_SK_SLOTS_PER_KEY=2.0"
-run m22_slots2_$round "SSHASH_AMD_SK_M=22 SSHASH_AMD_SK_SLOTS_PER_KEY=2.0"
-run m23_slots2_$round "SSHASH_AMD_SK_M=23 SSHASH_AMD_SK_SLOTS_PER_KEY=2.0"
 done

@@ -8,7 +8,7 @@ OUT=gpurun_out/$NAME
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python bench.py --no-cpu-baseline --no-extra-mixes --no-file-query --no-other-paths --no-other-workloads --no-line-probe --quiet-record --steps 3 --warmup 1 $*"
-$BENCH > $OUT/bench.jsonl 2> $OUT/bench.err      # builds and caches the index
+$BENCH --full-record $OUT/bench_full.json > $OUT/bench.jsonl 2> $OUT/bench.err      # builds and caches the index
 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
 find $OUT/trace -name 't_kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 i=0
