@@ -214,102 +214,6 @@ __device__ __forceinline__ uint64_t extend_run(dict_view const& d, const uint64_
     return run;
 }
 
-/* sk_probe (lookup_device.hpp) for a seed of the run-based kernel: the same walk, with three differences. The first bucket's choice and
-   the key's fingerprint are hashed alone (sk_hash_first, by the caller) -- the other four choices cost three more 64-bit multiplies and
-   one probe in twenty looks at them. The first bucket's line has been fetched by the wave together (sk_stage_lines: the four lanes of a
-   quad read one line with one instruction -- ONE address translation a line; a lane reading its own line in four 16-byte pieces asks for
-   four, and at 70 G translation misses a second chip-wide that, not DRAM, bounded the first version of this kernel: 2.28 x 10^9 misses
-   for 5 x 10^8 probes, profiles/r05/streaming_run_kernel_v2_random_pmc_summary.json) and is read out of LDS (`mine`). And the slots
-   say for how many of the following k-mers with the same key occurrence a miss stands (`lasts`: sk_examine_slot_tracking) -- the first
-   bucket's and those of the later buckets of the key's sequence; a probe that meets its key's marker, or ends on the complete path,
-   promises nothing. */
-template <int W>
-__device__ __forceinline__ fast_t stream_probe(dict_view const& d, kmer_w<W> const& x, kmer_w<W> const& x_rc, sk_key_t const& kk,
-                                               uint32_t b, uint32_t fingerprint, const uint4* mine, uint32_t& lasts) {
-    sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, fingerprint);
-    fast_t r = fast_unsettled(false);
-    lasts = 0xFFFFu;
-    auto staged = [mine](uint32_t i) { return mine[i]; };
-    sk_bucket_flags flags;
-    bool marker = false, seen = false;
-    sk_examine_slot_tracking<W, true, true>(d, Q, 0, staged, r, seen, marker, flags, lasts);
-    if (r.outcome == FAST_MISS && flags.second_used) {
-        if constexpr (W == 1) {
-            sk_examine_slot_tracking<W, false, true>(d, Q, 0, [mine](uint32_t i) { return mine[2 + i]; }, r, seen, marker, flags, lasts);
-        } else {  // slot 1 lives in the bucket's second line, and only the lanes whose key's fingerprint is there get here
-            const uint4* B1 = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(b) + 2 * W;
-            sk_examine_slot_tracking<W, false, true>(d, Q, 0, [B1](uint32_t i) { return B1[i]; }, r, seen, marker, flags, lasts);
-        }
-    }
-    const uint32_t first_go_on = flags.go_on;
-    if (r.outcome != FAST_MISS || (!marker && first_go_on == 0)) return r;  // found, or a miss that is final here
-    /* The rest of the walk (lookup_device.hpp: sk_walk_step), by this lane alone, the choices hashed as they are needed. Where it
-       stands: sequence `on` (the key's, or -- once the key's marker has been met -- the k-mer's own, in the k-mers' region), choice c
-       of it, and the choice of the key's sequence to come back to when the k-mer's sequence ends without the k-mer (the marker may
-       have been another key's with an equal fingerprint). */
-    uint64_t on = kk.key, on_a = sk_hash_a(kk.key);
-    uint32_t c = 0, back_to = SK_NO_RETURN, go_on = first_go_on;
-    bool visited = false;  // the k-mer's own sequence has been (or is being) walked
-    bool compact = false;  // the walk is on the k-mer's own sequence: the k-mers' region, compact entries (device_layout.hpp)
-#pragma unroll 1
-    for (;;) {
-        if (marker && !visited) {
-            lasts = 0;  // (from here on the walk follows the K-MER's own sequence: what it finds says nothing about the next k-mer)
-            back_to = go_on ? c + 1 : SK_NO_RETURN;
-            visited = true;
-            compact = true;
-            on = sk_kmer_key<W>(x, x_rc);
-            on_a = sk_hash_a(on);
-            c = 0;
-            Q.fingerprint = uint32_t(on_a) & 0xFFFFFFu;
-        } else if (go_on) {
-            if (++c >= SK_CHOICES) {  // a key (or k-mer) that found no slot: the complete path
-                r.outcome = FAST_DEFER;
-                lasts = 0;
-                break;
-            }
-        } else if (compact && back_to != SK_NO_RETURN) {  // not under its own key: the rest of the key's sequence
-            c = back_to;
-            back_to = SK_NO_RETURN;
-            if (c >= SK_CHOICES) {
-                r.outcome = FAST_DEFER;
-                break;
-            }
-            compact = false;
-            on = kk.key;
-            on_a = sk_hash_a(on);
-            Q.fingerprint = uint32_t(on_a) & 0xFFFFFFu;
-        } else {
-            break;  // a final miss
-        }
-        const uint32_t bucket = compact ? d.sk.num_buckets + sk_choice_of(on, on_a, c, d.sk.kmer_buckets) : sk_choice_of(on, on_a, c, d.sk.num_buckets);
-        const uint4* B = reinterpret_cast<const uint4*>(static_cast<char const*>(d.sk.slots) + sk_bucket_offset<W>(d, bucket, compact));
-        marker = false;
-        if constexpr (W == 2) {
-            if (compact) {
-                sk_examine_kmer_entry<true>(Q, c, [B](uint32_t i) { return B[i]; }, r, flags);
-                sk_examine_kmer_entry<false>(Q, c, [B](uint32_t i) { return B[2 + i]; }, r, flags);
-            }
-        } else {
-            if (compact) {
-                const uint4 l0 = B[0], l1 = B[1], l2 = B[2], l3 = B[3];
-                const uint32_t words[16] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
-                sk_examine_kmer_line(Q, c, [&words](uint32_t i) { return words[i]; }, r, flags);
-            }
-        }
-        if (!compact) {
-            /* the later buckets of the KEY's sequence are the key's alone -- which of them a walk sees, and in which order, does not
-               depend on the k-mer --, so their slots have their say on `lasts` like the first bucket's */
-            sk_examine_slot_tracking<W, true, true>(d, Q, c, [B](uint32_t i) { return B[i]; }, r, seen, marker, flags, lasts);
-            if (r.outcome == FAST_MISS && flags.second_used)
-                sk_examine_slot_tracking<W, false, true>(d, Q, c, [B](uint32_t i) { return B[2 * W + i]; }, r, seen, marker, flags, lasts);
-        }
-        if (r.outcome != FAST_MISS) break;
-        go_on = flags.go_on;
-    }
-    return r;
-}
-
 /* (four waves a SIMD: 102 registers at k <= 31, 118 at k <= 63. Compiled for five -- 96 registers, 20 to 100 bytes of scratch -- it is as fast at
    k <= 31 and 9 % slower at k <= 63; for six, 14 / 31 % slower: profiles/r05/streaming_run_kernel_waves_per_simd_ab.txt) */
 template <int W, bool CANON, bool SK>
@@ -333,9 +237,17 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
     int ori = 1;
     bool neg_unknown_mini = false;          // (no table) streaming_query.hpp:150-157
     uint64_t prev_f = 0, prev_r = 0;
+    /* a seed whose probe has to go on past its key's first bucket is WALKING: its k-mer, its key and where the walk stands are kept
+       from turn to turn. `where`: the choice of the sequence it is on | flags | the choice of the key's sequence to come back to */
+    constexpr uint32_t WALK_CHOICE = 7u, WALK_COMPACT = 8u, WALK_VISITED = 16u, WALK_WALKED = 32u, WALK_BACK_SHIFT = 8u, WALK_NO_RETURN = 7u;
+    bool walking = false;
+    kmer_w<W> x = kmer_zero<W>(), x_rc = kmer_zero<W>();
+    sk_key_t kk{};
+    uint64_t on = 0, on_a = 0;
+    uint32_t where = 0;
     for (;;) {
         /* -- the reads: whoever has none left takes the next of the wave's share -- */
-        const bool want = cur + k > rd_end;
+        const bool want = !walking && cur + k > rd_end;
         const uint64_t wants = __ballot(want);
         if (wants != 0 && next < last) {
             const uint64_t rank = uint64_t(__popcll(wants & ((uint64_t(1) << lane) - 1)));
@@ -370,13 +282,11 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             live = false;  // (its next k-mer waits for the next turn: it may lie over an invalid base, or in the next read)
         }
         pending = false;
-        /* -- seed() at cur (streaming_query.hpp:144-197): the k-mer, its key, its key's first bucket -- */
-        kmer_w<W> x = kmer_zero<W>(), x_rc = kmer_zero<W>();
-        sk_key_t kk{};
+        /* -- seed() at cur (streaming_query.hpp:144-197): the k-mer, its key, its key's first bucket; a lane in the middle of a walk
+              (its key's first bucket was not the end of it) keeps its k-mer and comes with the walk's next bucket instead -- */
         uint64_t ahead_f = 0, ahead_r = 0;
-        uint32_t bucket = 0, fingerprint = 0;
         bool table = false;
-        if (live) {
+        if (live && !walking) {
             const uint64_t i = cur >> 5;
             const uint32_t sh = 2 * (uint32_t(cur) & 31u);
             const uint64_t w0 = packed[i], w1 = packed[i + 1];
@@ -391,24 +301,85 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 ahead_r = read_bases32(packed, cur + k + 1 - hashed);
                 kk = sk_key<W>(x, x_rc, k, sm);
                 table = sk_usable(d, kk);
-                sk_hash_first(kk.key, d.sk.num_buckets, bucket, fingerprint);
+                on = kk.key;
+                on_a = sk_hash_a(on);
+                where = WALK_NO_RETURN << WALK_BACK_SHIFT;  // choice 0 of the key's own sequence, nothing to come back to, nothing walked yet
             }
         }
         bool settled = false, found = false;
         if constexpr (SK) {
-            sk_stage_lines<W>(d, bucket, 0u, table, wave_stage);  // (all 64 lanes, whatever their event)
-            if (table) {
-                uint32_t lasts;
-                const fast_t r = stream_probe<W>(d, x, x_rc, kk, bucket, fingerprint, wave_stage + (lane & 3u) * 64 + (lane >> 2) * 4, lasts);
-                if (r.outcome != FAST_DEFER) {
+            /* ONE bucket a turn for every lane that is at a seed: the key's first, or the next of a walk -- fetched by the wave together
+               (sk_stage_lines: the four lanes of a quad read one line with one instruction, ONE address translation a line; a lane
+               reading its own line in four pieces asks for four, and at 70 G translation misses a second chip-wide that bounded the
+               first version of this kernel) and examined out of LDS. A walk that goes on does so in the lane's next turn: no lane
+               waits inside a turn for another lane's second bucket (what the walk cost as a loop inside the turn: 27 % of the kernel,
+               profiles/r05/streaming_ablation_what_each_part_costs.txt). */
+            const bool need = table || walking;
+            const uint32_t c = where & WALK_CHOICE;
+            const bool compact = (where & WALK_COMPACT) != 0;  // on the k-mer's own sequence: the k-mers' region, compact entries
+            uint32_t bucket = 0;
+            if (need) bucket = compact ? d.sk.num_buckets + sk_choice_of(on, on_a, c, d.sk.kmer_buckets) : sk_choice_of(on, on_a, c, d.sk.num_buckets);
+            sk_stage_lines<W, true>(d, bucket, 0u, need, wave_stage, compact);  // (all 64 lanes, whatever their event)
+            if (need) {
+                const uint4* mine = wave_stage + (lane & 3u) * 64 + (lane >> 2) * 4;
+                sk_query_t<W> Q = sk_make_query<W>(x, x_rc, kk, uint32_t(on_a) & 0xFFFFFFu);
+                fast_t r = fast_unsettled(false);
+                sk_bucket_flags flags;
+                flags.go_on = 0;
+                flags.second_used = false;
+                bool marker = false, seen = false;
+                uint32_t lasts = 0xFFFFu;
+                if (!compact) {
+                    sk_examine_slot_tracking<W, true, true>(d, Q, c, [mine](uint32_t i) { return mine[i]; }, r, seen, marker, flags, lasts);
+                    if (r.outcome == FAST_MISS && flags.second_used) {
+                        if constexpr (W == 1) {
+                            sk_examine_slot_tracking<W, false, true>(d, Q, c, [mine](uint32_t i) { return mine[2 + i]; }, r, seen, marker, flags, lasts);
+                        } else {  // slot 1 lives in the bucket's second line, and only the lanes whose key's fingerprint is there get here
+                            const uint4* B1 = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(bucket) + 2 * W;
+                            sk_examine_slot_tracking<W, false, true>(d, Q, c, [B1](uint32_t i) { return B1[i]; }, r, seen, marker, flags, lasts);
+                        }
+                    }
+                } else if constexpr (W == 1) {
+                    const uint32_t* words = reinterpret_cast<const uint32_t*>(mine);
+                    sk_examine_kmer_line(Q, c, [words](uint32_t i) { return words[i]; }, r, flags);
+                } else {
+                    sk_examine_kmer_entry<true>(Q, c, [mine](uint32_t i) { return mine[i]; }, r, flags);
+                    sk_examine_kmer_entry<false>(Q, c, [mine](uint32_t i) { return mine[2 + i]; }, r, flags);
+                }
+                /* where the walk goes from here (lookup_device.hpp: sk_walk_step) */
+                const bool go_on = flags.go_on != 0;
+                bool more = false, defer = false;
+                if (r.outcome == FAST_MISS) {
+                    if (marker && !(where & WALK_VISITED)) {  // the key is heavy: its k-mers are entered under keys of their own
+                        where = WALK_VISITED | WALK_COMPACT | WALK_WALKED | ((go_on ? c + 1 : WALK_NO_RETURN) << WALK_BACK_SHIFT);
+                        on = sk_kmer_key<W>(x, x_rc);
+                        on_a = sk_hash_a(on);
+                        more = true;
+                    } else if (go_on) {
+                        defer = c + 1 >= SK_CHOICES;  // a key (or k-mer) that found no slot: the complete path
+                        where = (where & ~WALK_CHOICE) | (c + 1) | WALK_WALKED;
+                        more = !defer;
+                    } else if (compact && ((where >> WALK_BACK_SHIFT) & WALK_CHOICE) != WALK_NO_RETURN) {
+                        /* the k-mer is not under its own key (the marker may have been another key's with an equal fingerprint): what is
+                           left is the rest of the key's sequence */
+                        const uint32_t back = (where >> WALK_BACK_SHIFT) & WALK_CHOICE;
+                        defer = back >= SK_CHOICES;
+                        where = WALK_VISITED | WALK_WALKED | back | (WALK_NO_RETURN << WALK_BACK_SHIFT);
+                        on = kk.key;
+                        on_a = sk_hash_a(on);
+                        more = !defer;
+                    }
+                }
+                walking = more;
+                if (!more && !defer) {
                     settled = true;
                     found = r.outcome == FAST_HIT;
                     off = r.kmer_offset;
                     ori = r.orientation;
-                    if (!found) {
+                    if (!found && !(where & WALK_WALKED)) {
                         /* a miss that stands for the k-mers behind this one: those that elect the same key occurrence (sk_key_persists)
                            and still hold the base that keeps the read and the key's slot apart (`lasts`; no slot with the key: all of
-                           them) are negative as well -- counted, not looked at */
+                           them) are negative as well -- counted, not looked at. (A miss at the end of a walk stands for itself.) */
                         uint64_t keep = sk_key_persists<W>(kk, k, d.sk.m, ahead_f, ahead_r);
                         keep = keep < lasts ? keep : lasts;
                         keep = keep < valid_end - (cur + k) ? keep : valid_end - (cur + k);
@@ -418,7 +389,8 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 }
             }
         }
-        if (live && !settled) {
+        const bool finishing = live && !walking;  // (a walking lane's seed is settled in a later turn)
+        if (finishing && !settled) {
             /* no table, or a tie / an unplaced key / another shard's key: the complete seed() */
             const minimizer_t mf = compute_minimizer<W>(x, k, d.m, d.hash_magic);
             const minimizer_t mr = compute_minimizer<W>(x_rc, k, d.m, d.hash_magic);
@@ -434,7 +406,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 neg_unknown_mini = !SK && !h.found && !h.minimizer_found;
             }
         }
-        if (live) {
+        if (finishing) {
             if (found) {
                 ++c_searches;
                 neg_unknown_mini = false;
