@@ -353,8 +353,9 @@ def streaming_roofline(d, args, n_reads_local, W, achieved, avg_kernel_ms, kerne
                       "reads packed to 2 bits first; avg_kernel_ms = HIP-event time around one step, on the launch stream)" % W,
             "avg_kernel_ms": round(avg_kernel_ms, 3), "kernel_ms_steps": [round(float(t), 3) for t in kernel_ms],
             "algorithmic_bytes_per_kmer": round(algorithmic / rep["num_kmers"], 3),
-            "algorithmic_bytes_rule": "1 B per base + (searches + negatives) x the oracle-counted bytes of a lookup (%.1f B: the reference's seed() is a "
-                                      "full lookup) + extensions x 8 W B (the string's next k-mer)" % bytes_per_lookup}
+            "algorithmic_bytes_rule": "1 B per base + 8 B per distinct 64-bit index word the reference's streaming state machine dereferences per k-mer (the "
+                                      "lookups of a seed() its unchanged-minimizer test does not cut short; the strings' next k-mer of an extension), counted "
+                                      "by the instrumented oracle on the checked sample of reads"}
     if traffic:
         roof["frac_hbm_traffic"] = round(traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         roof["hbm_traffic_bytes_per_kmer"] = round(traffic / n_local_kmers, 3)
@@ -451,16 +452,15 @@ def streaming_mode(args, d, index_path, rank, world, local_rank, dev, use_dist, 
     got = dict(zip(names, (int(v) for v in part.cpu().tolist())))
     if got != {f: int(v) for f, v in want.items()}:
         raise SystemExit(f"PARITY FAILURE: streaming counters of the first {m} reads: GPU {got} vs oracle {want}")
-    # algorithmic bytes (SURVEY 8(d) rule, extended to the streaming query): every base is read once (1 B); a k-mer that does not
-    # extend the previous one costs the reference a full lookup (seed(): searches + negatives, at the bytes per lookup the
-    # instrumented oracle counts on this dictionary's 50/50 mix); an extension reads the next k-mer of the string (8 W B)
+    # algorithmic bytes (SURVEY 8(d) rule, applied to the streaming query k-mer by k-mer): 1 B per base of the reads + 8 B per distinct
+    # 64-bit index word the REFERENCE's state machine dereferences for a k-mer -- the lookups of a seed() that its unchanged-minimizer
+    # test does not cut short, the strings' next k-mer of an extension --, counted by the instrumented oracle on the sample it has just
+    # checked (the first `m` reads of rank 0's share) and scaled by k-mers. (Until round 5 every negative was priced as a full lookup,
+    # which the reference does not do either: a line that skips what the reference skips then sat above the roofline.)
     W = d.words_per_kmer()
-    from sshash_amd.synthetic import draw_queries_device
-
-    mix = draw_queries_device(d, local_rank, 100_000, 0.5, seed=args.seed + 3).cpu().numpy().view(np.uint64)
-    bytes_per_lookup = ora.count_bytes(mix) / 100_000
-    lookups = rep["num_searches"] + rep["num_negative_kmers"]
-    algorithmic = args.reads * L + lookups * bytes_per_lookup + rep["num_extensions"] * 8 * W
+    bytes_per_kmer = ora.streaming_count_bytes(sample) / max(1, want["num_kmers"])
+    algorithmic = bytes_per_kmer * rep["num_kmers"]
+    bytes_per_lookup = None
     n_local_kmers = per_rank[0]["report"][0]
     achieved = algorithmic * (n_local_kmers / rep["num_kmers"]) / (avg_kernel_ms * 1e-3) / 1e9
     total_kmers = rep["num_kmers"] * args.steps

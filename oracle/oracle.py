@@ -69,6 +69,8 @@ def lib() -> C.CDLL:
         L.oracle_weights.restype = C.c_int
         L.oracle_streaming_query.argtypes = [P, P, P, C.c_uint64, P]
         L.oracle_streaming_read.argtypes = [P, P, C.c_uint64, P]
+        L.oracle_streaming_count_bytes.restype = C.c_uint64
+        L.oracle_streaming_count_bytes.argtypes = [P, P, P, C.c_uint64]
         L.oracle_encode_kmer.argtypes = [C.c_char_p, C.c_uint32, P]
         L.oracle_revcomp.argtypes = [P, C.c_uint32, C.c_int, P]
         L.oracle_minimizer.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, P, P]
@@ -155,6 +157,16 @@ class OracleIndex:
         lib().oracle_streaming_query(self._h, bases.ctypes.data, offsets.ctypes.data, len(chunks), rep.ctypes.data)
         names = ["num_kmers", "num_positive_kmers", "num_negative_kmers", "num_invalid_kmers", "num_searches", "num_extensions"]
         return dict(zip(names, (int(x) for x in rep)))
+
+    def streaming_count_bytes(self, reads) -> int:
+        """Algorithmic bytes of streaming_query(reads): 8 B per distinct index word the reference's state machine dereferences per
+        k-mer (the lookups of a seed() that is not cut short, the strings' next k-mer of an extension) + 1 B per base."""
+        chunks = [s.encode("ascii", "replace") if isinstance(s, str) else bytes(s) for s in reads]
+        offsets = np.zeros(len(chunks) + 1, dtype=np.uint64)
+        if chunks:
+            offsets[1:] = np.cumsum([len(c) for c in chunks], dtype=np.uint64)
+        bases = np.frombuffer(b"".join(chunks) or b"\0", dtype=np.uint8)
+        return int(lib().oracle_streaming_count_bytes(self._h, bases.ctypes.data, offsets.ctypes.data, len(chunks)))
 
     def streaming_read(self, read) -> np.ndarray:
         b = read.encode("ascii", "replace") if isinstance(read, str) else bytes(read)

@@ -705,6 +705,33 @@ void oracle_streaming_query(const oracle_index* d, const char* bases, const uint
     report[5] = s.num_extensions;
 }
 
+/* Algorithmic bytes of a streaming query under the counting rule of SURVEY.md section 8(d), applied k-mer by k-mer to what the
+   REFERENCE's state machine does: 8 bytes per distinct 64-bit index word it dereferences for that k-mer -- the lookups of a seed()
+   that is not cut short by the unchanged-minimizer test (:150-157), the strings' next k-mer of an extension (:86-100) -- plus one byte
+   per base of the reads. (No per-k-mer result is counted: the query reports six counters.) */
+uint64_t oracle_streaming_count_bytes(const oracle_index* d, const char* bases, const uint64_t* off, uint64_t num_reads) {
+    sq_state s;
+    sq_init(&s, d);
+    touch_ctx ctx;
+    uint64_t total = 0;
+    for (uint64_t r = 0; r < num_reads; ++r) {
+        const char* read = bases + off[r];
+        const uint64_t len = off[r + 1] - off[r];
+        sq_reset(&s);
+        total += len;
+        if (len < d->k) continue;
+        for (uint64_t i = 0; i + d->k <= len; ++i) {
+            ctx.n = 0;
+            ctx.extra_bytes = 0;
+            g_touch = &ctx;
+            (void)sq_lookup(&s, read + i);
+            g_touch = NULL;
+            total += 8ull * (uint64_t)ctx.n + ctx.extra_bytes;
+        }
+    }
+    return total;
+}
+
 void oracle_streaming_read(const oracle_index* d, const char* read, uint64_t len, oracle_result* out) {
     sq_state s;
     sq_init(&s, d);

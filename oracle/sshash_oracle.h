@@ -70,6 +70,8 @@ void oracle_streaming_query(const oracle_index* idx, const char* bases, const ui
                             uint64_t report[6]);
 /* per-k-mer results of ONE read (len - k + 1 entries), as streaming_query::lookup returns them */
 void oracle_streaming_read(const oracle_index* idx, const char* read, uint64_t len, oracle_result* out);
+/* algorithmic bytes of a streaming query: 8 bytes per distinct index word the reference's state machine dereferences per k-mer + 1 per base */
+uint64_t oracle_streaming_count_bytes(const oracle_index* idx, const char* bases, const uint64_t* read_offsets, uint64_t num_reads);
 
 /* ---- primitives, exposed so that they can be pinned against golden vectors ---- */
 void oracle_encode_kmer(const char* s, uint32_t k, uint64_t out[2]);

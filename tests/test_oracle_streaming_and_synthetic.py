@@ -200,3 +200,22 @@ def test_the_stand_in_generator_cuts_chance_duplicates_out():
     pos = np.arange(total, dtype=np.int64)
     again = torch.from_numpy(((words[pos >> 5] >> ((pos & 31) * 2).astype(np.uint64)) & np.uint64(3)).astype(np.uint8))
     assert R._duplicate_kmer_starts(again, torch.from_numpy(np.diff(endpoints).astype(np.int64)), k, torch.device("cpu")).size == 0
+
+
+def test_streaming_algorithmic_bytes_follow_the_reference_state_machine(case_se_regular):
+    """oracle_streaming_count_bytes (bench.py's roofline for the streaming lines): 1 B per base + 8 B per distinct index word the
+    reference's state machine dereferences per k-mer. An extension costs the strings' next k-mer (one or two words), a seed that the
+    unchanged-minimizer test cuts short costs nothing, a read shorter than k costs its bases."""
+    case = case_se_regular
+    s = max(case.sequences, key=len)
+    whole = s[500:800]                                   # one search, then extensions only
+    rep = case.oracle.streaming_query([whole])
+    assert rep["num_searches"] == 1 and rep["num_extensions"] == len(whole) - case.k
+    b = case.oracle.streaming_count_bytes([whole])
+    assert len(whole) + 8 * rep["num_extensions"] <= b <= len(whole) + 16 * rep["num_extensions"] + 400
+    assert case.oracle.streaming_count_bytes(["ACGT"]) == 4 and case.oracle.streaming_count_bytes([]) == 0
+    poly = "A" * 200                                     # one minimizer throughout: after the first seed every k-mer is cut short (if absent)
+    rep = case.oracle.streaming_query([poly])
+    if rep["num_negative_kmers"] == rep["num_kmers"]:
+        assert case.oracle.streaming_count_bytes([poly]) < len(poly) + 400
+    assert case.oracle.streaming_count_bytes([whole, poly]) == b + case.oracle.streaming_count_bytes([poly])
