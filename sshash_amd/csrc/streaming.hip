@@ -443,10 +443,11 @@ void launch_streaming_runs(device_replica const* rep, dict_view const& d, char c
         hipLaunchKernelGGL(stream_pack_kernel, dim3(uint32_t((lanes + 255) / 256)), dim3(256), 0, s, bases, total_bases,
                            reinterpret_cast<uint16_t*>(packed), reinterpret_cast<uint8_t*>(okay));
     }
-    /* waves: a share of at least 8 reads a lane (a lane that finishes its read takes the wave's next: the longer the share, the
-       better the lanes of a wave even out), at most as many waves as the chip holds at once */
-    const uint64_t max_waves = uint64_t(256) * 4 * (W == 1 ? 5 : 4);  // (what the chip holds of this kernel: 96 registers at k <= 31, 114 at k <= 63)
-    uint64_t waves = std::min<uint64_t>(max_waves, std::max<uint64_t>(1, n_reads / (64 * 8)));
+    /* waves: as many as the chip holds at once -- a lane that finishes its read takes the next of its wave's share, and the longer the
+       share, the better the lanes of a wave even out --, fewer for a small call (a piece of a query file: some 10^4 reads, many calls
+       side by side on their own streams), down to two reads a lane */
+    const uint64_t max_waves = uint64_t(256) * 4 * (W == 1 ? 5 : 4);  // (what the chip holds of this kernel: 96 registers at k <= 31, 106 at k <= 63)
+    uint64_t waves = std::min<uint64_t>(max_waves, std::max<uint64_t>(1, n_reads / (64 * 2)));
     waves = (waves + 3) / 4 * 4;
     const uint64_t reads_per_wave = (n_reads + waves - 1) / waves;
     const dim3 grid(uint32_t(waves / 4)), block(256);
