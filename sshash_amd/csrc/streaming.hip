@@ -182,34 +182,54 @@ __device__ __forceinline__ void string_bases32(dict_view const& d, uint64_t p, u
 
 /* Length of the run behind a hit: the read's k-mer that ends at base `b` - 1 lies at offset `off` of the strings (orientation
    `ori`); at most `room` k-mers follow it inside the read's valid bases. Returns how many of them are extensions. */
+/* One step of a run's measurement: the 32 bases of the strings that come next in the run's direction and the marks that stop it,
+   next to the read's 32 bases from base b + run. Forward, the t-th extension gains the strings' base off + k - 1 + t and leaves its
+   string iff a string starts there. Backward it gains the base off - t, complemented, and leaves its string iff a string starts at
+   off - t + 1 (streaming_query.hpp:92: remaining_string_bases = kmer_id_in_string going backward): a step takes the `have` bases below
+   `top` = off - run. Loads only: what they bring is looked at by run_step_length. */
+struct run_step_t {
+    uint64_t s, marks, read;
+    uint32_t have;  // backward: how many bases lie below `top` (32, fewer at the very start of the strings; 0: none)
+};
+
+template <int W>
+__device__ __forceinline__ run_step_t run_step_load(dict_view const& d, const uint64_t* __restrict__ packed, uint64_t off, bool forward,
+                                                    uint64_t b, uint64_t run) {
+    run_step_t t;
+    const uint64_t top = off - run;
+    t.have = forward || top >= 32 ? 32u : uint32_t(top);
+    string_bases32<W>(d, forward ? off + d.k + run : top - t.have, t.s, t.marks);
+    t.read = read_bases32(packed, b + run);
+    return t;
+}
+
+/* how many of the (at most 32) extensions of a step hold: the strings' bases along the run -- backward: the `have` bases below `top`,
+   the last of them moved to place 31, reversed and complemented: place i = comp(S[top - 1 - i]) -- against the read's, up to the first
+   mark that stops the run -- bit 31 - i of `gate` stops extension i; backward the mark of base top - i: marks bit (have - i) */
+__device__ __forceinline__ uint32_t run_step_length(run_step_t const& t, bool forward) {
+    const uint64_t along = forward ? t.s : revcomp_word(t.s << (2 * (32 - t.have)));
+    const uint64_t diff = along ^ t.read;
+    const uint32_t same = diff ? uint32_t(__builtin_ctzll(diff)) >> 1 : 32u;
+    const uint32_t gate = forward ? uint32_t(__brev(uint32_t(t.marks))) : uint32_t((t.marks >> 1) << (32 - t.have));
+    const uint32_t inside = gate ? uint32_t(__builtin_clz(gate)) : 32u;
+    const uint32_t step = same < inside ? same : inside;
+    return step < t.have ? step : t.have;
+}
+
+/* Length of the run behind a hit: the read's k-mer that ends at base `b` - 1 lies at offset `off` of the strings (orientation `ori`);
+   at most `room` k-mers follow it inside the read's valid bases; `first`: the first step's loads, asked for by the caller early in
+   its turn so that they travel while the turn's bucket lines do. Returns how many of the following k-mers are extensions. */
 template <int W>
 __device__ __forceinline__ uint64_t extend_run(dict_view const& d, const uint64_t* __restrict__ packed, uint64_t off, int ori, uint64_t b,
-                                               uint64_t room) {
-    /* Forward, the t-th extension gains the strings' base off + k - 1 + t and leaves its string iff a string starts there. Backward it
-       gains the base off - t, complemented, and leaves its string iff a string starts at off - t + 1 (streaming_query.hpp:92:
-       remaining_string_bases = kmer_id_in_string going backward). ONE loop for both (the lanes of a wave run in both directions, and two
-       loops are paid for twice): a step takes the 32 bases of the strings that come next in the run's direction -- backward: the `have`
-       bases below `top`, the last of them moved to place 31, reversed and complemented: place i = comp(S[top - 1 - i]) -- and the marks
-       that stop it -- backward: the mark of base top - i stops extension i: marks bit (have - i), moved to bit 31 - i. */
+                                               uint64_t room, run_step_t t) {
     const bool forward = ori > 0;
-    const uint64_t q = off + d.k;
     uint64_t run = 0;
-    while (run < room) {
-        const uint64_t top = off - run;  // (backward) the base gained next is top - 1
-        if (!forward && top == 0) break;
-        const uint32_t have = forward || top >= 32 ? 32u : uint32_t(top);
-        uint64_t s, marks;
-        string_bases32<W>(d, forward ? q + run : top - have, s, marks);
-        const uint64_t along = forward ? s : revcomp_word(s << (2 * (32 - have)));
-        const uint64_t diff = along ^ read_bases32(packed, b + run);
-        const uint32_t same = diff ? uint32_t(__builtin_ctzll(diff)) >> 1 : 32u;
-        const uint32_t gate = forward ? uint32_t(__brev(uint32_t(marks))) : uint32_t((marks >> 1) << (32 - have));  // bit 31 - i stops extension i
-        const uint32_t inside = gate ? uint32_t(__builtin_clz(gate)) : 32u;
-        uint64_t step = same < inside ? same : inside;
-        if (step > have) step = have;
+    for (;;) {
+        uint64_t step = run_step_length(t, forward);
         if (step > room - run) step = room - run;
         run += step;
-        if (step < 32) break;
+        if (step < 32 || run >= room) break;
+        t = run_step_load<W>(d, packed, off, forward, b, run);
     }
     return run;
 }
@@ -275,10 +295,12 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
         }
         const uint64_t valid_end = inv < rd_end ? inv : rd_end;
         /* -- this turn's event of the lane: the run behind the hit of the turn before, or a seed -- */
-        if (live && pending) {
-            const uint64_t run = extend_run<W>(d, packed, off, ori, cur + k - 1, valid_end - (cur + k - 1));
-            c_extensions += run;
-            cur += run;
+        /* (the run's first 32 bases are asked for here and looked at behind the seeds' part of the turn: the strings' atom is a line
+           from HBM like a bucket, and the wave waits once for both) */
+        const bool extending = live && pending;
+        run_step_t first_step{};
+        if (extending) {
+            first_step = run_step_load<W>(d, packed, off, ori > 0, cur + k - 1, 0);
             live = false;  // (its next k-mer waits for the next turn: it may lie over an invalid base, or in the next read)
         }
         pending = false;
@@ -388,6 +410,11 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                     }
                 }
             }
+        }
+        if (extending) {
+            const uint64_t run = extend_run<W>(d, packed, off, ori, cur + k - 1, valid_end - (cur + k - 1), first_step);
+            c_extensions += run;
+            cur += run;
         }
         const bool finishing = live && !walking;  // (a walking lane's seed is settled in a later turn)
         if (finishing && !settled) {
