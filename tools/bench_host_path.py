@@ -7,19 +7,30 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench, sshash_amd
 from sshash_amd.synthetic import draw_queries
-ns = argparse.Namespace(bases=1_387_536_274, k=31, m=21, mean_len=85.0, canonical=False, seed=0x5555AAAA, cache_dir='/tmp', verbose=False)
+ns = argparse.Namespace(bases=1_387_536_274, k=31, m=21, recipe='se_k31', repeat_scale=1.0, canonical=False, seed=0x5555AAAA, cache_dir='/tmp', verbose=False)
 d, path = bench.get_index(ns, 0, 1, lambda: None)
 d.to_device(0)
 n = 50_000_000
 q = draw_queries(d, n, 0.5, seed=5)
 out = np.zeros(n, dtype=np.uint64)   # touched once
 from sshash_amd import _binding as B
-r = B._Results(); r.kmer_id = out.ctypes.data
 lib = B._load()
-def call():
-    st = lib.sshash_lookup_packed(d._h, q.ctypes.data, n, 1, B.C.byref(r)); assert st == 0
-call()
-best = 1e9
-for _ in range(4):
-    t0 = time.perf_counter(); call(); best = min(best, time.perf_counter() - t0)
-print(os.environ.get("SSHASH_AMD_TEST_HOOKS"), "ms", round(best*1e3, 2), "G/s", round(n/best/1e9, 3), flush=True)
+
+
+def measure(q_ptr, out_ptr, what):
+    r = B._Results(); r.kmer_id = out_ptr
+
+    def call():
+        st = lib.sshash_lookup_packed(d._h, q_ptr, n, 1, B.C.byref(r)); assert st == 0
+    call()
+    best = 1e9
+    for _ in range(4):
+        t0 = time.perf_counter(); call(); best = min(best, time.perf_counter() - t0)
+    print(what, os.environ.get("SSHASH_AMD_TEST_HOOKS"), "ms", round(best * 1e3, 2), "G lookups/s", round(n / best / 1e9, 3), "GB/s over the link (16 B per lookup)", round(16 * n / best / 1e9, 1), flush=True)
+
+
+measure(q.ctypes.data, out.ctypes.data, "pageable caller arrays:")
+qp = torch.from_numpy(q.view(np.int64)).pin_memory()
+op = torch.zeros(n, dtype=torch.int64).pin_memory()
+measure(qp.data_ptr(), op.data_ptr(), "page-locked caller arrays:")
+assert (op.numpy().view(np.uint64) == out).all()
