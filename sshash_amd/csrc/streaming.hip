@@ -259,7 +259,8 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
     uint64_t prev_f = 0, prev_r = 0;
     /* a seed whose probe has to go on past its key's first bucket is WALKING: its k-mer, its key and where the walk stands are kept
        from turn to turn. `where`: the choice of the sequence it is on | flags | the choice of the key's sequence to come back to */
-    constexpr uint32_t WALK_CHOICE = 7u, WALK_COMPACT = 8u, WALK_VISITED = 16u, WALK_WALKED = 32u, WALK_BACK_SHIFT = 8u, WALK_NO_RETURN = 7u;
+    constexpr uint32_t WALK_CHOICE = 7u, WALK_COMPACT = 8u, WALK_VISITED = 16u, WALK_BACK_SHIFT = 8u, WALK_NO_RETURN = 7u;
+    constexpr uint32_t WALK_LASTS_SHIFT = 16u, WALK_LASTS = 63u;  // what the slots met so far allow (min over the walk; 63: anything)
     bool walking = false;
     kmer_w<W> x = kmer_zero<W>(), x_rc = kmer_zero<W>();
     sk_key_t kk{};
@@ -325,7 +326,14 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 table = sk_usable(d, kk);
                 on = kk.key;
                 on_a = sk_hash_a(on);
-                where = WALK_NO_RETURN << WALK_BACK_SHIFT;  // choice 0 of the key's own sequence, nothing to come back to, nothing walked yet
+                where = (WALK_NO_RETURN << WALK_BACK_SHIFT) | (WALK_LASTS << WALK_LASTS_SHIFT);  // choice 0 of the key's own sequence, nothing to come back to
+            }
+        }
+        if constexpr (SK) {
+            if (live && walking && !(where & WALK_VISITED)) {  // (a walk along the key's own sequence may end in a miss that stands for more than itself)
+                const uint32_t sm = d.sk.m, hashed = sm < 12 ? sm : 12;
+                ahead_f = read_bases32(packed, cur + k - sm + 1);
+                ahead_r = read_bases32(packed, cur + k + 1 - hashed);
             }
         }
         bool settled = false, found = false;
@@ -368,25 +376,32 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                     sk_examine_kmer_entry<true>(Q, c, [mine](uint32_t i) { return mine[i]; }, r, flags);
                     sk_examine_kmer_entry<false>(Q, c, [mine](uint32_t i) { return mine[2 + i]; }, r, flags);
                 }
+                /* what the slots of the key's sequence have allowed so far, this bucket's included (the buckets of the KEY's sequence are
+                   the key's alone: which of them a walk sees does not depend on the k-mer) */
+                {
+                    const uint32_t before = (where >> WALK_LASTS_SHIFT) & WALK_LASTS;
+                    lasts = lasts < before ? lasts : before;
+                    where = (where & ~(WALK_LASTS << WALK_LASTS_SHIFT)) | (lasts << WALK_LASTS_SHIFT);
+                }
                 /* where the walk goes from here (lookup_device.hpp: sk_walk_step) */
                 const bool go_on = flags.go_on != 0;
                 bool more = false, defer = false;
                 if (r.outcome == FAST_MISS) {
                     if (marker && !(where & WALK_VISITED)) {  // the key is heavy: its k-mers are entered under keys of their own
-                        where = WALK_VISITED | WALK_COMPACT | WALK_WALKED | ((go_on ? c + 1 : WALK_NO_RETURN) << WALK_BACK_SHIFT);
+                        where = WALK_VISITED | WALK_COMPACT | ((go_on ? c + 1 : WALK_NO_RETURN) << WALK_BACK_SHIFT);
                         on = sk_kmer_key<W>(x, x_rc);
                         on_a = sk_hash_a(on);
                         more = true;
                     } else if (go_on) {
                         defer = c + 1 >= SK_CHOICES;  // a key (or k-mer) that found no slot: the complete path
-                        where = (where & ~WALK_CHOICE) | (c + 1) | WALK_WALKED;
+                        where = (where & ~WALK_CHOICE) | (c + 1);
                         more = !defer;
                     } else if (compact && ((where >> WALK_BACK_SHIFT) & WALK_CHOICE) != WALK_NO_RETURN) {
                         /* the k-mer is not under its own key (the marker may have been another key's with an equal fingerprint): what is
                            left is the rest of the key's sequence */
                         const uint32_t back = (where >> WALK_BACK_SHIFT) & WALK_CHOICE;
                         defer = back >= SK_CHOICES;
-                        where = WALK_VISITED | WALK_WALKED | back | (WALK_NO_RETURN << WALK_BACK_SHIFT);
+                        where = WALK_VISITED | back | (WALK_NO_RETURN << WALK_BACK_SHIFT);
                         on = kk.key;
                         on_a = sk_hash_a(on);
                         more = !defer;
@@ -398,10 +413,11 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                     found = r.outcome == FAST_HIT;
                     off = r.kmer_offset;
                     ori = r.orientation;
-                    if (!found && !(where & WALK_WALKED)) {
+                    if (!found && !(where & WALK_VISITED)) {
                         /* a miss that stands for the k-mers behind this one: those that elect the same key occurrence (sk_key_persists)
-                           and still hold the base that keeps the read and the key's slot apart (`lasts`; no slot with the key: all of
-                           them) are negative as well -- counted, not looked at. (A miss at the end of a walk stands for itself.) */
+                           and still hold the base that keeps the read and the key's slots apart (`lasts`, over every bucket of the key's
+                           sequence the walk has seen; no slot with the key: all of them) are negative as well -- counted, not looked at.
+                           (A walk that met its key's marker went on along the K-MER's own sequence: its miss stands for itself.) */
                         uint64_t keep = sk_key_persists<W>(kk, k, d.sk.m, ahead_f, ahead_r);
                         keep = keep < lasts ? keep : lasts;
                         keep = keep < valid_end - (cur + k) ? keep : valid_end - (cur + k);
