@@ -268,6 +268,10 @@ def measure_streaming_from_file(d, index_path, reads_tensor, directory, tag, ora
 def traffic_key(args, path=None):
     """name of this run's record in profiles/traffic.json (tools/make_traffic_json.py)"""
     name = args.workload + ("_canonical" if args.canonical else "")
+    if path is None and os.environ.get("SSHASH_AMD_SKTABLE", "1") == "0":  # (a replica built without the table: its own records)
+        path = "directory" if os.environ.get("SSHASH_AMD_DIRECTORY", "1") != "0" else "mphf"
+        if args.streaming:
+            return f"{name}_{path}_streaming_p{int(round(args.positive * 100))}"
     if path:
         return f"{name}_{path}"
     return f"{name}_streaming_p{int(round(args.positive * 100))}" if args.streaming else name
@@ -827,8 +831,7 @@ def main():
                        "device_bytes_per_kmer": round(d.device_bytes(local_rank) / d.num_kmers(), 2),
                        "device_stats": stats, "recipe": args.recipe, "repeat_scale": args.repeat_scale,
                        "index_statistics": index_statistics, "table_histogram": table_histogram},
-            "traffic_key": traffic_key(args, {("0", "1"): "directory", ("0", "0"): "mphf"}.get(
-                (os.environ.get("SSHASH_AMD_SKTABLE", "1"), os.environ.get("SSHASH_AMD_DIRECTORY", "1")))),
+            "traffic_key": traffic_key(args),
             "per_rank": per_rank,
             "roofline": roofline,
             "cpu_baseline": cpu,
