@@ -264,18 +264,9 @@ SSH_HD sk_hash_t sk_hash(uint64_t key, uint32_t num_buckets) {
     return h;
 }
 
-/* the first choice and the fingerprint alone (both come out of `a`): what a probe that ends in its key's first bucket needs -- 19 in 20 */
-SSH_HD void sk_hash_first(uint64_t key, uint32_t num_buckets, uint32_t& bucket, uint32_t& fingerprint) {
-    uint64_t a = key * 0xFF51AFD7ED558CCDULL;
-    a ^= a >> 32;
-    a *= 0xC4CEB9FE1A85EC53ULL;
-    a ^= a >> 29;
-    bucket = mulhi32(uint32_t(a >> 32), num_buckets);
-    fingerprint = uint32_t(a) & 0xFFFFFFu;
-}
-
-/* choice c of a key's bucket sequence out of the key and the `a` of sk_hash_first's arithmetic, computed when it is asked for: what
-   sk_hash lays out in advance (three more 64-bit multiplies), for a walk that nineteen times in twenty never leaves its first bucket */
+/* choice c of a key's bucket sequence out of the key and `a` -- the first stage of sk_hash's arithmetic, whose low 24 bits are the key's
+   fingerprint --, computed when it is asked for: what sk_hash lays out in advance (three more 64-bit multiplies), for a walk that nineteen
+   times in twenty never leaves its first bucket (the streaming query: streaming.hip) */
 SSH_HD uint64_t sk_hash_a(uint64_t key) {
     uint64_t a = key * 0xFF51AFD7ED558CCDULL;
     a ^= a >> 32;

@@ -124,9 +124,7 @@ int main() {
         if (h.fingerprint >> 24) return printf("fingerprint wider than 24 bits\n"), 1;
         /* the choices computed one by one (sk_choice_of: the streaming query's walk) are sk_hash's */
         const uint64_t k64 = key * 0x9E3779B97F4A7C15ULL >> 22, a = sk_hash_a(k64);
-        uint32_t b0, fp;
-        sk_hash_first(k64, 1000003u, b0, fp);
-        if (b0 != h.bucket[0] || fp != h.fingerprint || (uint32_t(a) & 0xFFFFFFu) != fp) return printf("sk_hash_first differs from sk_hash\n"), 1;
+        if ((uint32_t(a) & 0xFFFFFFu) != h.fingerprint) return printf("sk_hash_a's fingerprint differs from sk_hash's\n"), 1;
         for (uint32_t c = 0; c < SK_CHOICES; ++c)
             if (sk_choice_of(k64, a, c, 1000003u) != h.bucket[c]) return printf("sk_choice_of differs from sk_hash (choice %u)\n", c), 1;
     }
