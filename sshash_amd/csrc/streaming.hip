@@ -234,18 +234,24 @@ __device__ __forceinline__ uint64_t extend_run(dict_view const& d, const uint64_
     return run;
 }
 
-/* (four waves a SIMD: 102 registers at k <= 31, 118 at k <= 63. Compiled for five -- 96 registers, 20 to 100 bytes of scratch -- it is as fast at
-   k <= 31 and 9 % slower at k <= 63; for six, 14 / 31 % slower: profiles/r05/streaming_run_kernel_waves_per_simd_ab.txt) */
+/* (five waves a SIMD: 96 registers. Round 5's steps there, same-box: k <= 31 four -> five waves 110 -> 126 G k-mers/s; k <= 63, once 32-bit
+   counters and a run measurement without early loads had made room, 138 -> 147 with 20 bytes of scratch. Compiled for six: 14 / 31 % slower,
+   profiles/r05/streaming_run_kernel_waves_per_simd_ab.txt.) */
 template <int W, bool CANON, bool SK>
-__global__ void __launch_bounds__(256, W == 1 ? 5 : 4)
+__global__ void __launch_bounds__(256, 5)
 streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const uint64_t* __restrict__ packed,
                      const uint64_t* __restrict__ okay, const uint64_t* __restrict__ offsets, const uint64_t n_reads,
-                     const uint64_t reads_per_wave, uint64_t* __restrict__ report) {
+                     const uint64_t reads_per_wave, const uint32_t move_out_every, uint64_t* __restrict__ report) {
     __shared__ uint4 stage[SK ? 4 * 256 : 1];  // a wave's 64 bucket lines on their way from the quads that fetch them to the lanes that own them
     uint4* const wave_stage = stage + (SK ? (threadIdx.x >> 6) * 256 : 0);
-    uint64_t c_kmers = 0, c_invalid = 0, c_negative = 0, c_searches = 0, c_extensions = 0;
+    /* the counters are 32 bits wide in the lanes (six registers fewer than five 64-bit ones: with them the k <= 63 kernel fits five waves a
+       SIMD); every 2^16 turns -- long before one could wrap -- the wave moves them into 64-bit totals of its own in LDS */
+    __shared__ unsigned long long moved_out[4][5];
+    uint32_t c_invalid = 0, c_negative = 0, c_searches = 0, c_extensions = 0;  // (the k-mers of a read go straight to the wave's total)
     const uint32_t k = d.k;
     const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long* const wave_moved_out = moved_out[threadIdx.x >> 6];
+    if (lane < 5) wave_moved_out[lane] = 0;
     /* this wave's share of the reads, handed out in order to whichever lane is done with its read */
     const uint64_t wave = uint64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     uint64_t next = wave * reads_per_wave, last = next + reads_per_wave;
@@ -266,7 +272,19 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
     sk_key_t kk{};
     uint64_t on = 0, on_a = 0;
     uint32_t where = 0;
+    uint32_t turns = 0;
     for (;;) {
+        if (++turns >= move_out_every) {  // (scalar: a turn adds at most k + 21 to a counter, 2^16 turns some millions)
+            turns = 0;
+            const uint64_t i = wave_sum(c_invalid), n = wave_sum(c_negative), f = wave_sum(c_searches), e = wave_sum(c_extensions);
+            if (lane == 0) {
+                wave_moved_out[0] += i;
+                wave_moved_out[1] += n;
+                wave_moved_out[2] += f;
+                wave_moved_out[3] += e;
+            }
+            c_invalid = c_negative = c_searches = c_extensions = 0;
+        }
         /* -- the reads: whoever has none left takes the next of the wave's share -- */
         const bool want = !walking && cur + k > rd_end;
         const uint64_t wants = __ballot(want);
@@ -276,7 +294,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 const uint64_t r = next + rank;
                 cur = offsets[r];
                 rd_end = offsets[r + 1];
-                if (rd_end - cur >= k) c_kmers += rd_end - cur - k + 1;
+                if (rd_end - cur >= k) atomicAdd(wave_moved_out + 4, (unsigned long long)(rd_end - cur - k + 1));
                 inv = first_invalid_base(okay, cur, rd_end);
                 neg_unknown_mini = false;
             }
@@ -301,7 +319,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
         const bool extending = live && pending;
         run_step_t first_step{};
         if (extending) {
-            first_step = run_step_load<W>(d, packed, off, ori > 0, cur + k - 1, 0);
+            if constexpr (W == 1) first_step = run_step_load<W>(d, packed, off, ori > 0, cur + k - 1, 0);  // (k <= 63: the nine registers this holds across the turn cost the fifth wave)
             live = false;  // (its next k-mer waits for the next turn: it may lie over an invalid base, or in the next read)
         }
         pending = false;
@@ -428,8 +446,10 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             }
         }
         if (extending) {
+            if constexpr (W == 2) first_step = run_step_load<W>(d, packed, off, ori > 0, cur + k - 1, 0);
             const uint64_t run = extend_run<W>(d, packed, off, ori, cur + k - 1, valid_end - (cur + k - 1), first_step);
-            c_extensions += run;
+            if (run >> 30) atomicAdd(wave_moved_out + 3, (unsigned long long)run);  // (a run of a gigabase: past what the lane's counter may take in one turn)
+            else c_extensions += uint32_t(run);
             cur += run;
         }
         const bool finishing = live && !walking;  // (a walking lane's seed is settled in a later turn)
@@ -460,7 +480,9 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             ++cur;
         }
     }
-    block_report(c_kmers, c_invalid, c_negative, c_searches, c_extensions, report);
+    const bool first = lane == 0;  // (what the wave moved out is added once)
+    block_report(first ? wave_moved_out[4] : 0, uint64_t(c_invalid) + (first ? wave_moved_out[0] : 0), uint64_t(c_negative) + (first ? wave_moved_out[1] : 0),
+                 uint64_t(c_searches) + (first ? wave_moved_out[2] : 0), uint64_t(c_extensions) + (first ? wave_moved_out[3] : 0), report);
 }
 
 template <int W, bool CANON>
@@ -489,13 +511,14 @@ void launch_streaming_runs(device_replica const* rep, dict_view const& d, char c
     /* waves: as many as the chip holds at once -- a lane that finishes its read takes the next of its wave's share, and the longer the
        share, the better the lanes of a wave even out --, fewer for a small call (a piece of a query file: some 10^4 reads, many calls
        side by side on their own streams), down to two reads a lane */
-    const uint64_t max_waves = uint64_t(256) * 4 * (W == 1 ? 5 : 4);  // (what the chip holds of this kernel: 96 registers at k <= 31, 106 at k <= 63)
+    const uint64_t max_waves = uint64_t(256) * 4 * 5;  // (what the chip holds of this kernel: five waves a SIMD, 96 registers)  // (what the chip holds of this kernel: 96 registers at k <= 31, 106 at k <= 63)
     uint64_t waves = std::min<uint64_t>(max_waves, std::max<uint64_t>(1, n_reads / (64 * 2)));
     waves = (waves + 3) / 4 * 4;
     const uint64_t reads_per_wave = (n_reads + waves - 1) / waves;
     const dim3 grid(uint32_t(waves / 4)), block(256);
-    if (d.sk.enabled) hipLaunchKernelGGL((streaming_run_kernel<W, CANON, true>), grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, report);
-    else hipLaunchKernelGGL((streaming_run_kernel<W, CANON, false>), grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, report);
+    const uint32_t move_out_every = uint32_t(test_hook_u64("stream_move_out_every", uint64_t(1) << 16, 1, uint64_t(1) << 16));
+    if (d.sk.enabled) hipLaunchKernelGGL((streaming_run_kernel<W, CANON, true>), grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, move_out_every, report);
+    else hipLaunchKernelGGL((streaming_run_kernel<W, CANON, false>), grid, block, 0, s, d, rep->d_skew, packed, okay, offsets, n_reads, reads_per_wave, move_out_every, report);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -74,6 +74,21 @@ def test_streaming_counters_on_low_complexity_reads(case_name, request):
     assert got == case.oracle.streaming_query(reads)
 
 
+@pytest.mark.parametrize("case_name", ["case_se_regular", "case_k63_canonical"])
+def test_streaming_counters_moved_out_of_their_32_bit_registers(case_name, request, monkeypatch):
+    """Three of the run-based kernel's counters are 32 bits wide in the lanes and moved into 64-bit totals of the wave before they could
+    wrap (every 2^16 turns); SSHASH_AMD_TEST_HOOKS stream_move_out_every=<n> makes that happen every n turns: the report must not change."""
+    case = request.getfixturevalue(case_name)
+    d = case.dict.to_device(0)
+    reads = _synthetic_reads(case, 3000, seed=31)
+    want = case.oracle.streaming_query(reads)
+    assert _as_dict(d.streaming_query(reads)) == want
+    for at in ("1", "7", "300"):
+        monkeypatch.setenv("SSHASH_AMD_TEST_HOOKS", "stream_move_out_every=" + at)
+        assert _as_dict(d.streaming_query(reads)) == want, at
+    monkeypatch.delenv("SSHASH_AMD_TEST_HOOKS")
+
+
 def test_streaming_runs_and_skips_against_hand_made_reads(case_se_regular, case_se_canonical, case_k63_regular):
     """What the run-based kernel decides without looking (streaming.hip): extension runs measured 32 bases a step, forward and
     backward, across word boundaries, up to a string's end and past it; the k-mers behind a miss counted by the slot's say. Reads cut
