@@ -204,6 +204,59 @@ def measure_other_paths(args, index_path, device, d, dq, W, bytes_per_lookup):
                      "hbm_traffic_bytes_per_lookup": round(traffic / m, 2) if traffic else None,
                      "frac_hbm_traffic": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None}
         d2.close()
+    res.update(measure_host_entry_points(d, device, dq, W, ids_of_table_path))
+    return res
+
+
+def measure_host_entry_points(d, device, dq, W, ids_of_device_path, queries=50_000_000):
+    """Side measurement, OUTSIDE the timed region, PCIe INCLUSIVE (never `value`): the entry points a drop-in caller of the reference's
+    `dict.lookup(...)` loop uses (tools/perf.hpp:57,79) -- sshash_lookup_packed and sshash_lookup_ascii on HOST arrays, here page-locked
+    ones (the kernels then read the queries and write the ids where they lie: engine.hip host_lookup), wall clock of the call, ids equal
+    to the device path's. 16 B per lookup cross the link packed (8 in, 8 out), k + 8 as characters."""
+    import torch
+
+    from sshash_amd import _binding as B
+
+    m = min(dq.numel() // W, queries)
+    k = d.k()
+    lib = B._load()
+    want = ids_of_device_path[:m].cpu()
+    q_host = dq[: m * W].cpu().pin_memory()
+    out_host = torch.zeros(m, dtype=torch.int64).pin_memory()
+    res = {}
+
+    def timed(fn, q_ptr):
+        r = B._Results()
+        r.kmer_id = out_host.data_ptr()
+        best = None
+        for i in range(4):  # (the first call sizes pools and maps the arrays)
+            out_host.fill_(7)
+            t0 = time.perf_counter()
+            status = fn(d._h, q_ptr, m, 1, B.C.byref(r))
+            dt = time.perf_counter() - t0
+            B._check(status)
+            if i:
+                best = dt if best is None else min(best, dt)
+        if not torch.equal(out_host, want):
+            raise SystemExit("PARITY FAILURE: a host-buffer entry point and the device path disagree")
+        return best
+
+    t = timed(lib.sshash_lookup_packed, q_host.data_ptr())
+    res["host_packed"] = {"lookups_per_s": round(m / t, 1), "ms": round(t * 1e3, 2), "queries": m, "ids_equal_device_path": True,
+                          "link_GBps_both_directions": round(m * (8 * W + 8) / t / 1e9, 1), "caller_arrays": "page-locked, device-mapped"}
+    # the same queries as characters (include/kmer.hpp:118: A C T G = 0 1 2 3), k bytes each
+    chars = torch.tensor(list(b"ACTG"), dtype=torch.uint8, device=dq.device)
+    sh = torch.arange(k, device=dq.device, dtype=torch.int64)
+    ascii_host = torch.empty((m, k), dtype=torch.uint8).pin_memory()
+    for a in range(0, m, 1 << 22):
+        b = min(m, a + (1 << 22))
+        words = dq[a * W: b * W].view(-1, W)
+        codes = (words[:, (sh >> 5)] >> ((sh & 31) * 2)[None, :]) & 3
+        ascii_host[a:b] = chars[codes].cpu()
+    del q_host
+    t = timed(lib.sshash_lookup_ascii, ascii_host.data_ptr())
+    res["host_ascii"] = {"lookups_per_s": round(m / t, 1), "ms": round(t * 1e3, 2), "queries": m, "ids_equal_device_path": True,
+                         "link_GBps_both_directions": round(m * (k + 8) / t / 1e9, 1), "caller_arrays": "page-locked, device-mapped"}
     return res
 
 
@@ -396,7 +449,7 @@ def streaming_mode(args, d, index_path, rank, world, local_rank, dev, use_dist, 
 
     def step():
         report.zero_()
-        d.streaming_query_device(local_rank, reads.data_ptr(), offsets.data_ptr(), n, report.data_ptr(), stream=stream.cuda_stream)
+        d.streaming_query_device(local_rank, reads.data_ptr(), offsets.data_ptr(), n, report.data_ptr(), stream=stream.cuda_stream, total_bases=n * L)
 
     for _ in range(args.warmup):
         step()
@@ -451,7 +504,7 @@ def streaming_mode(args, d, index_path, rank, world, local_rank, dev, use_dist, 
     want = ora.streaming_query(sample)
     t_oracle = time.perf_counter() - t0
     part = torch.zeros(6, dtype=torch.int64, device=dev)
-    d.streaming_query_device(local_rank, reads.data_ptr(), offsets.data_ptr(), m, part.data_ptr(), stream=stream.cuda_stream)
+    d.streaming_query_device(local_rank, reads.data_ptr(), offsets.data_ptr(), m, part.data_ptr(), stream=stream.cuda_stream, total_bases=m * L)
     torch.cuda.synchronize()
     got = dict(zip(names, (int(v) for v in part.cpu().tolist())))
     if got != {f: int(v) for f, v in want.items()}:
@@ -827,6 +880,9 @@ def main():
                        "ids_equal_oracle_on_queries": sample, "num_bases": d.num_bases(),
                        "queries_per_step": args.queries, "queries_per_gpu": n, "num_kmers": d.num_kmers(), "k": d.k(), "m": d.m(),
                        "canonical": d.canonical(), "index_replicated_per_gpu": sharded is None, "sharded": args.sharded,
+                       # what carries the exchange of a routed lookup: torch.distributed's all_to_all_single over the group's backend -- nccl
+                       # (= RCCL over xGMI) whenever every rank has a GPU of its own; gloo only under the tests' one-device scaffolding
+                       "exchange": (f"all_to_all_single over {backend}" + (" (TEST scaffolding: every rank on one device)" if one_device is not None else "")) if sharded is not None else None,
                        "positive_fraction_found": round(found, 4), "device_index_bytes": d.device_bytes(local_rank),
                        "device_bytes_per_kmer": round(d.device_bytes(local_rank) / d.num_kmers(), 2),
                        "device_stats": stats, "recipe": args.recipe, "repeat_scale": args.repeat_scale,
@@ -919,7 +975,7 @@ def compact_line(full, record_path):
     line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "traffic_key"))
     cfg = full.get("config", {})
     line["config"] = _pick(cfg, ("queries_per_step", "queries_per_gpu", "reads", "read_length", "reads_per_gpu", "num_kmers", "k", "m", "canonical",
-                                 "num_bases", "index_replicated_per_gpu", "sharded", "positive_fraction_found", "positive_fraction_of_kmers", "extensions_per_search",
+                                 "num_bases", "index_replicated_per_gpu", "sharded", "exchange", "positive_fraction_found", "positive_fraction_of_kmers", "extensions_per_search",
                                  "counters_equal_oracle_on_reads", "ids_equal_oracle_on_queries", "device_index_bytes", "device_bytes_per_kmer", "recipe",
                                  "report"))
     line["config"] = {"workload": str(cfg.get("workload_short") or cfg.get("workload", ""))[:400], **line["config"]}
@@ -931,7 +987,7 @@ def compact_line(full, record_path):
     if full.get("other_mixes"):
         line["other_mixes"] = {k: v.get("lookups_per_s") for k, v in full["other_mixes"].items()}
     if full.get("other_paths"):
-        line["other_paths"] = {k: _pick(v, ("lookups_per_s", "roofline_frac", "ids_equal_table_path", "hbm_traffic_bytes_per_lookup")) for k, v in full["other_paths"].items()}
+        line["other_paths"] = {k: _pick(v, ("lookups_per_s", "roofline_frac", "ids_equal_table_path", "hbm_traffic_bytes_per_lookup", "ids_equal_device_path", "link_GBps_both_directions")) for k, v in full["other_paths"].items()}
     f = full.get("streaming_from_file")
     if f:
         line["streaming_from_file"] = {fl: {"ns_per_kmer": f[fl]["ns_per_kmer"]} for fl in ("fastq", "fastq.gz", "bgzf.fastq.gz") if fl in f}

@@ -226,12 +226,13 @@ sshash_status sshash_streaming_query_from_file(const sshash_dict* d, const char*
 /* reads stored back to back: read r = bases[read_offsets[r] .. read_offsets[r+1]) ; host buffers */
 sshash_status sshash_streaming_query(const sshash_dict* d, const char* bases, const uint64_t* read_offsets,
                                      uint64_t num_reads, sshash_streaming_report* report);
-/* device buffers; `report` is a device pointer to 6 uint64 counters, accumulated into. The kernels are enqueued on `hip_stream`; before
- * that the call reads read_offsets[num_reads] back (8 bytes: the size of the 2-bit packed copy of the reads it makes) and so waits for
- * what the stream holds at that moment -- the one synchronisation of this entry point. */
+/* device buffers; `report` is a device pointer to 6 uint64 counters, accumulated into. `total_bases` = read_offsets[num_reads] (as
+ * sshash_streaming_lookup_device takes it): the size of the 2-bit packed copy of the reads the call makes in scratch the replica keeps
+ * per stream. With it the call only enqueues work on `hip_stream` and returns. 0 = "not known to the caller": the call then reads
+ * read_offsets[num_reads] back (8 bytes) and so waits for what the stream holds at that moment -- its one synchronisation. */
 sshash_status sshash_streaming_query_device(const sshash_dict* d, int device, const char* bases,
-                                            const uint64_t* read_offsets, uint64_t num_reads, uint64_t* report,
-                                            void* hip_stream);
+                                            const uint64_t* read_offsets, uint64_t num_reads, uint64_t total_bases,
+                                            uint64_t* report, void* hip_stream);
 
 /* ---- streaming_query<Dict,canonical>::lookup for EVERY k-mer of every read (include/streaming_query.hpp:56-109),
  *      batched: what the reference returns k-mer by k-mer while it streams a read. Every non-NULL array of `out` has one
@@ -281,7 +282,10 @@ sshash_status sshash_route_combine_device(const sshash_dict* d, int device, cons
  *      receives the n ids, identical to the unpartitioned dictionary's. The one step that needs communication is handed
  *      in as two callbacks (return 0 on success):
  *        counts  all-to-all of ONE uint64 per peer: send[p] goes to rank p, recv[p] comes from rank p (host arrays of
- *                num_ranks entries);
+ *                num_ranks entries). The words are opaque to the callback: the library carries the length of its table keys in
+ *                their top byte, so that ranks built under different SSHASH_AMD_SK_M refuse to work together (SSHASH_ERR_ARGUMENT
+ *                on every rank, after this exchange and before the data exchange) -- in the same exchange on every call, so no rank
+ *                ever runs a collective step its peers skip;
  *        data    all-to-all-v of DEVICE buffers: the block for rank p starts after the blocks of the ranks before it,
  *                send_counts[p] / recv_counts[p] elements of elem_bytes each (host arrays); it must be complete, or ordered
  *                on hip_stream, when it returns.

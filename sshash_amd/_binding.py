@@ -173,7 +173,7 @@ def _load() -> C.CDLL:
         "sshash_access_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, P, P]),
         "sshash_streaming_query_from_file": (C.c_int, [P, C.c_char_p, C.c_int, C.POINTER(_Report)]),
         "sshash_streaming_query": (C.c_int, [P, P, P, C.c_uint64, C.POINTER(_Report)]),
-        "sshash_streaming_query_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, P, P]),
+        "sshash_streaming_query_device": (C.c_int, [P, C.c_int, P, P, C.c_uint64, C.c_uint64, P, P]),
         "sshash_route_packed_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_uint32, P, P, P]),
         "sshash_route_bucket_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_uint32, C.c_int, P, P, P, P]),
         "sshash_route_bucket_by_key_device": (C.c_int, [P, C.c_int, P, C.c_uint64, C.c_uint32, P, P, P, P]),
@@ -652,6 +652,8 @@ class Dictionary:
                                                       int(num_reads), int(total_bases), C.byref(r), C.c_void_p(d_report), C.c_void_p(stream)))
 
     def streaming_query_device(self, device: int, d_bases: int, d_read_offsets: int, num_reads: int, d_report: int,
-                               stream: int = 0) -> None:
+                               stream: int = 0, total_bases: int = 0) -> None:
+        """`total_bases` = read_offsets[num_reads] when the caller knows it: the call then only enqueues work (0: it reads the
+        eight bytes back and waits for the stream first)."""
         _check(_load().sshash_streaming_query_device(self._h, int(device), C.c_void_p(d_bases), C.c_void_p(d_read_offsets),
-                                                     int(num_reads), C.c_void_p(d_report), C.c_void_p(stream)))
+                                                     int(num_reads), int(total_bases), C.c_void_p(d_report), C.c_void_p(stream)))

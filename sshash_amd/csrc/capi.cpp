@@ -38,6 +38,7 @@ sshash_status classify(std::exception const& e) {
 template <typename Fn>
 sshash_status guarded(Fn&& fn) {
     try {
+        test_hooks_refresh();  // (hooks.hpp: the environment is read here, on the caller's thread, never by the library's own threads)
         fn();
         return SSHASH_OK;
     } catch (std::exception const& e) { return classify(e); } catch (...) {
@@ -455,10 +456,10 @@ sshash_status sshash_streaming_query(const sshash_dict* d, const char* bases, co
 }
 
 sshash_status sshash_streaming_query_device(const sshash_dict* d, int device, const char* bases,
-                                            const uint64_t* read_offsets, uint64_t num_reads, uint64_t* report,
-                                            void* hip_stream) {
+                                            const uint64_t* read_offsets, uint64_t num_reads, uint64_t total_bases,
+                                            uint64_t* report, void* hip_stream) {
     if (!d || !report || (num_reads && (!bases || !read_offsets))) return fail(SSHASH_ERR_ARGUMENT, "null argument");
-    return guarded([&] { d->eng->streaming_query_device(device, bases, read_offsets, num_reads, 0, report, hip_stream); });
+    return guarded([&] { d->eng->streaming_query_device(device, bases, read_offsets, num_reads, total_bases, report, hip_stream); });
 }
 
 static void fill_report(sshash_streaming_report* report, streaming_report const& r) {

@@ -1463,6 +1463,91 @@ static void host_lookup(engine const& eng, std::vector<int> const& devs, void co
                    (!plan.wanted[4] || pinned(h_out.string_begin, n * 8)) && (!plan.wanted[5] || pinned(h_out.string_end, n * 8)) &&
                    (!plan.wanted[6] || pinned(h_out.kmer_orientation, n)) && (!plan.wanted[7] || pinned(h_out.minimizer_found, n));
 
+    /* Page-locked caller arrays that the devices can address (hipHostMalloc'ed, or registered with hipHostRegisterMapped): the KERNELS read
+       the queries and write the results where they lie -- no copy engine, no staging block, no chunk. A copy pipeline moves a chunk in,
+       runs the kernels, moves the results out, and what it achieved on this box was both directions together at the rate of one
+       (47-52 GB/s, 2.9-3.2 G lookups/s: profiles/r05/host_buffer_entry_point_pcie_inclusive.txt); a kernel's coalesced query loads and
+       id stores travel in both directions of the link at once by themselves, and the batch is one launch sequence per device, as on
+       device buffers. (tests: host_staged_copies=1 keeps the copy pipeline below, which arrays that are page-locked but not
+       mapped take anyway.) */
+    if (in_place && !test_hook_u64("host_staged_copies", 0, 0, 1)) {
+        struct mapped_share {
+            void const* in = nullptr;
+            result_view out{};
+            uint8_t* member = nullptr;
+        };
+        std::vector<mapped_share> mapped(G);
+        bool all_mapped = true;
+        int before = 0;
+        HIP_CHECK(hipGetDevice(&before));
+        for (uint64_t g = 0; g < G && all_mapped; ++g) {
+            HIP_CHECK(hipSetDevice(devs[g]));
+            auto device_address = [&](auto* p) -> decltype(p) {
+                if (!p) return nullptr;
+                void* dptr = nullptr;
+                if (hipHostGetDevicePointer(&dptr, const_cast<void*>(static_cast<void const*>(p)), 0) != hipSuccess || !dptr) {
+                    (void)hipGetLastError();
+                    all_mapped = false;
+                    return nullptr;
+                }
+                return static_cast<decltype(p)>(dptr);
+            };
+            const uint64_t lo = shares[g].lo;
+            mapped_share& ms = mapped[g];
+            if (char const* in = device_address(static_cast<char const*>(h_in))) ms.in = in + lo * bytes_per_query;
+            if (mode == out_mode::member) {
+                if (uint8_t* q = device_address(h_member)) ms.member = q + lo;
+            } else {
+                auto place = [&](auto* host, bool wanted) -> decltype(host) {
+                    if (!wanted) return nullptr;
+                    auto* q = device_address(host);
+                    return q ? q + lo : nullptr;
+                };
+                ms.out.kmer_id = place(h_out.kmer_id, true);
+                ms.out.kmer_id_in_string = place(h_out.kmer_id_in_string, plan.wanted[1]);
+                ms.out.kmer_offset = place(h_out.kmer_offset, plan.wanted[2]);
+                ms.out.string_id = place(h_out.string_id, plan.wanted[3]);
+                ms.out.string_begin = place(h_out.string_begin, plan.wanted[4]);
+                ms.out.string_end = place(h_out.string_end, plan.wanted[5]);
+                ms.out.kmer_orientation = place(h_out.kmer_orientation, plan.wanted[6]);
+                ms.out.minimizer_found = place(h_out.minimizer_found, plan.wanted[7]);
+            }
+        }
+        (void)hipSetDevice(before);
+        if (all_mapped) {
+            std::vector<std::exception_ptr> failed(G);
+            auto run_device = [&](uint64_t g) {
+                try {
+                    const uint64_t m = shares[g].hi - shares[g].lo;
+                    if (m == 0) return;
+                    device_replica const* rep = eng.replica(devs[g]);
+                    HIP_CHECK(hipSetDevice(devs[g]));
+                    host_lane* lane = rep->acquire_lane(0);  // (for its stream)
+                    struct give_back {
+                        device_replica const* rep;
+                        host_lane* lane;
+                        ~give_back() { rep->release_lane(lane); }
+                    } guard{rep, lane};
+                    mapped_share const& ms = mapped[g];
+                    if (ASCII) eng.lookup_ascii_device(devs[g], static_cast<char const*>(ms.in), m, check_rc, mode, ms.out, ms.member, lane->stream);
+                    else eng.lookup_packed_device(devs[g], static_cast<uint64_t const*>(ms.in), m, check_rc, mode, ms.out, ms.member, lane->stream);
+                    HIP_CHECK(hipStreamSynchronize(lane->stream));
+                } catch (...) { failed[g] = std::current_exception(); }
+            };
+            if (G == 1) {
+                run_device(0);
+            } else {
+                std::vector<std::thread> workers;
+                for (uint64_t g = 0; g < G; ++g) workers.emplace_back(run_device, g);
+                for (auto& w : workers) w.join();
+            }
+            (void)hipSetDevice(before);
+            for (auto const& e : failed)
+                if (e) std::rethrow_exception(e);
+            return;
+        }
+    }
+
     auto run_lane = [&](size_t li) {
         try {
             const uint64_t g = lanes[li].first;

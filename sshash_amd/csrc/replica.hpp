@@ -54,8 +54,6 @@ struct device_replica {
     uint64_t directory_entries = 0;     // keys resident in the directory
     uint64_t sk_keys = 0, sk_heavy_keys = 0, sk_heavy_kmers = 0, sk_unplaced = 0, sk_slots_used = 0, sk_bytes = 0;  // super-k-mer table
     uint32_t sk_absent_reason = 1;  // SK_ABSENT_* (0 = the table is there)
-    /* sharded lookups (sharded.cpp): the number of ranks this replica has compared its table key length with (0: not yet) */
-    mutable std::atomic<uint32_t> peers_share_table_key{0};
     /* keys of the table by number of occurrences (bins SK_HIST_BINS: 1, 2, 3, 4, 5-8, 9-16, 17-64, 65-1024, > 1024):
        [0..9) keys per bin, [9..18) occurrences (= super-k-mers) per bin; [18] super-k-mers, [19] slots asked for */
     uint64_t sk_histogram[20] = {0};
@@ -160,6 +158,48 @@ struct device_replica {
         return slot;
     }
 
+    /* Per-stream scratch of the streaming query (streaming.hip: the 2-bit packed copy of a call's reads and their validity bits).
+       Round 5 took it from the pool above and gave it back at every call -- two stream-ordered allocations of ~0.4 GB each per call
+       of 3 x 10^9 bases, on the host side of a step that the device then waits for (profiles/r06/). Kept per stream instead: calls
+       on one stream are ordered, so the block is reused without synchronisation and only grows (hipFree of the old block
+       synchronises). An application that makes a stream per request does not keep a block per stream it ever used: the least
+       recently used ones go once more than READ_SCRATCH_STREAMS_MAX streams or READ_SCRATCH_BYTES_MAX bytes are held. */
+    struct read_scratch {
+        void* block = nullptr;
+        size_t bytes = 0;
+        uint64_t last_use = 0;
+    };
+    mutable std::unordered_map<void*, read_scratch> read_scratches;
+    static constexpr size_t READ_SCRATCH_STREAMS_MAX = 64;  // (the file query runs up to 32 lanes, each on its own stream)
+    static constexpr size_t READ_SCRATCH_BYTES_MAX = size_t(8) << 30;
+    void* read_scratch_for(void* stream, size_t bytes) const {
+        std::lock_guard<std::mutex> lock(scratch_mutex);
+        auto it = read_scratches.find(stream);
+        if (it == read_scratches.end()) it = read_scratches.emplace(stream, read_scratch{}).first;
+        read_scratch& slot = it->second;
+        slot.last_use = ++scratch_clock;
+        if (slot.bytes < bytes) {
+            if (slot.block) HIP_CHECK(hipFree(slot.block));  // (synchronises: nothing in flight still reads it)
+            slot.block = nullptr;
+            slot.bytes = 0;
+            const size_t want = bytes + bytes / 8 + 4096;
+            size_t held = want;
+            for (auto const& kv : read_scratches) held += kv.second.bytes;
+            while (read_scratches.size() > 1 && (read_scratches.size() > READ_SCRATCH_STREAMS_MAX || held > READ_SCRATCH_BYTES_MAX)) {
+                auto oldest = read_scratches.end();
+                for (auto jt = read_scratches.begin(); jt != read_scratches.end(); ++jt)
+                    if (jt != it && (oldest == read_scratches.end() || jt->second.last_use < oldest->second.last_use)) oldest = jt;
+                if (oldest == read_scratches.end()) break;
+                if (oldest->second.block) (void)hipFree(oldest->second.block);
+                held -= oldest->second.bytes;
+                read_scratches.erase(oldest);
+            }
+            HIP_CHECK(hipMalloc(&slot.block, want));
+            slot.bytes = want;
+        }
+        return slot.block;
+    }
+
     /* pooled lanes of the host-buffer path */
     mutable std::mutex lanes_mutex;
     mutable std::vector<host_lane*> idle_lanes;
@@ -197,6 +237,8 @@ struct device_replica {
             (void)hipMemPoolDestroy(scratch_pool);
         }
         for (auto& kv : scratch) kv.second.release();
+        for (auto& kv : read_scratches)
+            if (kv.second.block) (void)hipFree(kv.second.block);
         for (host_lane* lane : idle_lanes) {
             if (lane->pinned) (void)hipHostFree(lane->pinned);
             if (lane->device) (void)hipFree(lane->device);

@@ -50,21 +50,6 @@ void engine::sharded_lookup_device(int device, uint32_t num_ranks, bool by_table
     const uint32_t W = rep->view.k <= 31 ? 1 : 2, R = num_ranks;
     stream_buffers buf{s, rep, {}};
 
-    /* 0. (first call of this replica with this many ranks) every rank elects table keys of the same length: the length steers which
-       rank owns a key (route_bucket_kernel BY_KEY, sk_owner) and is read from the environment when a replica is built
-       (SSHASH_AMD_SK_M: sktable.hip), so ranks started under different environments would route keys to ranks that do not hold
-       them -- complete-path fallbacks at best, misses on table shards -- with nothing to show for it. One more
-       exchange of R words, once. */
-    if (by_table_key && rep->peers_share_table_key.load() != R) {
-        std::vector<uint64_t> mine(R, uint64_t(rep->view.sk.m)), theirs(R, 0);
-        call(x.counts(x.ctx, mine.data(), theirs.data()), "table key length");
-        for (uint32_t r = 0; r < R; ++r)
-            if (theirs[r] != mine[r])
-                throw error(error_kind::argument, "sharded lookup: rank " + std::to_string(r) + " elects table keys of " + std::to_string(theirs[r]) +
-                                                      " bases, this rank of " + std::to_string(mine[r]) + " (SSHASH_AMD_SK_M must be the same on every rank)");
-        rep->peers_share_table_key.store(R);
-    }
-
     /* 1. route: messages per owner, then the messages themselves in per-owner regions (engine.hip: route_bucket_kernel) */
     uint64_t* d_cursors = buf.get<uint64_t>(R);
     HIP_CHECK(hipMemsetAsync(d_cursors, 0, R * sizeof(uint64_t), s));
@@ -80,8 +65,29 @@ void engine::sharded_lookup_device(int device, uint32_t num_ranks, bool by_table
     uint32_t* d_slots = buf.get<uint32_t>(total);
     route_bucket_device(device, d_kmers, n, R, check_rc, by_table_key, d_cursors, d_send, d_slots, s, d_owners);
 
-    /* 2. exchange: one packed k-mer per message */
-    call(x.counts(x.ctx, send_counts.data(), recv_counts.data()), "count");
+    /* 2. exchange: one packed k-mer per message. Every rank must elect table keys of the same length: the length steers which rank owns
+       a key (route_bucket_kernel BY_KEY, sk_owner) and is read from the environment when a replica is built (SSHASH_AMD_SK_M:
+       sktable.hip), so ranks started under different environments would route keys to ranks that do not hold them -- complete-path
+       fallbacks at best, misses on table shards -- with nothing to show for it. The length travels in the top byte of
+       every count of THIS exchange, on every call: round 5 compared it in an exchange of its own that a rank ran or skipped by its
+       local state, so a rank with a fresh replica paired its key-length exchange with its peers' count exchange. */
+    constexpr uint32_t KEY_SHIFT = 56;
+    const uint64_t my_key = by_table_key ? uint64_t(rep->view.sk.m) & 0xFFu : 0;
+    {
+        std::vector<uint64_t> tagged(send_counts);
+        for (uint64_t& c : tagged) {
+            if (c >> KEY_SHIFT) throw error(error_kind::argument, "sharded lookup: more than 2^56 messages for one rank");
+            c |= my_key << KEY_SHIFT;
+        }
+        call(x.counts(x.ctx, tagged.data(), recv_counts.data()), "count");
+    }
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint64_t their_key = recv_counts[r] >> KEY_SHIFT;
+        recv_counts[r] &= (uint64_t(1) << KEY_SHIFT) - 1;
+        if (their_key != my_key)
+            throw error(error_kind::argument, "sharded lookup: rank " + std::to_string(r) + " elects table keys of " + std::to_string(their_key) +
+                                                  " bases, this rank of " + std::to_string(my_key) + " (SSHASH_AMD_SK_M must be the same on every rank, and every rank must shard the same way)");
+    }
     const uint64_t m = std::accumulate(recv_counts.begin(), recv_counts.end(), uint64_t(0));
     uint64_t* d_recv = buf.get<uint64_t>(m * W);
     call(x.data(x.ctx, d_send, send_counts.data(), d_recv, recv_counts.data(), W * 8, stream), "k-mer");

@@ -157,6 +157,20 @@ __device__ __forceinline__ uint64_t first_invalid_base(const uint64_t* __restric
     return p < end ? p : end;
 }
 
+/* first valid base in [from, end), or `end` */
+__device__ __forceinline__ uint64_t first_valid_base(const uint64_t* __restrict__ okay, uint64_t from, uint64_t end) {
+    uint64_t p = from;
+    while (p < end) {
+        const uint64_t good = okay[p >> 6] >> (p & 63u);
+        if (good) {
+            p += uint64_t(__builtin_ctzll(good));
+            break;
+        }
+        p = (p | 63u) + 1;
+    }
+    return p < end ? p : end;
+}
+
 /* the 32 bases of the packed reads starting at base p */
 __device__ __forceinline__ uint64_t read_bases32(const uint64_t* __restrict__ packed, uint64_t p) {
     const uint64_t i = p >> 5;
@@ -207,7 +221,7 @@ __device__ __forceinline__ run_step_t run_step_load(dict_view const& d, const ui
    the last of them moved to place 31, reversed and complemented: place i = comp(S[top - 1 - i]) -- against the read's, up to the first
    mark that stops the run -- bit 31 - i of `gate` stops extension i; backward the mark of base top - i: marks bit (have - i) */
 __device__ __forceinline__ uint32_t run_step_length(run_step_t const& t, bool forward) {
-    const uint64_t along = forward ? t.s : revcomp_word(t.s << (2 * (32 - t.have)));
+    const uint64_t along = forward ? t.s : revcomp_word(t.s << ((2 * (32 - t.have)) & 63u));  // (have = 0: a shift by 64 is not one; the step is min(., have) = 0 whatever this gives)
     const uint64_t diff = along ^ t.read;
     const uint32_t same = diff ? uint32_t(__builtin_ctzll(diff)) >> 1 : 32u;
     const uint32_t gate = forward ? uint32_t(__brev(uint32_t(t.marks))) : uint32_t((t.marks >> 1) << (32 - t.have));
@@ -274,7 +288,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
     uint32_t where = 0;
     uint32_t turns = 0;
     for (;;) {
-        if (++turns >= move_out_every) {  // (scalar: a turn adds at most k + 21 to a counter, 2^16 turns some millions)
+        if (++turns >= move_out_every) {  // (scalar; a turn adds less than 2^15 to a lane's counter -- a longer run of extensions or of invalid k-mers goes to the wave's 64-bit totals at once --, so 2^16 turns stay below 2^31)
             turns = 0;
             const uint64_t i = wave_sum(c_invalid), n = wave_sum(c_negative), f = wave_sum(c_searches), e = wave_sum(c_extensions);
             if (lane == 0) {
@@ -303,15 +317,25 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
         }
         bool live = cur + k <= rd_end;
         if (next >= last && __ballot(live) == 0) break;
-        /* -- the k-mers over an invalid base: all invalid (streaming_query.hpp:59-65), counted and skipped -- */
+        /* -- the k-mers over an invalid base: all invalid (streaming_query.hpp:59-65), counted and skipped -- a whole RUN of invalid
+              bases a step: every k-mer that starts at or before the run's last base holds one of them (those from `cur` on reach
+              `inv`: cur + k > inv). (Round 5 advanced one invalid base per iteration, each with a dependent load, the other 63 lanes
+              waiting: a read with a long run of N was a cliff) -- */
+        uint32_t c_invalid_turn = 0;
         while (live && cur + k > inv) {
-            const uint64_t last_over_it = inv < rd_end - k ? inv : rd_end - k;
-            c_invalid += last_over_it - cur + 1;
-            cur = inv + 1;
-            inv = first_invalid_base(okay, cur < rd_end ? cur : rd_end, rd_end);
+            const uint64_t nv = first_valid_base(okay, inv + 1, rd_end);  // the run of invalid bases is [inv, nv)
+            const uint64_t last_over_it = nv - 1 < rd_end - k ? nv - 1 : rd_end - k;
+            const uint64_t over = last_over_it - cur + 1;
+            /* (a turn may add 2^15 - 1 to a lane's 32-bit counter and no more -- 2^16 turns lie between two move-outs --; this loop
+               can cross a whole read in one turn, so what it adds is bounded by the loop's own sum, kept here) */
+            if ((over + c_invalid_turn) >> 15) atomicAdd(wave_moved_out + 0, (unsigned long long)over);
+            else c_invalid_turn += uint32_t(over);
+            cur = nv;
+            inv = first_invalid_base(okay, nv, rd_end);
             neg_unknown_mini = false;
             live = cur + k <= rd_end;
         }
+        c_invalid += c_invalid_turn;
         const uint64_t valid_end = inv < rd_end ? inv : rd_end;
         /* -- this turn's event of the lane: the run behind the hit of the turn before, or a seed -- */
         /* (the run's first 32 bases are asked for here and looked at behind the seeds' part of the turn: the strings' atom is a line
@@ -448,7 +472,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
         if (extending) {
             if constexpr (W == 2) first_step = run_step_load<W>(d, packed, off, ori > 0, cur + k - 1, 0);
             const uint64_t run = extend_run<W>(d, packed, off, ori, cur + k - 1, valid_end - (cur + k - 1), first_step);
-            if (run >> 30) atomicAdd(wave_moved_out + 3, (unsigned long long)run);  // (a run of a gigabase: past what the lane's counter may take in one turn)
+            if (run >> 15) atomicAdd(wave_moved_out + 3, (unsigned long long)run);  // (past what the lane's 32-bit counter may take in one turn: 2^16 turns lie between two move-outs)
             else c_extensions += uint32_t(run);
             cur += run;
         }
@@ -491,18 +515,11 @@ void launch_streaming_runs(device_replica const* rep, dict_view const& d, char c
     /* two bits and a validity bit a base, in words of 32 and 64 bases; three words of slack behind the last base (a seed and a
        run read up to two words past their first) */
     const uint64_t packed_bytes = ((total_bases + 31) / 32 + 3) * 8, okay_bytes = ((total_bases + 63) / 64 + 2) * 8;
-    struct temporaries {
-        hipStream_t s;
-        void* p[2];
-        ~temporaries() {
-            for (void* q : p)
-                if (q) (void)hipFreeAsync(q, s);
-        }
-    } tmp{s, {nullptr, nullptr}};
-    tmp.p[0] = rep->stream_alloc(packed_bytes, s);
-    tmp.p[1] = rep->stream_alloc(okay_bytes, s);
-    uint64_t* packed = static_cast<uint64_t*>(tmp.p[0]);
-    uint64_t* okay = static_cast<uint64_t*>(tmp.p[1]);
+    /* (scratch the replica keeps for this stream, replica.hpp; two host threads that share a stream must not interleave their
+       launch sequences, which share it) */
+    std::lock_guard<std::mutex> sequence(rep->launch_mutex);
+    uint64_t* packed = static_cast<uint64_t*>(rep->read_scratch_for(s, packed_bytes + okay_bytes));
+    uint64_t* okay = packed + packed_bytes / 8;
     if (total_bases) {
         const uint64_t lanes = (total_bases + 7) / 8;
         hipLaunchKernelGGL(stream_pack_kernel, dim3(uint32_t((lanes + 255) / 256)), dim3(256), 0, s, bases, total_bases,

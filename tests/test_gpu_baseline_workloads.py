@@ -174,34 +174,39 @@ def test_streaming_query_at_the_read_count_of_config_c4(synthetic_case):
     assert (summed == whole).all()
 
 
-def full_size_dictionary(workload):
-    """the dictionary bench.py indexes for `workload` (built here, or taken from the bench's cache) and the index file it came from"""
+def full_size_dictionary(workload, canonical=False):
+    """the dictionary bench.py indexes for `workload` (`--canonical`: its canonical flavour) -- built here, or taken from the bench's
+    cache -- and the index file it came from"""
     import bench
     from sshash_amd.repeats import load_recipe
 
     bases, recipe, _, _ = bench.WORKLOADS[workload]
     r = load_recipe(recipe)
-    args = argparse.Namespace(bases=bases, k=int(r["k"]), m=int(r["m"]), recipe=recipe, repeat_scale=1.0, canonical=False, seed=0x5555AAAA,
+    args = argparse.Namespace(bases=bases, k=int(r["k"]), m=int(r["m"]), recipe=recipe, repeat_scale=1.0, canonical=canonical, seed=0x5555AAAA,
                               cache_dir=os.environ.get("SSHASH_BENCH_CACHE", "/tmp"), verbose=False)
     d, path = bench.get_index(args, 0, 1, lambda: None)
     d.to_device(0)
     return d, path, args
 
 
-@pytest.mark.parametrize("workload,least_kmers", [("c3", 2_400_000_000), ("c2", 850_000_000), ("c4", 2_600_000_000)])
-def test_full_size_dictionary_properties(workload, least_kmers):
+@pytest.mark.parametrize("workload,canonical,least_kmers", [("c3", False, 2_400_000_000), ("c2", False, 850_000_000), ("c4", False, 2_600_000_000),
+                                                            ("c3", True, 2_400_000_000), ("c4", True, 2_600_000_000)],
+                         ids=["c3", "c2", "c4", "c3_canonical", "c4_canonical"])
+def test_full_size_dictionary_properties(workload, canonical, least_kmers):
     """BASELINE.json configs[2], [1] and [3] at FULL size -- the very dictionaries bench.py measures (C3: human scale k = 31, C2: S. enterica
-    pangenome scale, C4: human scale k = 63, two-word k-mers): 10^8 strided ids (5 x 10^7 at k = 63): lookup(access(id)) == id on both
-    strands (test/check.hpp:29-49), is_member, two launches identical, 10^8 random negatives all absent (:78-96) -- and the CPU oracle
-    over 10^6 queries of the bench's own 50/50 mix, read from the index file on disk."""
+    pangenome scale, C4: human scale k = 63, two-word k-mers; C3 and C4 also as CANONICAL dictionaries, src/dictionary.cpp:24-56, the flavour
+    the reference publishes beside the regular one: benchmarks/results-21-01-26/k31/canon-bench.json): 10^8 strided ids (5 x 10^7 at k = 63):
+    lookup(access(id)) == id on both strands with the orientation the strand implies -- +1 for the k-mer as the strings spell it, -1 for its
+    reverse complement (test/check.hpp:29-49, test/check_from_file.hpp:100-116) --, is_member, two launches identical, 10^8 random negatives
+    all absent (:78-96) -- and the CPU oracle over 10^6 queries of the bench's own 50/50 mix, read from the index file on disk."""
     import torch
 
     from oracle import oracle as O
     from sshash_amd.synthetic import draw_queries_device, revcomp_device
 
-    d, path, args = full_size_dictionary(workload)
+    d, path, args = full_size_dictionary(workload, canonical)
     k, W = args.k, 1 if args.k <= 31 else 2
-    assert d.num_kmers() > least_kmers and d.k() == k
+    assert d.num_kmers() > least_kmers and d.k() == k and bool(d.canonical()) == canonical
     stats = d.device_stats(0)
     assert stats["sk_slots"] > 0, "the full-size dictionaries must be served by the super-k-mer table"
     dev = torch.device("cuda", 0)
@@ -213,14 +218,17 @@ def test_full_size_dictionary_properties(workload, least_kmers):
     out = torch.empty(n, dtype=torch.int64, device=dev)
     again = torch.empty(n, dtype=torch.int64, device=dev)
     member = torch.empty(n, dtype=torch.uint8, device=dev)
-    for qq in (q, revcomp_device(q, k).contiguous()):
+    orientation = torch.empty(n, dtype=torch.int8, device=dev)
+    for strand, qq in ((1, q), (-1, revcomp_device(q, k).contiguous())):
         d.lookup_device(0, qq.data_ptr(), n, out.data_ptr())
-        d.lookup_device(0, qq.data_ptr(), n, again.data_ptr())
+        d.lookup_device(0, qq.data_ptr(), n, again.data_ptr(), kmer_orientation=orientation.data_ptr())
         d.is_member_device(0, qq.data_ptr(), n, member.data_ptr())
         torch.cuda.synchronize()
         assert int((out != ids).sum().item()) == 0
         assert torch.equal(out, again)
+        assert int((orientation != strand).sum().item()) == 0
         assert int((member != 1).sum().item()) == 0
+    del orientation
     del again, member
     g = torch.Generator(device=dev)
     g.manual_seed(11)

@@ -65,7 +65,7 @@ def run_bench(extra, env_extra, tmp_path):
 
 def test_one_gpu_line_carries_the_contract(tmp_path):
     line, r = run_bench([], {}, tmp_path)
-    assert set(line["other_mixes"]) == set(r["other_mixes"]) and set(line["other_paths"]) == {"directory", "mphf"}
+    assert set(line["other_mixes"]) == set(r["other_mixes"]) and set(line["other_paths"]) == {"directory", "mphf", "host_packed", "host_ascii"}
     assert line["streaming_from_file"]["fastq"]["ns_per_kmer"] == r["streaming_from_file"]["fastq"]["ns_per_kmer"]
     assert r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "strong" and r["higher_is_better"] is True
     assert r["vs_baseline"] is None and r["data"] == "synthetic" and r["dtype"] == "u64"
@@ -84,7 +84,11 @@ def test_one_gpu_line_carries_the_contract(tmp_path):
     hist = r["config"]["table_histogram"]
     assert sum(hist["keys_by_occurrences"].values()) == r["config"]["device_stats"]["sk_keys"]
     assert sum(hist["super_kmers_by_occurrences_of_their_key"].values()) == hist["super_kmers"]
-    assert set(r["other_paths"]) == {"directory", "mphf"} and all(v["ids_equal_table_path"] and v["lookups_per_s"] > 0 for v in r["other_paths"].values())
+    paths = r["other_paths"]
+    assert set(paths) == {"directory", "mphf", "host_packed", "host_ascii"} and all(v["lookups_per_s"] > 0 for v in paths.values())
+    assert paths["directory"]["ids_equal_table_path"] and paths["mphf"]["ids_equal_table_path"]
+    # round 6: the host-buffer entry points (PCIe inclusive, page-locked caller arrays), ids equal the device path's
+    assert paths["host_packed"]["ids_equal_device_path"] and paths["host_ascii"]["ids_equal_device_path"] and line["other_paths"]["host_packed"]["link_GBps_both_directions"] > 0
     f = r["streaming_from_file"]
     assert f["counters_equal_oracle_on_sample"] is True and f["kmers"] == 200000 * 120
     for flavour in ("fastq", "fastq.gz", "bgzf.fastq.gz"):
@@ -120,6 +124,39 @@ def test_two_ranks_route_one_batch_over_a_partitioned_dictionary(how, tmp_path):
     assert sum(p["queries"] for p in r["per_rank"]) == 4000000 and abs(r["config"]["positive_fraction_found"] - 0.5) < 0.01
 
 
+@pytest.mark.parametrize("mode", ["lookup", "streaming", "sharded_table", "sharded_minimizer"])
+def test_eight_ranks_rehearsal(mode, tmp_path):
+    """The driver's `bench.py --gpus 8` before an 8-GPU node ever runs it (round 6): eight self-launched ranks on the ONE device of
+    the test box, coordination over gloo -- rendezvous, per-rank seeds, the share arithmetic (4000003 queries / 400001 reads do not
+    divide by eight), the MAX over the ranks, the gather of the per-rank numbers, and for the routed modes the group size of the
+    all-to-all. What it cannot show is RCCL itself: with a GPU per rank the same code takes `nccl` (asserted on the line's `exchange`)."""
+    env = {"SSHASH_BENCH_TEST_ALL_RANKS_ON_DEVICE": "0"}
+    small = ["--workload", "c2", "--bases", "12000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-line-probe", "--gpus", "8"]
+    if mode == "streaming":
+        line, r = run(small + ["--streaming", "--reads", "400001", "--stream-oracle-reads", "2000"], env, tmp_path)
+        assert r["n_gpus"] == 8 and len(r["per_rank"]) == 8 and [p["rank"] for p in r["per_rank"]] == list(range(8))
+        assert sum(p["reads"] for p in r["per_rank"]) == 400001 and max(p["reads"] for p in r["per_rank"]) - min(p["reads"] for p in r["per_rank"]) <= 1
+        rep = r["config"]["report"]
+        assert rep["num_kmers"] == 400001 * (150 - 31 + 1) == sum(p["report"][0] for p in r["per_rank"])
+        assert [sum(p["report"][i] for p in r["per_rank"]) for i in range(6)] == list(rep.values())
+        assert len({tuple(p["report"]) for p in r["per_rank"]}) == 8  # every rank drew its own reads (per-rank seeds)
+    else:
+        extra = {"lookup": [], "sharded_table": ["--sharded", "table"], "sharded_minimizer": ["--sharded", "minimizer"]}[mode]
+        line, r = run(small + ["--queries", "4000003"] + extra, env, tmp_path)
+        assert r["n_gpus"] == 8 and len(r["per_rank"]) == 8 and [p["rank"] for p in r["per_rank"]] == list(range(8))
+        assert sum(p["queries"] for p in r["per_rank"]) == r["config"]["queries_per_step"] == 4000003
+        assert max(p["queries"] for p in r["per_rank"]) - min(p["queries"] for p in r["per_rank"]) <= 1
+        assert abs(r["config"]["positive_fraction_found"] - 0.5) < 0.01  # (ids are checked against the oracle inside bench.py)
+        if mode == "lookup":
+            assert r["config"]["index_replicated_per_gpu"] is True and r["config"]["exchange"] is None
+        else:
+            assert r["config"]["index_replicated_per_gpu"] is False and r["config"]["sharded"] == extra[1]
+            assert r["config"]["exchange"].startswith("all_to_all_single over gloo") and "TEST scaffolding" in r["config"]["exchange"]
+    assert r["scaling"] == "strong" and r["cpu_baseline"] is None
+    assert r["ms_per_step"] >= max(p["ms_per_step"] for p in r["per_rank"]) * 0.98  # the MAX over the ranks
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".sshash")]) == 1  # built once, by rank 0
+
+
 def test_config_c4_line(tmp_path):
     """`bench.py --workload c4` (human k = 63, m = 25 stand-in) at reduced size: the two-word path behind the same line -- statistics
     against the published k = 63 build, the table-less paths, and the FASTQ query with its counters equal to the oracle's."""
@@ -128,7 +165,7 @@ def test_config_c4_line(tmp_path):
     assert r["config"]["k"] == 63 and r["config"]["m"] == 25 and r["dtype"] == "u64" and r["config"]["recipe"] == "human_k63"
     assert r["config"]["index_statistics"]["source"].startswith("benchmarks/results-10-11-25/k63/regular-build.log")
     assert abs(r["config"]["positive_fraction_found"] - 0.5) < 0.01
-    assert all(v["ids_equal_table_path"] for v in r["other_paths"].values())
+    assert all(v.get("ids_equal_table_path") or v.get("ids_equal_device_path") for v in r["other_paths"].values())
     f = r["streaming_from_file"]
     assert f["counters_equal_oracle_on_sample"] is True and f["kmers"] == 100000 * (150 - 63 + 1)
     assert f["fastq"]["report"] == f["fastq.gz"]["report"] and f["fastq"]["report"]["num_positive_kmers"] > 0

@@ -4,6 +4,8 @@ Integer/index work: every comparison is bit-exact.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pytest
 
@@ -566,6 +568,19 @@ def test_page_locked_caller_buffers_are_used_in_place(case_se_regular):
     d.lookup(q_pin.numpy().view(np.uint64), out=mixed)
     assert (mixed == want).all()
     assert (want == case.oracle.lookup_packed(q, True)["kmer_id"]).all()
+    # round 6: device-mapped page-locked arrays are read and written by the kernels where they lie (the call above); the copy pipeline
+    # over the same arrays (what arrays that are page-locked but not mapped take), all eight fields and is_member both ways
+    full_mapped = d.lookup(q_pin.numpy().view(np.uint64), full=True, out=out_pin.numpy().view(np.uint64))
+    os.environ["SSHASH_AMD_TEST_HOOKS"] = "host_staged_copies=1,host_chunk=65536"
+    try:
+        out_pin.fill_(7)
+        d.lookup(q_pin.numpy().view(np.uint64), out=out_pin.numpy().view(np.uint64))
+        assert (out_pin.numpy().view(np.uint64) == want).all()
+    finally:
+        del os.environ["SSHASH_AMD_TEST_HOOKS"]
+    full_pageable = d.lookup(q, full=True)
+    for f in ("kmer_id", "kmer_id_in_string", "kmer_offset", "string_id", "string_begin", "string_end", "kmer_orientation", "minimizer_found"):
+        assert (getattr(full_mapped, f) == getattr(full_pageable, f)).all(), f
 
 
 def test_many_caller_streams(case_se_regular):

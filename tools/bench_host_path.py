@@ -34,3 +34,26 @@ qp = torch.from_numpy(q.view(np.int64)).pin_memory()
 op = torch.zeros(n, dtype=torch.int64).pin_memory()
 measure(qp.data_ptr(), op.data_ptr(), "page-locked caller arrays:")
 assert (op.numpy().view(np.uint64) == out).all()
+# the same queries as characters (sshash_lookup_ascii: k bytes per query over the link instead of 8)
+k = d.k()
+codes = (q[:, None] >> (2 * np.arange(k, dtype=np.uint64))[None, :]) & np.uint64(3)
+chars = torch.from_numpy(np.frombuffer(b"ACTG", dtype=np.uint8)[codes.astype(np.int64)]).pin_memory()
+del codes
+op.zero_()
+
+
+def measure_ascii():
+    r = B._Results(); r.kmer_id = op.data_ptr()
+
+    def call():
+        st = lib.sshash_lookup_ascii(d._h, chars.data_ptr(), n, 1, B.C.byref(r)); assert st == 0
+    call()
+    best = 1e9
+    for _ in range(4):
+        t0 = time.perf_counter(); call(); best = min(best, time.perf_counter() - t0)
+    print("page-locked caller arrays, ASCII:", os.environ.get("SSHASH_AMD_TEST_HOOKS"), "ms", round(best * 1e3, 2), "G lookups/s", round(n / best / 1e9, 3),
+          f"GB/s over the link ({k + 8} B per lookup)", round((k + 8) * n / best / 1e9, 1), flush=True)
+
+
+measure_ascii()
+assert (op.numpy().view(np.uint64) == out).all()
