@@ -36,8 +36,10 @@ measure(qp.data_ptr(), op.data_ptr(), "page-locked caller arrays:")
 assert (op.numpy().view(np.uint64) == out).all()
 # the same queries as characters (sshash_lookup_ascii: k bytes per query over the link instead of 8)
 k = d.k()
-codes = (q[:, None] >> (2 * np.arange(k, dtype=np.uint64))[None, :]) & np.uint64(3)
-chars = torch.from_numpy(np.frombuffer(b"ACTG", dtype=np.uint8)[codes.astype(np.int64)]).pin_memory()
+chars = torch.empty((n, k), dtype=torch.uint8).pin_memory()
+for a in range(0, n, 1 << 21):  # (in pieces: n x k codes as 64-bit words would be 12 GB)
+    codes = (q[a:a + (1 << 21), None] >> (2 * np.arange(k, dtype=np.uint64))[None, :]) & np.uint64(3)
+    chars[a:a + codes.shape[0]] = torch.from_numpy(np.frombuffer(b"ACTG", dtype=np.uint8)[codes.astype(np.int64)])
 del codes
 op.zero_()
 
