@@ -152,7 +152,7 @@ def test_eight_ranks_rehearsal(mode, tmp_path):
         else:
             assert r["config"]["index_replicated_per_gpu"] is False and r["config"]["sharded"] == extra[1]
             assert r["config"]["exchange"].startswith("all_to_all_single over gloo") and "TEST scaffolding" in r["config"]["exchange"]
-    assert r["scaling"] == "strong" and r["cpu_baseline"] is None
+    assert r["scaling"] == "strong" and (mode == "streaming" or r["cpu_baseline"] is None)
     assert r["ms_per_step"] >= max(p["ms_per_step"] for p in r["per_rank"]) * 0.98  # the MAX over the ranks
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".sshash")]) == 1  # built once, by rank 0
 
