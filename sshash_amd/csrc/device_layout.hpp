@@ -529,9 +529,6 @@ struct dict_view {
     uint64_t const* weight_starts;  // run-length intervals of the weights over the k-mer ids (index.hpp), or null
     uint64_t const* weight_values;
     uint64_t num_weight_intervals;
-    /* SSHASH_AMD_TEST_HOOKS read at upload (hooks.hpp), for same-box A/B runs and for the tests to reach the path the default leaves:
-       bit 0 = mphf_strands_in_turn (lookup_device.hpp: fast_lookup_pairs) */
-    uint32_t test_flags;
 };
 
 /* Struct-of-arrays lookup output; any pointer except kmer_id may be null.

@@ -257,7 +257,6 @@ void engine::to_device(int device, uint32_t table_shards, uint32_t table_shard_i
     v.m = idx.m;
     v.canonical = idx.canonical;
     v.skew_parts = idx.skew_num_partitions;
-    v.test_flags = uint32_t(test_hook_u64("mphf_strands_in_turn", 0, 0, 1));
     v.hash_magic = idx.hash_magic;
     v.num_kmers = idx.num_kmers;
     v.num_strings = idx.num_strings;

@@ -597,45 +597,8 @@ __device__ __forceinline__ fast_t fast_probe_regular_pairs(dict_view const& d, k
     return r;
 }
 
-/* MPHF + codeword for BOTH strands of a regular dictionary's query at once (round 6). One after the other the two strands are two
-   chains of three dependent reads -- pilot, control codeword, strings -- and three quarters of the queries of a 50 % positive batch
-   walk the second chain (every negative, every positive spelled on the other strand). Here both pilots are asked for together, then
-   both codewords: a chain of three round trips where there were up to six; what it costs is the pilot and the codeword of the other
-   strand for the quarter of the queries the forward strand would have settled. (With the one-read directory the same trade measured
-   as a loss, fast_lookup_one below: there the first chain is two reads, not three.) */
-__device__ __forceinline__ void fast_resolve_mphf_both(dict_view const& d, uint64_t mini_f, uint64_t mini_r, bool need, bool need_rc, resolve_t& af,
-                                                       resolve_t& ar) {
-    af.code = ar.code = 0;
-    af.present = ar.present = false;
-    af.settled = ar.settled = true;
-    if (!need) return;
-    const uint64_t id_f = mphf_eval(d.minimizers, city128_u64(mini_f, d.minimizers.seed));
-    const uint64_t id_r = need_rc ? mphf_eval(d.minimizers, city128_u64(mini_r, d.minimizers.seed)) : id_f;
-    const uint64_t entry_f = d.cw_packed ? packed_get(d.codewords, id_f, d.cw_width) : __builtin_nontemporal_load(d.codewords + id_f);
-    const uint64_t entry_r = d.cw_packed ? packed_get(d.codewords, id_r, d.cw_width) : __builtin_nontemporal_load(d.codewords + id_r);
-    af.code = entry_f & low_mask(d.cw_width);
-    ar.code = entry_r & low_mask(d.cw_width);
-    af.present = d.cw_packed || (entry_f >> d.cw_width) == minimizer_fingerprint(mini_f, d.m, d.canonical != 0, d.cw_width);
-    ar.present = need_rc && (d.cw_packed || (entry_r >> d.cw_width) == minimizer_fingerprint(mini_r, d.m, d.canonical != 0, d.cw_width));
-}
-
 /* all lanes of the wave; active = false: no query */
 __device__ __forceinline__ fast_t fast_lookup_pairs(dict_view const& d, kmer_w<1> const& x, bool active, bool check_rc) {
-    if (!d.directory.enabled && check_rc && !(d.test_flags & 1u)) {  // uniform: the MPHF path
-        const kmer_w<1> x_rc = kmer_revcomp<1>(x, d.k);
-        const minimizer_t mf = compute_minimizer<1>(x, d.k, d.m, d.hash_magic);
-        const minimizer_t mr = compute_minimizer<1>(x_rc, d.k, d.m, d.hash_magic);
-        resolve_t af, ar;
-        fast_resolve_mphf_both(d, mf.value, mr.value, active, true, af, ar);
-        fast_t r = fast_probe_regular_pairs(d, x, mf, false, af, active);
-        const bool second = active && r.outcome == FAST_MISS;
-        if (__ballot(second && ar.present) != 0) {  // wave-uniform (a strand whose minimizer is not the dictionary's ends at its codeword)
-            const fast_t r2 = fast_probe_regular_pairs(d, x_rc, mr, true, ar, second);
-            if (second) r = r2;
-        }
-        if (second) r.orientation = -1;
-        return r;
-    }
     const minimizer_t mf = compute_minimizer<1>(x, d.k, d.m, d.hash_magic);
     fast_t r = fast_probe_regular_pairs(d, x, mf, false, fast_resolve_pairs(d, mf.value, active), active);
     const bool second = active && r.outcome == FAST_MISS && check_rc;
@@ -663,7 +626,10 @@ __device__ __forceinline__ fast_t fast_lookup_one(dict_view const& d, kmer_w<W> 
         const minimizer_t mf = compute_minimizer<W>(x, d.k, d.m, d.hash_magic);
         /* (Asking for both strands' directory buckets at once -- three of four queries of the benchmark mix need the second
            answer anyway -- shortens the chain by one read and wastes a line on every forward hit: measured 12.1 against 13.0 G
-           lookups/s on the C3 stand-in, profiles/r03/; the strands stay one after the other.) */
+           lookups/s on the C3 stand-in, profiles/r03/; the strands stay one after the other. Round 6 measured the same trade on the
+           MPHF path, whose chains are three reads long -- both pilots together, then both codewords, fast_lookup_pairs --: 10.8 against
+           11.96 G lookups/s, same box, two alternating rounds, profiles/r06/mphf_both_strands_together_ab.txt. These paths are bound by
+           the REQUESTS they make of the memory system, not by the length of their chains.) */
         fast_t r = fast_probe_regular<W>(d, x, mf, false, fast_resolve(d, mf.value));
         if (r.outcome == FAST_MISS && check_rc) {
             const kmer_w<W> x_rc = kmer_revcomp<W>(x, d.k);

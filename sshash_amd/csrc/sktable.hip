@@ -373,6 +373,41 @@ static void absent(device_replica& rep, uint32_t reason) {
     if (std::getenv("SSHASH_AMD_VERBOSE")) fprintf(stderr, "[sshash_amd] device %d: no super-k-mer table (reason %u, sshash_amd.h)\n", rep.device, reason);
 }
 
+/* SSHASH_AMD_SK_DENSITY: how full the table is packed -- the footprint / rate trade of a replica, a documented switch.
+     (unset), "default"   2.5 slots per item in the keys' region (3.0 at k <= 63), 1.75 (2.5) places per k-mer of a heavy key
+     "compact"            1.6 / 1.35 (k <= 63: 2.0 / 1.75)
+     a number x           x slots per item, 1.2 <= x <= 4.0; the k-mers' region scaled along
+   C3, one box (profiles/r06/density_sweep_c3.txt): 2.5 -> 2.0 -> 1.6 -> 1.4 -> 1.25 slots per item = 16.8 -> 14.0 -> 11.8 -> 10.6 -> 9.8 B/k-mer
+   in HBM for 40.2 -> 37.3 -> 35.8 -> 33.9 -> 29.7 G lookups/s: what a fuller table costs is second choices (a second line) and, past a load
+   factor of 0.6, keys that find no slot in five choices and take the complete path (0.05 % of the keys at 2.5, 0.9 % at 1.6, 3.7 % at 1.25).
+   Round 5 had folded the two knobs of round 2 (SSHASH_AMD_SK_SLOTS_PER_KEY / _PER_KMER) into the tests' hooks while INTEGRATION.md still
+   offered them to deployments: they are named once on stderr if set, and this is what replaces them. */
+static void sk_density(bool wide, double& slots_per_key, double& slots_per_kmer) {
+    const double key_default = wide ? SK_SLOTS_PER_KEY_WIDE : SK_SLOTS_PER_KEY, kmer_default = wide ? SK_SLOTS_PER_KMER_WIDE : SK_SLOTS_PER_KMER_NARROW;
+    slots_per_key = key_default;
+    slots_per_kmer = kmer_default;
+    for (char const* gone : {"SSHASH_AMD_SK_SLOTS_PER_KEY", "SSHASH_AMD_SK_SLOTS_PER_KMER"}) {
+        static std::atomic<bool> said{false};
+        if (std::getenv(gone) && !said.exchange(true))
+            fprintf(stderr, "[sshash_amd] %s is no longer read (round 5): use SSHASH_AMD_SK_DENSITY=compact or =<slots per item> (INTEGRATION.md)\n", gone);
+    }
+    char const* e = std::getenv("SSHASH_AMD_SK_DENSITY");
+    if (!e || !*e || std::strcmp(e, "default") == 0) return;
+    if (std::strcmp(e, "compact") == 0) {
+        slots_per_key = wide ? 2.0 : 1.6;
+        slots_per_kmer = wide ? 1.75 : 1.35;
+        return;
+    }
+    char* end = nullptr;
+    const double x = std::strtod(e, &end);
+    if (end == e || *end || !(x >= 1.2 && x <= 4.0)) {
+        fprintf(stderr, "[sshash_amd] SSHASH_AMD_SK_DENSITY=%s: expected default, compact or a number of slots per item in [1.2, 4.0]; using the default\n", e);
+        return;
+    }
+    slots_per_key = x;
+    slots_per_kmer = std::min(kmer_default, std::max(1.2, x * kmer_default / key_default));
+}
+
 uint64_t hbm_budget() {
     if (const char* e = std::getenv("SSHASH_AMD_HBM_BUDGET")) return std::strtoull(e, nullptr, 10);
     return 0;
@@ -487,7 +522,8 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     }
     uint64_t K = 0;
     HIP_CHECK(hipMemcpy(&K, d_num_runs, 8, hipMemcpyDeviceToHost));
-    double slots_per_key = wide ? SK_SLOTS_PER_KEY_WIDE : SK_SLOTS_PER_KEY;
+    double slots_per_key, slots_per_kmer;
+    sk_density(wide, slots_per_key, slots_per_kmer);
     slots_per_key = test_hook_f64("slots_per_key", slots_per_key, 1.2, 16.0);  // (tests: a packed table, where second choices and unplaced items are common)
     if (K == 0) return absent(rep, SK_ABSENT_TOO_MANY_ITEMS);
     uint32_t* run_begins = tmp.alloc<uint32_t>(K);
@@ -537,7 +573,6 @@ void build_sk_table(device_replica& rep, host_index const& idx, uint32_t table_s
     }
     /* slots asked for: one per occurrence of a light key, one marker per heavy key -- the keys' region -- and one per k-mer of
        a heavy key, in the region behind it (sk_view::kmer_buckets) */
-    double slots_per_kmer = wide ? SK_SLOTS_PER_KMER_WIDE : SK_SLOTS_PER_KMER_NARROW;
     slots_per_kmer = test_hook_f64("slots_per_kmer", slots_per_kmer, 1.2, 16.0);
     const uint64_t wanted = (T - heavy_occurrences) + heavy_keys + heavy_kmers;
     const uint64_t key_buckets = uint64_t(double(wanted - heavy_kmers) * slots_per_key / SK_BUCKET_SLOTS) + 8;

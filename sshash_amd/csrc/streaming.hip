@@ -337,6 +337,22 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
         }
         c_invalid += c_invalid_turn;
         const uint64_t valid_end = inv < rd_end ? inv : rd_end;
+#ifndef SSHASH_STREAM_RUN_AFTER_SEED
+        /* -- the run behind the hit of the turn before, THEN this turn's seed (round 6): the lane measures its run and goes straight on to the
+              k-mer behind it -- the negative over the substitution that ended the run, as a rule -- in the same turn. Until round 5 a lane did
+              one or the other in a turn (the run's first loads travelled beside the seeds' bucket lines: one wait for both), and a hit -- run --
+              miss cycle of a read took a turn more than it has events: a fifth of the turns of a high-hit read set. The wave now waits twice a
+              turn (the strings' atom, then the bucket), which five waves a SIMD hide (tools/jobs/r06_stream_ab.sh: same-box A/B). -- */
+        if (live && pending) {
+            const uint64_t b = cur + k - 1;
+            const uint64_t run = extend_run<W>(d, packed, off, ori, b, valid_end - b, run_step_load<W>(d, packed, off, ori > 0, b, 0));
+            if (run >> 15) atomicAdd(wave_moved_out + 3, (unsigned long long)run);  // (past what the lane's 32-bit counter may take in one turn: 2^16 turns lie between two move-outs)
+            else c_extensions += uint32_t(run);
+            cur += run;
+            live = cur + k <= valid_end;  // (else: the k-mer behind the run lies over an invalid base, or past the read's end -- the next turn's business)
+        }
+        pending = false;
+#else
         /* -- this turn's event of the lane: the run behind the hit of the turn before, or a seed -- */
         /* (the run's first 32 bases are asked for here and looked at behind the seeds' part of the turn: the strings' atom is a line
            from HBM like a bucket, and the wave waits once for both) */
@@ -347,6 +363,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             live = false;  // (its next k-mer waits for the next turn: it may lie over an invalid base, or in the next read)
         }
         pending = false;
+#endif
         /* -- seed() at cur (streaming_query.hpp:144-197): the k-mer, its key, its key's first bucket; a lane in the middle of a walk
               (its key's first bucket was not the end of it) keeps its k-mer and comes with the walk's next bucket instead -- */
         uint64_t ahead_f = 0, ahead_r = 0;
@@ -469,6 +486,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 }
             }
         }
+#ifdef SSHASH_STREAM_RUN_AFTER_SEED
         if (extending) {
             if constexpr (W == 2) first_step = run_step_load<W>(d, packed, off, ori > 0, cur + k - 1, 0);
             const uint64_t run = extend_run<W>(d, packed, off, ori, cur + k - 1, valid_end - (cur + k - 1), first_step);
@@ -476,6 +494,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             else c_extensions += uint32_t(run);
             cur += run;
         }
+#endif
         const bool finishing = live && !walking;  // (a walking lane's seed is settled in a later turn)
         if (finishing && !settled) {
             /* no table, or a tie / an unplaced key / another shard's key: the complete seed() */

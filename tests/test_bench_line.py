@@ -37,7 +37,9 @@ def test_the_line_of_the_drivers_command_is_compact_and_complete():
     for name, short in line["other_workloads"].items():
         child = full["other_workloads"][name]
         assert short["value"] == child["value"] and short["roofline_frac"] == child["roofline"]["frac"] and short["parity"]
-        assert 0 < short["roofline_frac"] < 1, (name, short)  # no line above the roofline (streaming: the reference's own bytes)
+        # (lookups: algorithmic bytes are what the kernel has to move at least -- below the roofline. Streaming: the reference's own bytes, which
+        # the kernel is free to skip -- reported, labelled `frac_is`, not asserted to stay below 1: ADVICE r5)
+        assert 0 < short["roofline_frac"] and (short["roofline_frac"] < 1 or "streaming" in name), (name, short)
         assert short["traffic"], name                            # PMC traffic on every line that has a kernel
     assert json.loads(text) == line
 

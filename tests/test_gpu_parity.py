@@ -267,18 +267,15 @@ def test_batch_larger_than_one_launch_piece(case_se_regular):
     assert int((got == np.uint64(0xFFFFFFFFFFFFFFFD)).sum()) == 0  # nothing left unwritten
 
 
-@pytest.mark.parametrize("settings", [{"SSHASH_AMD_DIRECTORY": "0", "SSHASH_AMD_SKTABLE": "0"},
-                                      {"SSHASH_AMD_DIRECTORY": "0", "SSHASH_AMD_SKTABLE": "0", "SSHASH_AMD_TEST_HOOKS": "mphf_strands_in_turn=1"},
-                                      {"SSHASH_AMD_SKTABLE": "0"}, {},
+@pytest.mark.parametrize("settings", [{"SSHASH_AMD_DIRECTORY": "0", "SSHASH_AMD_SKTABLE": "0"}, {"SSHASH_AMD_SKTABLE": "0"}, {},
                                       {"SSHASH_AMD_DIRECTORY": "1"}, {"SSHASH_AMD_TEST_HOOKS": "slots_per_key=1.2,slots_per_kmer=1.2"}, {"SSHASH_AMD_TEST_HOOKS": "piece=4096"},
                                       {"SSHASH_AMD_TEST_HOOKS": "piece=4096", "SSHASH_AMD_SKTABLE": "0"}],
-                         ids=["mphf_only", "mphf_only_strands_in_turn", "directory_only", "sktable_lean", "sktable_over_directory", "sktable_packed_tight",
+                         ids=["mphf_only", "directory_only", "sktable_lean", "sktable_over_directory", "sktable_packed_tight",
                               "many_launch_pieces", "many_launch_pieces_no_table"])
 def test_accelerators_disabled(tmp_path, settings):
     """The lookup structures are layered (device_layout.hpp (3)-(5)): with the super-k-mer table and/or
     the minimizer directory switched off (also what an over-wide dictionary gets) the remaining path must
-    give the same ids / membership / full results as the oracle. mphf_only resolves both strands' minimizers of a regular
-    dictionary's query together (round 6), mphf_only_strands_in_turn one after the other. sktable_lean is the default replica: the table over
+    give the same ids / membership / full results as the oracle. sktable_lean is the default replica: the table over
     bit-packed codewords, no directory; sktable_over_directory forces the round-2 layout; sktable_packed_tight fills both
     regions of the table (the keys', the heavy keys' k-mers') to a load factor of 0.83: long bucket sequences, and items
     that find no slot and are left to the complete path; many_launch_pieces cuts every batch into sequences of 4096 queries:

@@ -1,5 +1,5 @@
 """GPU: the environment switches that change what a replica holds or how a batch is launched (SSHASH_AMD_SKTABLE,
-_DIRECTORY, _SK_M, and the tests' own SSHASH_AMD_TEST_HOOKS), each in a process of its own (tests/gpu_switch_worker.py): every k-mer of
+_DIRECTORY, _SK_M, _SK_DENSITY, and the tests' own SSHASH_AMD_TEST_HOOKS), each in a process of its own (tests/gpu_switch_worker.py): every k-mer of
 a C2-like stand-in through the id-returning and the is_member instances, launch after launch -- 20 launches where the round-3 hazard
 lived --, ASCII input, the bench's mixes against the oracle. (Round 5 removed the A/B-only switches -- INWAVE, OVERLAP -- and their kernels.)"""
 from __future__ import annotations
@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
 SETTINGS = [
     ("default", {}, 20),
     ("packed_table", {"SSHASH_AMD_TEST_HOOKS": "slots_per_key=1.4,slots_per_kmer=1.3"}, 3),
+    ("density_compact", {"SSHASH_AMD_SK_DENSITY": "compact"}, 3),   # the documented footprint switch (round 6): 1.6 slots per item instead of 2.5
+    ("density_number", {"SSHASH_AMD_SK_DENSITY": "2.0", "SSHASH_AMD_SK_SLOTS_PER_KEY": "9"}, 3),  # (the removed knob is named on stderr and not read)
     ("small_pieces", {"SSHASH_AMD_TEST_HOOKS": "piece=1000000"}, 3),
     ("table_key_17", {"SSHASH_AMD_SK_M": "17"}, 3),   # the table's own key length (sk_view::m): shorter and longer than the
     ("table_key_25", {"SSHASH_AMD_SK_M": "25"}, 3),   # dictionary's minimizers (m = 21 here)
@@ -44,6 +46,8 @@ def test_every_kmer_launch_after_launch(name, env, launches):
         assert got["sk_slots"] == 0 and (name == "directory") == bool(got["directory_sectors"])
     else:
         assert got["sk_slots"] > 0
+    if name.startswith("density"):  # fewer slots than the default replica of the same dictionary, the same answers
+        assert got["sk_slots"] < run("c2_like_regular", {}, 1)["sk_slots"] * (0.7 if name == "density_compact" else 0.85)
 
 
 @pytest.mark.parametrize("workload", ["c3_like_canonical", "c4_like_k63"])
