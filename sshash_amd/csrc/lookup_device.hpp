@@ -698,10 +698,12 @@ struct sk_bucket_flags {
    does not carry the key's fingerprint has no say. One that does holds the strings around an occurrence of the key: the read lies
    against it at a fixed offset for as long as the key occurrence is the same, so a base at which the two differ keeps them apart
    while the k-mer still holds that base -- the LAST differing base of the k-mer when the read runs along the strings here, the first
-   when it runs against them. No difference (the k-mer ends outside the super-k-mer's extent) or a marker: no promise. */
+   when it runs against them. No difference (the k-mer ends outside the super-k-mer's extent) or a marker: no promise.
+   `inline_seen`: the slot carries the fingerprint and is not a marker (what a walk needs to know before it lets the k-mers behind a
+   heavy key's marker start on their own sequences: streaming.hip). */
 template <int W, bool FIRST, bool TRACK, class Piece>
 __device__ __forceinline__ void sk_examine_slot_tracking(dict_view const& d, sk_query_t<W> const Q, uint32_t c, Piece piece, fast_t& r,
-                                                         bool& key_seen, bool& marker, sk_bucket_flags& flags, uint32_t& lasts) {
+                                                         bool& key_seen, bool& marker, sk_bucket_flags& flags, uint32_t& lasts, bool& inline_seen) {
     const uint32_t km = d.k - d.sk.m;
     const uint32_t j = Q.j;
     /* values, not references into Q: a select between two members of a by-reference struct is compiled into an
@@ -780,6 +782,7 @@ __device__ __forceinline__ void sk_examine_slot_tracking(dict_view const& d, sk_
         uint32_t mine = along ? last : d.k - 1 - first;
         mine = (differ && !is_marker) ? mine : 0u;
         lasts = (same_fingerprint && mine < lasts) ? mine : lasts;
+        inline_seen = inline_seen || (same_fingerprint && !is_marker);  // an occurrence of (a key with) the query's fingerprint held inline
     }
 }
 
@@ -787,7 +790,8 @@ template <int W, bool FIRST, class Piece>
 __device__ __forceinline__ void sk_examine_slot(dict_view const& d, sk_query_t<W> const Q, uint32_t c, Piece piece, fast_t& r,
                                                 bool& key_seen, bool& marker, sk_bucket_flags& flags) {
     uint32_t unused = 0;
-    sk_examine_slot_tracking<W, FIRST, false>(d, Q, c, piece, r, key_seen, marker, flags, unused);
+    bool unused_too = false;
+    sk_examine_slot_tracking<W, FIRST, false>(d, Q, c, piece, r, key_seen, marker, flags, unused, unused_too);
 }
 
 /* k <= 63: one ENTRY of the k-mers' region (device_layout.hpp: 32 bytes -- meta, string id, position | fingerprint, the

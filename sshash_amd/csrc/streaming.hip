@@ -251,8 +251,11 @@ __device__ __forceinline__ uint64_t extend_run(dict_view const& d, const uint64_
 /* (five waves a SIMD: 96 registers. Round 5's steps there, same-box: k <= 31 four -> five waves 110 -> 126 G k-mers/s; k <= 63, once 32-bit
    counters and a run measurement without early loads had made room, 138 -> 147 with 20 bytes of scratch. Compiled for six: 14 / 31 % slower,
    profiles/r05/streaming_run_kernel_waves_per_simd_ab.txt.) */
+#ifndef SSHASH_STREAM_WAVES
+#define SSHASH_STREAM_WAVES 5
+#endif
 template <int W, bool CANON, bool SK>
-__global__ void __launch_bounds__(256, 5)
+__global__ void __launch_bounds__(256, SSHASH_STREAM_WAVES)
 streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, const uint64_t* __restrict__ packed,
                      const uint64_t* __restrict__ okay, const uint64_t* __restrict__ offsets, const uint64_t n_reads,
                      const uint64_t reads_per_wave, const uint32_t move_out_every, uint64_t* __restrict__ report) {
@@ -281,13 +284,35 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
        from turn to turn. `where`: the choice of the sequence it is on | flags | the choice of the key's sequence to come back to */
     constexpr uint32_t WALK_CHOICE = 7u, WALK_COMPACT = 8u, WALK_VISITED = 16u, WALK_BACK_SHIFT = 8u, WALK_NO_RETURN = 7u;
     constexpr uint32_t WALK_LASTS_SHIFT = 16u, WALK_LASTS = 63u;  // what the slots met so far allow (min over the walk; 63: anything)
+    /* A HEAVY key remembered (round 6). The k-mers of a heavy key are entered under keys of their own, and a seed learns that from the key's
+       marker: one bucket for the marker, another -- a turn later -- on the k-mer's own sequence. Over a substitution inside a repeat every one
+       of the k (negative) k-mers paid both, and none stands for its neighbours: on the high-hit set a fifth of all lane-turns were such
+       second turns (profiles/r06/streaming_lane_occupancy_per_turn.txt). The k-mers that FOLLOW along the read and elect the same key
+       occurrence (sk_key_persists) would walk the same buckets of the key's sequence up to the same marker; if none of those buckets holds
+       an inline slot with the key's fingerprint (WALK_INLINE: then nothing in them can answer any k-mer of this key) they may start where
+       that walk ended: on their own sequence, with the same choice of the key's sequence to come back to. Fields of `where` that outlive
+       the seed: how many following k-mers may still do so, and that choice. */
+    constexpr uint32_t WALK_INLINE = 32u, WALK_HEAVY_BACK_SHIFT = 11u, WALK_HEAVY_SHIFT = 24u, WALK_HEAVY = 63u, WALK_HEAVY_PENDING = 1u << 30;
+    constexpr uint32_t WALK_HEAVY_FIELDS = (7u << WALK_HEAVY_BACK_SHIFT) | (WALK_HEAVY << WALK_HEAVY_SHIFT) | WALK_HEAVY_PENDING;
     bool walking = false;
     kmer_w<W> x = kmer_zero<W>(), x_rc = kmer_zero<W>();
     sk_key_t kk{};
     uint64_t on = 0, on_a = 0;
     uint32_t where = 0;
     uint32_t turns = 0;
+#ifdef SSHASH_STREAM_STATS
+    /* (a debug build, tools/jobs/r06_stream_stats.sh: what the lanes of a wave do per turn -- wave-level sums in scalar registers, out
+       through report[6 ..]; the caller's report has 16 entries then) */
+    unsigned long long st_turns = 0, st_fresh = 0, st_walk = 0, st_ext = 0, st_slot1 = 0, st_inv = 0, st_idle = 0, st_full = 0, st_short = 0;
+    uint64_t st_kept_lane = 0;
+#define STAT(var, pred) var += (unsigned long long)__popcll(__ballot(pred))
+#else
+#define STAT(var, pred) (void)0
+#endif
     for (;;) {
+#ifdef SSHASH_STREAM_STATS
+        ++st_turns;
+#endif
         if (++turns >= move_out_every) {  // (scalar; a turn adds less than 2^15 to a lane's counter -- a longer run of extensions or of invalid k-mers goes to the wave's 64-bit totals at once --, so 2^16 turns stay below 2^31)
             turns = 0;
             const uint64_t i = wave_sum(c_invalid), n = wave_sum(c_negative), f = wave_sum(c_searches), e = wave_sum(c_extensions);
@@ -299,6 +324,24 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             }
             c_invalid = c_negative = c_searches = c_extensions = 0;
         }
+#ifndef SSHASH_STREAM_RUN_AFTER_SEED
+        /* -- the run behind the hit of the turn before, THEN this turn's seed (round 6): the lane measures its run and goes straight on to
+              whatever lies behind it in the same turn -- the negative over the substitution that ended the run, as a rule; the NEXT READ when
+              the run reached the end of this one (which is why the run comes before the reads are handed out). Until round 5 a lane did one
+              or the other in a turn (the run's first loads travelled beside the seeds' bucket lines: one wait for both), and a hit -- run --
+              miss cycle took a turn more than it has events. (`pending` is only set when the k-mer behind the hit lies inside the read's
+              valid bases: no test of its own here.) -- */
+        STAT(st_ext, pending);
+        if (pending) {
+            const uint64_t b = cur + k - 1, valid_end = inv < rd_end ? inv : rd_end;
+            const uint64_t run = extend_run<W>(d, packed, off, ori, b, valid_end - b, run_step_load<W>(d, packed, off, ori > 0, b, 0));
+            if (run >> 15) atomicAdd(wave_moved_out + 3, (unsigned long long)run);  // (past what the lane's 32-bit counter may take in one turn: 2^16 turns lie between two move-outs)
+            else c_extensions += uint32_t(run);
+            cur += run;
+            if (run) where &= ~WALK_HEAVY_FIELDS;  // (the k-mer behind a run elects a key of its own)
+        }
+        pending = false;
+#endif
         /* -- the reads: whoever has none left takes the next of the wave's share -- */
         const bool want = !walking && cur + k > rd_end;
         const uint64_t wants = __ballot(want);
@@ -311,6 +354,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 if (rd_end - cur >= k) atomicAdd(wave_moved_out + 4, (unsigned long long)(rd_end - cur - k + 1));
                 inv = first_invalid_base(okay, cur, rd_end);
                 neg_unknown_mini = false;
+                where = 0;
             }
             const uint64_t taken = uint64_t(__popcll(wants));
             next = taken < last - next ? next + taken : last;
@@ -322,6 +366,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
               `inv`: cur + k > inv). (Round 5 advanced one invalid base per iteration, each with a dependent load, the other 63 lanes
               waiting: a read with a long run of N was a cliff) -- */
         uint32_t c_invalid_turn = 0;
+        STAT(st_inv, live && cur + k > inv);
         while (live && cur + k > inv) {
             const uint64_t nv = first_valid_base(okay, inv + 1, rd_end);  // the run of invalid bases is [inv, nv)
             const uint64_t last_over_it = nv - 1 < rd_end - k ? nv - 1 : rd_end - k;
@@ -333,26 +378,12 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             cur = nv;
             inv = first_invalid_base(okay, nv, rd_end);
             neg_unknown_mini = false;
+            where = 0;
             live = cur + k <= rd_end;
         }
         c_invalid += c_invalid_turn;
         const uint64_t valid_end = inv < rd_end ? inv : rd_end;
-#ifndef SSHASH_STREAM_RUN_AFTER_SEED
-        /* -- the run behind the hit of the turn before, THEN this turn's seed (round 6): the lane measures its run and goes straight on to the
-              k-mer behind it -- the negative over the substitution that ended the run, as a rule -- in the same turn. Until round 5 a lane did
-              one or the other in a turn (the run's first loads travelled beside the seeds' bucket lines: one wait for both), and a hit -- run --
-              miss cycle of a read took a turn more than it has events: a fifth of the turns of a high-hit read set. The wave now waits twice a
-              turn (the strings' atom, then the bucket), which five waves a SIMD hide (tools/jobs/r06_stream_ab.sh: same-box A/B). -- */
-        if (live && pending) {
-            const uint64_t b = cur + k - 1;
-            const uint64_t run = extend_run<W>(d, packed, off, ori, b, valid_end - b, run_step_load<W>(d, packed, off, ori > 0, b, 0));
-            if (run >> 15) atomicAdd(wave_moved_out + 3, (unsigned long long)run);  // (past what the lane's 32-bit counter may take in one turn: 2^16 turns lie between two move-outs)
-            else c_extensions += uint32_t(run);
-            cur += run;
-            live = cur + k <= valid_end;  // (else: the k-mer behind the run lies over an invalid base, or past the read's end -- the next turn's business)
-        }
-        pending = false;
-#else
+#ifdef SSHASH_STREAM_RUN_AFTER_SEED
         /* -- this turn's event of the lane: the run behind the hit of the turn before, or a seed -- */
         /* (the run's first 32 bases are asked for here and looked at behind the seeds' part of the turn: the strings' atom is a line
            from HBM like a bucket, and the wave waits once for both) */
@@ -368,6 +399,9 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
               (its key's first bucket was not the end of it) keeps its k-mer and comes with the walk's next bucket instead -- */
         uint64_t ahead_f = 0, ahead_r = 0;
         bool table = false;
+        STAT(st_fresh, live && !walking);
+        STAT(st_walk, live && walking);
+        STAT(st_idle, !live);
         if (live && !walking) {
             const uint64_t i = cur >> 5;
             const uint32_t sh = 2 * (uint32_t(cur) & 31u);
@@ -381,15 +415,27 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 const uint32_t sm = d.sk.m, hashed = sm < 12 ? sm : 12;
                 ahead_f = read_bases32(packed, cur + k - sm + 1);
                 ahead_r = read_bases32(packed, cur + k + 1 - hashed);
-                kk = sk_key<W>(x, x_rc, k, sm);
-                table = sk_usable(d, kk);
-                on = kk.key;
+                const uint32_t heavy_left = (where >> WALK_HEAVY_SHIFT) & WALK_HEAVY;
+                STAT(st_short, heavy_left != 0);
+                if (heavy_left) {
+                    /* the k-mer before this one met its key's marker, and this one elects the same occurrence -- one base further along its
+                       strand --: straight to its own sequence */
+                    kk.pos = kk.rc ? kk.pos + 1 : kk.pos - 1;
+                    table = true;
+                    on = sk_kmer_key<W>(x, x_rc);
+                    const uint32_t back = (where >> WALK_HEAVY_BACK_SHIFT) & 7u;
+                    where = WALK_VISITED | WALK_COMPACT | (back << WALK_BACK_SHIFT) | (back << WALK_HEAVY_BACK_SHIFT) | ((heavy_left - 1) << WALK_HEAVY_SHIFT);
+                } else {
+                    kk = sk_key<W>(x, x_rc, k, sm);
+                    table = sk_usable(d, kk);
+                    on = kk.key;
+                    where = (WALK_NO_RETURN << WALK_BACK_SHIFT) | (WALK_LASTS << WALK_LASTS_SHIFT);  // choice 0 of the key's own sequence, nothing to come back to
+                }
                 on_a = sk_hash_a(on);
-                where = (WALK_NO_RETURN << WALK_BACK_SHIFT) | (WALK_LASTS << WALK_LASTS_SHIFT);  // choice 0 of the key's own sequence, nothing to come back to
             }
         }
         if constexpr (SK) {
-            if (live && walking && !(where & WALK_VISITED)) {  // (a walk along the key's own sequence may end in a miss that stands for more than itself)
+            if (live && walking && (!(where & WALK_VISITED) || (where & WALK_HEAVY_PENDING))) {  // (a walk along the key's own sequence may end in a miss that stands for more than itself; one behind a heavy key's marker ends with a look at how long the key lasts)
                 const uint32_t sm = d.sk.m, hashed = sm < 12 ? sm : 12;
                 ahead_f = read_bases32(packed, cur + k - sm + 1);
                 ahead_r = read_bases32(packed, cur + k + 1 - hashed);
@@ -416,16 +462,17 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 sk_bucket_flags flags;
                 flags.go_on = 0;
                 flags.second_used = false;
-                bool marker = false, seen = false;
+                bool marker = false, seen = false, inline_seen = false;
                 uint32_t lasts = 0xFFFFu;
                 if (!compact) {
-                    sk_examine_slot_tracking<W, true, true>(d, Q, c, [mine](uint32_t i) { return mine[i]; }, r, seen, marker, flags, lasts);
+                    sk_examine_slot_tracking<W, true, true>(d, Q, c, [mine](uint32_t i) { return mine[i]; }, r, seen, marker, flags, lasts, inline_seen);
+                    STAT(st_slot1, r.outcome == FAST_MISS && flags.second_used);
                     if (r.outcome == FAST_MISS && flags.second_used) {
                         if constexpr (W == 1) {
-                            sk_examine_slot_tracking<W, false, true>(d, Q, c, [mine](uint32_t i) { return mine[2 + i]; }, r, seen, marker, flags, lasts);
+                            sk_examine_slot_tracking<W, false, true>(d, Q, c, [mine](uint32_t i) { return mine[2 + i]; }, r, seen, marker, flags, lasts, inline_seen);
                         } else {  // slot 1 lives in the bucket's second line, and only the lanes whose key's fingerprint is there get here
                             const uint4* B1 = reinterpret_cast<const uint4*>(d.sk.slots) + (SK_BUCKET_SLOTS * 2 * W) * uint64_t(bucket) + 2 * W;
-                            sk_examine_slot_tracking<W, false, true>(d, Q, c, [B1](uint32_t i) { return B1[i]; }, r, seen, marker, flags, lasts);
+                            sk_examine_slot_tracking<W, false, true>(d, Q, c, [B1](uint32_t i) { return B1[i]; }, r, seen, marker, flags, lasts, inline_seen);
                         }
                     }
                 } else if constexpr (W == 1) {
@@ -440,14 +487,16 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 {
                     const uint32_t before = (where >> WALK_LASTS_SHIFT) & WALK_LASTS;
                     lasts = lasts < before ? lasts : before;
-                    where = (where & ~(WALK_LASTS << WALK_LASTS_SHIFT)) | (lasts << WALK_LASTS_SHIFT);
+                    where = (where & ~(WALK_LASTS << WALK_LASTS_SHIFT)) | (lasts << WALK_LASTS_SHIFT) | (inline_seen ? WALK_INLINE : 0u);
                 }
                 /* where the walk goes from here (lookup_device.hpp: sk_walk_step) */
                 const bool go_on = flags.go_on != 0;
                 bool more = false, defer = false;
                 if (r.outcome == FAST_MISS) {
                     if (marker && !(where & WALK_VISITED)) {  // the key is heavy: its k-mers are entered under keys of their own
-                        where = WALK_VISITED | WALK_COMPACT | ((go_on ? c + 1 : WALK_NO_RETURN) << WALK_BACK_SHIFT);
+                        const uint32_t back = go_on ? c + 1 : WALK_NO_RETURN;
+                        where = WALK_VISITED | WALK_COMPACT | (back << WALK_BACK_SHIFT) |
+                                ((where & WALK_INLINE) ? 0u : (WALK_HEAVY_PENDING | (back << WALK_HEAVY_BACK_SHIFT)));  // (nothing inline on the way: the k-mers behind may skip it)
                         on = sk_kmer_key<W>(x, x_rc);
                         on_a = sk_hash_a(on);
                         more = true;
@@ -460,7 +509,7 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                            left is the rest of the key's sequence */
                         const uint32_t back = (where >> WALK_BACK_SHIFT) & WALK_CHOICE;
                         defer = back >= SK_CHOICES;
-                        where = WALK_VISITED | back | (WALK_NO_RETURN << WALK_BACK_SHIFT);
+                        where = WALK_VISITED | back | (WALK_NO_RETURN << WALK_BACK_SHIFT) | (where & WALK_HEAVY_FIELDS);
                         on = kk.key;
                         on_a = sk_hash_a(on);
                         more = !defer;
@@ -472,16 +521,24 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                     found = r.outcome == FAST_HIT;
                     off = r.kmer_offset;
                     ori = r.orientation;
-                    if (!found && !(where & WALK_VISITED)) {
+                    const bool stands = !found && !(where & WALK_VISITED);
+                    if (stands || (where & WALK_HEAVY_PENDING)) {
                         /* a miss that stands for the k-mers behind this one: those that elect the same key occurrence (sk_key_persists)
                            and still hold the base that keeps the read and the key's slots apart (`lasts`, over every bucket of the key's
                            sequence the walk has seen; no slot with the key: all of them) are negative as well -- counted, not looked at.
                            (A walk that met its key's marker went on along the K-MER's own sequence: its miss stands for itself.) */
                         uint64_t keep = sk_key_persists<W>(kk, k, d.sk.m, ahead_f, ahead_r);
-                        keep = keep < lasts ? keep : lasts;
                         keep = keep < valid_end - (cur + k) ? keep : valid_end - (cur + k);
-                        c_negative += keep;
-                        cur += keep;
+                        if (stands) {
+                            keep = keep < lasts ? keep : lasts;
+                            c_negative += keep;
+                            cur += keep;
+#ifdef SSHASH_STREAM_STATS
+                            st_kept_lane += keep;
+#endif
+                        } else {  // (a heavy key's first k-mer, settled on its own sequence -- found or not: that many k-mers behind it share the key)
+                            where = (where & ~(WALK_HEAVY_PENDING | (WALK_HEAVY << WALK_HEAVY_SHIFT))) | (uint32_t(keep) << WALK_HEAVY_SHIFT);
+                        }
                     }
                 }
             }
@@ -493,9 +550,11 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             if (run >> 15) atomicAdd(wave_moved_out + 3, (unsigned long long)run);  // (past what the lane's 32-bit counter may take in one turn: 2^16 turns lie between two move-outs)
             else c_extensions += uint32_t(run);
             cur += run;
+            if (run) where &= ~WALK_HEAVY_FIELDS;
         }
 #endif
         const bool finishing = live && !walking;  // (a walking lane's seed is settled in a later turn)
+        STAT(st_full, finishing && !settled);
         if (finishing && !settled) {
             /* no table, or a tie / an unplaced key / another shard's key: the complete seed() */
             const minimizer_t mf = compute_minimizer<W>(x, k, d.m, d.hash_magic);
@@ -523,6 +582,14 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             ++cur;
         }
     }
+#ifdef SSHASH_STREAM_STATS
+    const unsigned long long st_neg_kept = wave_sum(st_kept_lane);
+    if (lane == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(report) + 6;
+        atomicAdd(st + 0, st_turns); atomicAdd(st + 1, st_fresh); atomicAdd(st + 2, st_walk); atomicAdd(st + 3, st_ext); atomicAdd(st + 4, st_slot1);
+        atomicAdd(st + 5, st_inv); atomicAdd(st + 6, st_idle); atomicAdd(st + 7, st_full); atomicAdd(st + 8, st_neg_kept); atomicAdd(st + 9, st_short);
+    }
+#endif
     const bool first = lane == 0;  // (what the wave moved out is added once)
     block_report(first ? wave_moved_out[4] : 0, uint64_t(c_invalid) + (first ? wave_moved_out[0] : 0), uint64_t(c_negative) + (first ? wave_moved_out[1] : 0),
                  uint64_t(c_searches) + (first ? wave_moved_out[2] : 0), uint64_t(c_extensions) + (first ? wave_moved_out[3] : 0), report);
@@ -547,7 +614,7 @@ void launch_streaming_runs(device_replica const* rep, dict_view const& d, char c
     /* waves: as many as the chip holds at once -- a lane that finishes its read takes the next of its wave's share, and the longer the
        share, the better the lanes of a wave even out --, fewer for a small call (a piece of a query file: some 10^4 reads, many calls
        side by side on their own streams), down to two reads a lane */
-    const uint64_t max_waves = uint64_t(256) * 4 * 5;  // (what the chip holds of this kernel: five waves a SIMD, 96 registers)  // (what the chip holds of this kernel: 96 registers at k <= 31, 106 at k <= 63)
+    const uint64_t max_waves = uint64_t(256) * 4 * SSHASH_STREAM_WAVES;  // (what the chip holds of this kernel: five waves a SIMD, 96 registers)  // (what the chip holds of this kernel: 96 registers at k <= 31, 106 at k <= 63)
     uint64_t waves = std::min<uint64_t>(max_waves, std::max<uint64_t>(1, n_reads / (64 * 2)));
     waves = (waves + 3) / 4 * 4;
     const uint64_t reads_per_wave = (n_reads + waves - 1) / waves;
