@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/traffic.json from a PMC profile of the bench command (tools/jobs/r05_profile.sh -> <dir>/summary.json + bench.jsonl):
+"""profiles/traffic.json from a PMC profile of the bench command (tools/jobs/r06_profile.sh -> <dir>/summary.json + bench.jsonl):
 HBM bytes per bench step, with the counters, the formula and the commit it was measured at.
 
     python tools/make_traffic_json.py <profile dir> <kept summary path> [record name]
@@ -46,7 +46,7 @@ rec = {
     "per_kernel_bytes": {k: int(v) for k, v in per_kernel.items()},
     "per_launch_counters": {k: {c: int(v) for c, v in pl[k].items() if c.startswith(("TCC", "TCP", "SQ_INSTS_VALU", "SQ_WAVES"))} for k in pl},
     "kernel_avg_ns": {k: ks[k]["avg_ns"] for k in ks},
-    "counters": "rocprofv3 --pmc, one group per pass (tools/jobs/r05_profile.sh)",
+    "counters": "rocprofv3 --pmc, one group per pass (tools/jobs/r06_profile.sh)",
     "commit": subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip(),
     "source": kept,
 }
