@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """RESULTS.md's table from the full record of the driver's command (bench.py --full-record, default bench_full.json):
 
-    python tools/make_results_md.py profiles/r05/bench_driver_command_full.json [driver's BENCH_rNN.json]
+    python tools/make_results_md.py profiles/r06/bench_driver_command_full.json [driver's BENCH_rNN.json]
 
 One row per configuration: the number, its time, roofline fraction on algorithmic bytes, PMC traffic (bytes per unit and fraction of the
 HBM peak), the 64-byte requests against this box's random-line probe, the CPU restatement on the same host. Printed to stdout."""
@@ -43,6 +43,11 @@ for key, w in (full.get("other_workloads") or {}).items():
              else f"{c['queries_per_step'] / 1e9:.1f} G queries/step, {c['device_bytes_per_kmer']} B/k-mer in HBM"))
     print(row(names.get(key, key), what, w))
 for name, v in (full.get("other_paths") or {}).items():
+    if name.startswith("host_"):  # the host-buffer entry points: PCIe inclusive, wall clock of the call
+        what = "sshash_lookup_packed" if name == "host_packed" else "sshash_lookup_ascii (k-mers as characters)"
+        print(f"| C3, host arrays (PCIe inclusive): {what} | {v['queries'] / 1e6:.0f} M queries of the headline batch in page-locked, device-mapped caller arrays; ids equal the device path's | "
+              f"**{g(v['lookups_per_s'])}** G lookups/s | {v['ms']} | | {v['link_GBps_both_directions']} GB/s over the link, both directions together | — | — |")
+        continue
     print(f"| C3 without the table: {name} | 10^8 queries of the headline batch, ids equal the table path's | **{g(v['lookups_per_s'])}** G lookups/s | {v['ms']} | {v['roofline_frac']} | "
           f"{v.get('hbm_traffic_bytes_per_lookup') or '—'} B = {v.get('frac_hbm_traffic') or '—'} | — | — |")
 for name, v in (full.get("other_mixes") or {}).items():
