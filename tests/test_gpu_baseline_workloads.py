@@ -128,10 +128,10 @@ def test_streaming_query_at_the_read_count_of_config_c4(synthetic_case):
     import torch
 
     c, d = synthetic_case, synthetic_case.dict
-    if c.k != 63:
-        pytest.skip("the C4-shaped case")
     dev = torch.device("cuda", 0)
-    R, L, parts = 100_000_000, 150, 10
+    # (round 6: the k = 31 cases too, at a fifth of the reads -- the regular one is the stand-in with the most k-mers under heavy keys, which
+    # is where the run kernel's memory of a heavy key acts: counters of the whole = sum over parts = the position-parallel pipeline's)
+    R, L, parts = (100_000_000 if c.k == 63 else 20_000_000), 150, 10
     total = int(c.endpoints[-1])
     words = torch.from_numpy(c.words.view(np.int64)).to(dev)
     pos = torch.arange(total, dtype=torch.int64, device=dev)
@@ -158,7 +158,7 @@ def test_streaming_query_at_the_read_count_of_config_c4(synthetic_case):
     whole = whole.cpu().numpy()
     assert whole[0] == R * (L - c.k + 1)
     assert whole[0] == whole[1] + whole[2] + whole[3] and whole[1] == whole[4] + whole[5]
-    assert whole[1] > 0.2 * whole[0] and whole[3] > 0 and whole[5] > whole[4]  # hits, N's, mostly extensions
+    assert whole[1] > 0.15 * whole[0] and whole[3] > 0 and whole[5] > whole[4]  # hits, N's, mostly extensions
     summed = np.zeros(6, dtype=np.int64)
     rel = torch.arange(per + 1, dtype=torch.int64, device=dev) * L
     for a in range(0, R, per):
