@@ -1,6 +1,6 @@
 // alloc_modes.hip -- does the random-line rate of a large hipMalloc block depend on WHICH allocation it is (round 6: two processes of one box
 // gave the same replica 37.0 and 41.0 G lookups/s)? Blocks of <GiB> are allocated one after the other and HELD, each probed with 2^27 random
-// 64-byte lines fetched by quads (the table's bucket fetch); then all are freed and the round repeats.   alloc_modes [GiB=37] [blocks=5] [rounds=2]
+// 64-byte lines fetched by quads (the table's bucket fetch); then all are freed and the round repeats.   alloc_modes [GiB=37] [blocks=5] [rounds=2] [contiguous 0|1]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -18,6 +18,7 @@ __global__ void __launch_bounds__(256) probe(const char* __restrict__ a, uint64_
 }
 int main(int argc, char** argv) {
     const uint64_t gib = argc > 1 ? strtoull(argv[1], nullptr, 10) : 37, blocks = argc > 2 ? strtoull(argv[2], nullptr, 10) : 5, rounds = argc > 3 ? strtoull(argv[3], nullptr, 10) : 2;
+    const bool contiguous = argc > 4 && argv[4][0] == '1';  // hipExtMallocWithFlags(hipDeviceMallocContiguous): physically contiguous memory
     const uint64_t bytes = gib << 30, lanes = uint64_t(1) << 29;  // 2^27 lines x 4 lanes
     uint32_t* out = nullptr;
     CHECK(hipMalloc(&out, lanes * 4));
@@ -28,7 +29,8 @@ int main(int argc, char** argv) {
         std::vector<char*> held;
         for (uint64_t b = 0; b < blocks; ++b) {
             char* p = nullptr;
-            CHECK(hipMalloc(&p, bytes));
+            if (contiguous) CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&p), bytes, hipDeviceMallocContiguous));
+            else CHECK(hipMalloc(&p, bytes));
             CHECK(hipMemset(p, 1, bytes));
             held.push_back(p);
             float best = 1e9f;
@@ -41,7 +43,7 @@ int main(int argc, char** argv) {
                 CHECK(hipEventElapsedTime(&ms, e0, e1));
                 if (t && ms < best) best = ms;
             }
-            printf("round %llu block %llu at %p: %.2f G lines/s (%.3f ms per 2^27 random 64-byte lines)\n", (unsigned long long)r, (unsigned long long)b, (void*)p,
+            printf("%sround %llu block %llu at %p: %.2f G lines/s (%.3f ms per 2^27 random 64-byte lines)\n", contiguous ? "contiguous " : "", (unsigned long long)r, (unsigned long long)b, (void*)p,
                    double(lanes / 4) / best / 1e6, best);
             fflush(stdout);
         }
