@@ -324,12 +324,12 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             }
             c_invalid = c_negative = c_searches = c_extensions = 0;
         }
-#ifndef SSHASH_STREAM_RUN_AFTER_SEED
         /* -- the run behind the hit of the turn before, THEN this turn's seed (round 6): the lane measures its run and goes straight on to
               whatever lies behind it in the same turn -- the negative over the substitution that ended the run, as a rule; the NEXT READ when
               the run reached the end of this one (which is why the run comes before the reads are handed out). Until round 5 a lane did one
               or the other in a turn (the run's first loads travelled beside the seeds' bucket lines: one wait for both), and a hit -- run --
-              miss cycle took a turn more than it has events. (`pending` is only set when the k-mer behind the hit lies inside the read's
+              miss cycle took a turn more than it has events (that order, as a build of this file, is the "run after seed" column of
+              profiles/r06/streaming_*_ab.txt). (`pending` is only set when the k-mer behind the hit lies inside the read's
               valid bases: no test of its own here.) -- */
         STAT(st_ext, pending);
         if (pending) {
@@ -341,7 +341,6 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
             if (run) where &= ~WALK_HEAVY_FIELDS;  // (the k-mer behind a run elects a key of its own)
         }
         pending = false;
-#endif
         /* -- the reads: whoever has none left takes the next of the wave's share -- */
         const bool want = !walking && cur + k > rd_end;
         const uint64_t wants = __ballot(want);
@@ -383,18 +382,6 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
         }
         c_invalid += c_invalid_turn;
         const uint64_t valid_end = inv < rd_end ? inv : rd_end;
-#ifdef SSHASH_STREAM_RUN_AFTER_SEED
-        /* -- this turn's event of the lane: the run behind the hit of the turn before, or a seed -- */
-        /* (the run's first 32 bases are asked for here and looked at behind the seeds' part of the turn: the strings' atom is a line
-           from HBM like a bucket, and the wave waits once for both) */
-        const bool extending = live && pending;
-        run_step_t first_step{};
-        if (extending) {
-            if constexpr (W == 1) first_step = run_step_load<W>(d, packed, off, ori > 0, cur + k - 1, 0);  // (k <= 63: the nine registers this holds across the turn cost the fifth wave)
-            live = false;  // (its next k-mer waits for the next turn: it may lie over an invalid base, or in the next read)
-        }
-        pending = false;
-#endif
         /* -- seed() at cur (streaming_query.hpp:144-197): the k-mer, its key, its key's first bucket; a lane in the middle of a walk
               (its key's first bucket was not the end of it) keeps its k-mer and comes with the walk's next bucket instead -- */
         uint64_t ahead_f = 0, ahead_r = 0;
@@ -543,16 +530,6 @@ streaming_run_kernel(const dict_view d, const skew_part_dev* __restrict__ skew, 
                 }
             }
         }
-#ifdef SSHASH_STREAM_RUN_AFTER_SEED
-        if (extending) {
-            if constexpr (W == 2) first_step = run_step_load<W>(d, packed, off, ori > 0, cur + k - 1, 0);
-            const uint64_t run = extend_run<W>(d, packed, off, ori, cur + k - 1, valid_end - (cur + k - 1), first_step);
-            if (run >> 15) atomicAdd(wave_moved_out + 3, (unsigned long long)run);  // (past what the lane's 32-bit counter may take in one turn: 2^16 turns lie between two move-outs)
-            else c_extensions += uint32_t(run);
-            cur += run;
-            if (run) where &= ~WALK_HEAVY_FIELDS;
-        }
-#endif
         const bool finishing = live && !walking;  // (a walking lane's seed is settled in a later turn)
         STAT(st_full, finishing && !settled);
         if (finishing && !settled) {
