@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: same-box A/B of two builds of the streaming kernel -- the shipped library against tools/ab/libvariant_*.so (built with
+# round 6: same-box A/B of builds of the streaming kernel (how every streaming_*_ab.txt of profiles/r06 was made; the lane statistics:
+# r06_stream_stats.sh over tools/ab_stats/) -- the shipped library against tools/ab/libvariant_*.so (built with
 # `make -C sshash_amd/csrc DEFS=-D...`, copied aside, default rebuilt) -- on the bench's read sets, alternating, counters printed (they must agree).
 cd "$(dirname "$0")/../.."
 out=gpurun_out/${1:-r06_stream_ab}; mkdir -p $out
